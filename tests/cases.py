@@ -1,0 +1,68 @@
+"""Shared helpers for the parity tests: rebuild a stored LMC case.
+
+The .npz fixtures under tests/golden/ hold INPUTS (seeded, stored, never
+re-drawn) and the reference's OUTPUTS for them (tests/golden/make_golden.py).
+"""
+import os
+
+import numpy as np
+import scipy.sparse
+
+from oracle.kernels import KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def kernel_from_desc(desc):
+    parts = str(desc).split(';')
+    kind, vals = parts[0], [float(v) for v in parts[1:]]
+    if kind == 'rbf':
+        return RBFSpec(*vals)
+    if kind == 'matern':
+        return Matern32Spec(*vals)
+    if kind == 'periodic':
+        return StdPeriodicSpec(*vals)
+    raise ValueError(kind)
+
+
+class Case:
+    """One golden LMC case: inputs as attributes, reference outputs in .g"""
+
+    def __init__(self, name):
+        g = np.load(os.path.join(GOLDEN, name + '.npz'))
+        self.g = g
+        self.name = name
+        self.D, self.Q, self.m = int(g['D']), int(g['Q']), int(g['m'])
+        self.lens = [int(v) for v in g['lens']]
+        self.n = sum(self.lens)
+        self.grid_dists = g['grid_dists']
+        self.noise = g['noise']
+        self.y = g['y']
+        self.coreg_vecs = [g[f'A{q}'] for q in range(self.Q)]
+        self.coreg_diags = [g[f'kappa{q}'] for q in range(self.Q)]
+        self.kdesc = [str(k) for k in g['kdesc']]
+        self.W = scipy.sparse.csr_matrix(
+            (g['W_data'], g['W_indices'], g['W_indptr']),
+            shape=(self.n, self.D * self.m))
+        self.WT = scipy.sparse.csr_matrix(
+            (g['WT_data'], g['WT_indices'], g['WT_indptr']),
+            shape=(self.D * self.m, self.n))
+        self.Xs = [g[f'X{d}'] for d in range(self.D)]
+        self.Ys = np.split(self.y, np.cumsum(self.lens)[:-1])
+        self.rs = g['rs']
+        self.tops = g['tops']
+
+    def spec(self):
+        sp = KernelSpec(self.D, [kernel_from_desc(k) for k in self.kdesc],
+                        self.coreg_vecs, self.coreg_diags, self.noise)
+        sp.set_input_dim(1)
+        return sp
+
+    def dtops(self):
+        cnt = self.g['dtops_count']
+        return [[self.g[f'dtop{q}_{p}'] for p in range(int(cnt[q]))]
+                for q in range(self.Q)]
+
+
+ALL_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid']
+DENSE_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1']

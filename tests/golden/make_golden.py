@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (vlad17/runlmc).
+
+Run in the build container only (needs /root/reference, which does not exist
+on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own runlmc.linalg / runlmc.approx / runlmc.lmc
+modules, feeds them seeded inputs, and stores inputs + reference outputs as
+small .npz files next to this script.  The fixtures are data only.
+
+Two shims are needed to run the reference in this image:
+  1. SciPy >= 1.14 renamed minres/cg ``tol`` to ``rtol``; the reference passes
+     ``tol=`` (runlmc/approx/iterative.py:50-51).
+  2. runlmc.lmc.functional_kernel and runlmc.kern.* need paramz (absent); the
+     reference's gen_grid_kernel / ApproxLMCLikelihood only need a duck-typed
+     kernel spec, supplied by oracle.kernels.KernelSpec (data holder; all
+     operator maths below is executed by reference code).
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.linalg as la
+import scipy.sparse.linalg as sla
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+# --- shim 1: tol -> rtol -----------------------------------------------------
+_orig_minres, _orig_cg = sla.minres, sla.cg
+
+
+def _minres(A, b, tol=None, **kw):
+    if tol is not None:
+        kw['rtol'] = tol
+    return _orig_minres(A, b, **kw)
+
+
+def _cg(A, b, tol=None, **kw):
+    if tol is not None:
+        kw['rtol'] = tol
+    return _orig_cg(A, b, **kw)
+
+
+sla.minres, sla.cg = _minres, _cg
+
+from runlmc.linalg.bttb import BTTB  # noqa: E402
+from runlmc.linalg.toeplitz import Toeplitz  # noqa: E402
+from runlmc.linalg.kronecker import Kronecker  # noqa: E402
+from runlmc.linalg.numpy_matrix import NumpyMatrix  # noqa: E402
+from runlmc.linalg.sum_matrix import SumMatrix  # noqa: E402
+from runlmc.linalg.diag import Diag  # noqa: E402
+from runlmc.approx.interpolation import (  # noqa: E402
+    cubic_kernel, interp_cubic, multi_interpolant, autogrid)
+from runlmc.approx.iterative import Iterative  # noqa: E402
+from runlmc.lmc.grid_kernel import GridKernel, gen_grid_kernel  # noqa: E402
+from runlmc.lmc.likelihood import ApproxLMCLikelihood  # noqa: E402
+from runlmc.lmc.stochastic_deriv import StochasticDeriv  # noqa: E402
+from runlmc.lmc.exact_deriv import ExactDeriv  # noqa: E402
+from runlmc.util.inline_pool import InlinePool  # noqa: E402
+
+from oracle.kernels import (  # noqa: E402
+    KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec)
+
+
+def _save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+# ---------------------------------------------------------------------------
+# 1. structured operators: the reference's own unit-test examples
+#    (runlmc/linalg/test_bttb.py:14-24, test_toeplitz.py:18-35,
+#     test_matrix_base.py:33-47, test_kronecker.py:19-61)
+# ---------------------------------------------------------------------------
+def gen_linalg():
+    rng = np.random.RandomState(20240101)
+    out = {}
+    shapes = [(1,), (3,), (2, 3), (10,), (100,), (2, 3, 4)]
+    tops = [np.arange(int(np.prod(s)), dtype=float).reshape(s) for s in shapes]
+    tops += [rng.rand(*s) for s in shapes]
+    out['bttb_count'] = len(tops)
+    for i, t in enumerate(tops):
+        M = BTTB(t.ravel(), t.shape)
+        n = t.size
+        out[f'bttb{i}_top'] = t.ravel()
+        out[f'bttb{i}_sizes'] = np.array(t.shape)
+        out[f'bttb{i}_dense'] = M.as_numpy()
+        out[f'bttb{i}_matvec'] = M.matvec(np.arange(n) + 1)
+        out[f'bttb{i}_matmat'] = M.matmat(np.arange(2 * n).reshape(-1, 2))
+    # hand-written known answers test_bttb.py:26-68 are exact restatements of
+    # as_numpy(); store the 2-D and 3-D tops used there
+    top2 = np.array([[4, 3, 2, 1], [3, 2, 1, 0], [2, 1, 0, 0]], dtype=float)
+    out['bttb_known2d_top'] = top2
+    out['bttb_known2d_dense'] = BTTB(top2.ravel(), top2.shape).as_numpy()
+    top3 = np.array([[[4, 3], [2, 1]], [[3, 2], [1, 0]], [[2, 1], [0, 0]]],
+                    dtype=float)
+    out['bttb_known3d_top'] = top3
+    out['bttb_known3d_dense'] = BTTB(top3.ravel(), top3.shape).as_numpy()
+
+    eigtol = 1e-6
+
+    def toep_eig(e, mult):  # test_matrix_base.py:22-30
+        o = np.ones(mult + 1) * 1 - e
+        o[0] = 1
+        return o
+
+    ttops = [[1], [1, 0], [1, 1], [0, 0], [1, -1],
+             [3.5] + [0.999] * 5 + [0] * 110,
+             toep_eig(eigtol / 2, 5), toep_eig(eigtol, 5),
+             toep_eig(eigtol * 2, 5), (np.arange(10) + 1)[::-1],
+             np.exp(-rng.rand() * np.arange(10)),
+             np.exp(-rng.rand() * np.arange(50)),
+             np.exp(-rng.rand() * np.arange(100))]
+    out['toep_count'] = len(ttops)
+    for i, t in enumerate(ttops):
+        t = np.array(t, dtype=float)
+        M = Toeplitz(t)
+        n = len(t)
+        out[f'toep{i}_top'] = t
+        out[f'toep{i}_matvec'] = M.matvec(np.arange(n) + 1)
+        out[f'toep{i}_matmat'] = M.matmat(np.arange(2 * n).reshape(-1, 2))
+        out[f'toep{i}_dense'] = M.as_numpy()
+
+    # Kronecker(NumpyMatrix(B), BTTB/Toeplitz) and SumMatrix of those
+    def rpsd(n):  # test_matrix_base.py:16-20
+        A = rng.randint(-10, 10, (n, n))
+        A = (A + A.T).astype(np.float64)
+        A += np.diag(np.fabs(A).sum(axis=1) + 1)
+        return A
+
+    krons = [(rpsd(5), np.exp(-rng.rand() * np.arange(10))),
+             (rpsd(5), np.exp(-rng.rand() * np.arange(100))),
+             (rpsd(3), (np.arange(10)[::-1] + 1).astype(float)),
+             (la.hilbert(3), rng.rand(37))]
+    out['kron_count'] = len(krons)
+    terms = []
+    for i, (B, t) in enumerate(krons):
+        K = Kronecker(NumpyMatrix(B), BTTB(t, t.shape))
+        n = K.shape[0]
+        out[f'kron{i}_B'] = B
+        out[f'kron{i}_top'] = t
+        out[f'kron{i}_matvec'] = K.matvec(np.arange(n) + 1)
+        out[f'kron{i}_matmat'] = K.matmat(np.arange(2 * n).reshape(-1, 2))
+        out[f'kron{i}_dense'] = K.as_numpy()
+        terms.append((B, t))
+    # a SumMatrix of three Kronecker terms on a common (D=4, m=60) shape
+    Bs = [rpsd(4) for _ in range(3)]
+    ts = [np.exp(-(q + 1) * 0.3 * np.arange(60)) for q in range(3)]
+    S = SumMatrix([Kronecker(NumpyMatrix(B), BTTB(t, t.shape))
+                   for B, t in zip(Bs, ts)])
+    out['sum_Bs'] = np.array(Bs)
+    out['sum_tops'] = np.array(ts)
+    x = rng.randn(240)
+    out['sum_x'] = x
+    out['sum_matvec'] = S.matvec(x)
+    _save('linalg.npz', **out)
+
+
+# ---------------------------------------------------------------------------
+# 2. interpolation (runlmc/approx/interpolation.py; test_interpolation.py)
+# ---------------------------------------------------------------------------
+def gen_interp():
+    rng = np.random.RandomState(7)
+    out = {}
+    s = np.linspace(-2, 2, 41)
+    out['cubic_in'] = s
+    out['cubic_out'] = cubic_kernel(s)
+    grid = np.linspace(0, 1, 12)
+    samples = np.concatenate([rng.rand(20), [0.0, 1.0, -0.05, 1.07, 0.5]])
+    out['ic_grid'] = grid
+    out['ic_samples'] = samples
+    out['ic_dense'] = interp_cubic(grid, samples).toarray()
+    Xs = [rng.rand(13, 1), rng.rand(7, 1) * 0.8 + 0.1, rng.rand(10, 1)]
+    g = autogrid(Xs, lo=None, hi=None, m=None)[0]
+    out['ag_default'] = g
+    out['ag_m25'] = autogrid(Xs, lo=None, hi=None, m=np.array([25]))[0]
+    Wm = multi_interpolant(Xs, g)
+    out['mi_X0'], out['mi_X1'], out['mi_X2'] = [X.ravel() for X in Xs]
+    out['mi_dense'] = Wm.toarray()
+    out['mi_indptr'], out['mi_indices'], out['mi_data'] = (
+        Wm.indptr, Wm.indices, Wm.data)
+    _save('interp.npz', **out)
+
+
+# ---------------------------------------------------------------------------
+# 3. LMC operator, solves, gradients
+# ---------------------------------------------------------------------------
+def _kernel_from_desc(desc):
+    kind = desc[0]
+    if kind == 'rbf':
+        return RBFSpec(desc[1])
+    if kind == 'matern':
+        return Matern32Spec(desc[1])
+    if kind == 'periodic':
+        return StdPeriodicSpec(desc[1], desc[2])
+    raise ValueError(kind)
+
+
+def _lmc_case(name, seed, D, kdescs, ranks, lens, m, noise_scale=0.1,
+              n_probes=6, dense=True, store_dense=True, n_mv=3):
+    """One seeded LMC model run through the reference's operator, solver and
+    gradient code.  Stores inputs and outputs in tests/golden/<name>.npz."""
+    rng = np.random.RandomState(seed)
+    Q = len(kdescs)
+    coreg_vecs = [rng.uniform(-1, 1, size=(r, D)) for r in ranks]
+    coreg_diags = [1.0 / rng.gamma(2.0, 1.0, size=D) for _ in range(Q)]
+    noise = noise_scale * (0.5 + rng.rand(D))
+    Xs = [np.sort(rng.rand(n)).reshape(-1, 1) for n in lens]
+    Ys = [np.sin(6 * X.ravel() + d) + 0.1 * rng.randn(len(X))
+          for d, X in enumerate(Xs)]
+    y = np.hstack(Ys)
+    n = sum(lens)
+
+    grid = autogrid(Xs, lo=None, hi=None, m=np.array([float(m)]))[0]
+    grid_dists = grid - grid[0]
+    W = multi_interpolant(Xs, grid)
+    WT = W.transpose().tocsr()
+    mgrid = len(grid)
+
+    def new_spec():
+        sp = KernelSpec(D, [_kernel_from_desc(k) for k in kdescs],
+                        coreg_vecs, coreg_diags, noise)
+        sp.set_input_dim(1)
+        return sp
+
+    out = dict(D=D, Q=Q, ranks=np.array(ranks), lens=np.array(lens),
+               m=mgrid, grid=grid, grid_dists=grid_dists,
+               kdesc=np.array([';'.join(str(v) for v in k) for k in kdescs]),
+               noise=noise, y=y,
+               W_indptr=W.indptr, W_indices=W.indices, W_data=W.data,
+               WT_indptr=WT.indptr, WT_indices=WT.indices, WT_data=WT.data)
+    for q in range(Q):
+        out[f'A{q}'] = coreg_vecs[q]
+        out[f'kappa{q}'] = coreg_diags[q]
+    for d in range(D):
+        out[f'X{d}'] = Xs[d].ravel()
+
+    spec = new_spec()
+    ad = (0,)
+    tops = spec.eval_kernels_fixed_dim(grid_dists, ad)
+    out['tops'] = tops
+    dt = spec.eval_kernel_gradients({ad: grid_dists})
+    out['dtops_count'] = np.array([len(g) for g in dt])
+    for q, gl in enumerate(dt):
+        for p, g in enumerate(gl):
+            out[f'dtop{q}_{p}'] = g
+
+    # grid MVM in all three representations (reference grid_kernel.py:22-44)
+    gx = rng.randn(n_mv, D * mgrid)
+    out['grid_x'] = gx
+    for kt in ('sum', 'bt', 'slfm'):
+        gk = GridKernel(spec, grid_dists, W, WT, kt, ad)
+        out[f'grid_mv_{kt}'] = np.array([gk.grid_K.matvec(v) for v in gx])
+    # full operator, auto-selected representation (gen_grid_kernel)
+    K, _ = gen_grid_kernel(spec, {ad: grid_dists}, {ad: (W, WT)}, lens)
+    xx = rng.randn(n_mv, n)
+    out['full_x'] = xx
+    out['full_mv'] = np.array([K.matvec(v) for v in xx])
+
+    # probes, explicit (reference would draw from the global RNG,
+    # stochastic_deriv.py:35)
+    rs = rng.randint(0, 2, (n_probes, n)) * 2 - 1
+    out['rs'] = rs
+
+    if dense:
+        Kd = K.as_numpy()
+        Kd = 0.5 * (Kd + Kd.T)
+        if store_dense:
+            out['K_dense'] = Kd
+        c = la.cho_factor(Kd)
+        alpha = la.cho_solve(c, y)
+        inv_rs = la.cho_solve(c, rs.T.astype(float)).T
+        out['alpha_dense'] = alpha
+        out['inv_rs_dense'] = inv_rs
+        out['logdet_dense'] = 2 * np.sum(np.log(np.diag(c[0])))
+
+        # the reference's gradient loops, fed the dense solves + fixed probes
+        class _FixedDeriv:
+            def generate(self, K_, y_):
+                return StochasticDeriv(alpha, rs, inv_rs, n_probes)
+
+        lik = ApproxLMCLikelihood(spec, K, {ad: grid_dists}, {ad: (W, WT)},
+                                  Ys, _FixedDeriv())
+        gv = lik.coreg_vec_gradients()
+        gd = lik.coreg_diags_gradients()
+        gkk = lik.kernel_gradients()
+        gn = lik.noise_gradient()
+        for q in range(Q):
+            out[f'grad_A{q}'] = gv[q]
+            out[f'grad_kappa{q}'] = gd[q]
+            out[f'grad_kern{q}'] = np.array(gkk[q])
+        out['grad_noise'] = gn
+
+        # exact-trace gradients with the same (SKI) dense K: what the
+        # Hutchinson estimate converges to
+        ed = ExactDeriv(c, y)
+
+    # the reference's own MINRES wrapper (iterates, counts, residuals)
+    sols = [Iterative.solve(K, rhs, verbose=True, minres=True, tol=1e-4)
+            for rhs in [y] + [r.astype(float) for r in rs[:2]]]
+    out['ref_minres_x'] = np.array([s[0] for s in sols])
+    out['ref_minres_iters'] = np.array([s[1] for s in sols])
+    out['ref_minres_err'] = np.array([s[2] for s in sols])
+    sols = [Iterative.solve(K, rhs, verbose=True, minres=False, tol=1e-4)
+            for rhs in [y]]
+    out['ref_cg_x'] = np.array([s[0] for s in sols])
+    out['ref_cg_iters'] = np.array([s[1] for s in sols])
+    out['ref_cg_err'] = np.array([s[2] for s in sols])
+    _save(name + '.npz', **out)
+
+
+def gen_lmc():
+    # small mixed-kernel model, every gradient family, dense K stored
+    _lmc_case('lmc_small', seed=11, D=3,
+              kdescs=[('rbf', 2.0), ('matern', 1.5), ('periodic', 1.0, 0.7)],
+              ranks=[2, 1, 1], lens=[40, 55, 35], m=28, n_probes=6)
+    # notebook/README-like C1: D=2, two RBF kernels rank 1, n=[65,100]
+    # (examples/example.ipynb cell 1; default m = mean n_d = 82 (+4))
+    _lmc_case('lmc_c1', seed=12, D=2,
+              kdescs=[('rbf', 1.0), ('rbf', 20.0)],
+              ranks=[1, 1], lens=[65, 100], m=82, n_probes=8,
+              store_dense=False)
+    # Q == 1 (auto 'sum'), higher rank, D=5: FX2007-shaped in miniature
+    _lmc_case('lmc_q1', seed=13, D=5, kdescs=[('rbf', 8.0)], ranks=[2],
+              lens=[30, 25, 40, 35, 20], m=40, n_probes=4, store_dense=False)
+    # four-step FFT territory: L = 4096, D*L too big for the one-workgroup
+    # path; vectors only
+    _lmc_case('lmc_mid', seed=14, D=6,
+              kdescs=[('rbf', 30.0), ('matern', 10.0), ('rbf', 300.0)],
+              ranks=[1, 2, 1], lens=[300, 280, 310, 290, 305, 295], m=1100,
+              n_probes=2, dense=False, n_mv=2)
+
+
+if __name__ == '__main__':
+    gen_linalg()
+    gen_interp()
+    gen_lmc()
