@@ -1,0 +1,101 @@
+/* runlmc_hip.h -- C ABI of the MI355X-native LMC inference hot path.
+ *
+ * Drop-in boundary for vlad17/runlmc's matrix-free path.  Every entry point
+ * names the reference interface it replaces (file:line in the reference
+ * tree).  INTEGRATION.md shows the ctypes binding a runlmc maintainer adds.
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on failure;
+ *     rl_last_error() then holds a message (thread-local).  Shape / argument
+ *     errors are RL_EINVAL (the Python wrapper raises ValueError, as the
+ *     reference does: runlmc/linalg/matrix.py:20-21, bttb.py:93-101).
+ *   - "host" pointers are ordinary CPU memory, copied during the call.
+ *   - "dev" pointers are device memory owned by the caller (e.g.
+ *     torch.Tensor.data_ptr()); fp64, contiguous, vectors stored one after
+ *     another: X[v][i].  Grid vectors are output-major, index d*m + i
+ *     (reference kronecker.py:42-46); data vectors are the concatenation of
+ *     the outputs (reference likelihood.py:30-31).
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls enqueue work
+ *     and return; rl_solve_batch / rl_*_host helpers synchronise themselves.
+ *   - handles are not thread-safe; one handle per device.
+ */
+#ifndef RUNLMC_HIP_H
+#define RUNLMC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL_OK 0
+#define RL_EINVAL 1   /* bad argument / shape */
+#define RL_EHIP 2     /* HIP runtime error */
+#define RL_ENOMEM 3
+#define RL_ELIMIT 4   /* problem exceeds a documented kernel limit */
+
+typedef struct rl_gridop rl_gridop;
+typedef struct rl_ski rl_ski;
+
+const char* rl_last_error(void);
+/* "hip-gfx950" for the product library. */
+const char* rl_backend(void);
+int rl_device_count(int* count);
+
+/* ---- grid operator  K_UU = sum_q B_q (x) T_q  ------------------------------
+ * Replaces BTTB.__init__/_cyclic_extend_n (runlmc/linalg/bttb.py:91-120),
+ * BTTB.matvec (bttb.py:144-148), Kronecker.matvec (kronecker.py:39-46),
+ * SumMatrix.matvec (sum_matrix.py:31-32) and the three grid representations
+ * _gen_sum_grid/_gen_bt_grid/_gen_slfm_grid (runlmc/lmc/grid_kernel.py:77-136),
+ * which are the same linear operator.
+ *   D outputs, m grid points (1-D grid), embedding length L = pow2 >= 2m
+ *   (>= 16).  max_tops bounds Q in later rl_gridop_set_* calls.            */
+int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out);
+int rl_gridop_destroy(rl_gridop* g);
+/* L = N1*N2 and tile parameters actually chosen (any pointer may be NULL). */
+int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int* rowsB);
+
+/* Parameters of the LMC kernel, in the reference's own factored form
+ * B_q = A_q^T A_q + diag(kappa_q) (runlmc/lmc/functional_kernel.py:280-287):
+ *   tops        host [Q][m]   first rows k_q(grid distances)
+ *   ranks       host [Q]      R_q >= 0
+ *   coreg_vecs  host [sum R_q][D]   rows of A_0, then A_1, ...
+ *   coreg_diags host [Q][D]
+ * Rebuilds the Q circulant spectra on the device (per optimiser step).      */
+int rl_gridop_set_lmc(rl_gridop* g, int Q, const double* tops, const int* ranks,
+                      const double* coreg_vecs, const double* coreg_diags);
+/* Same with arbitrary symmetric B_q given densely, host [Q][D][D]
+ * (Kronecker(NumpyMatrix(B), BTTB(top)), kronecker.py:30-46).               */
+int rl_gridop_set_dense(rl_gridop* g, int Q, const double* tops, const double* B);
+
+/* Y[v] = K_UU X[v], v < nvec.  X, Y dev [nvec][D*m]; may not alias.         */
+int rl_gridop_mvm(rl_gridop* g, const double* X, double* Y, int nvec, void* stream);
+/* Y[v] = (I_D (x) T_q) X[v]: one top row applied to every output block
+ * (BTTB.matmat, matrix.py:55-67 + bttb.py:144-148).                          */
+int rl_gridop_mvm_top(rl_gridop* g, int q, const double* X, double* Y, int nvec, void* stream);
+/* Circulant spectrum of top q in NATURAL frequency order, host out[L]
+ * (test hook; the reference's BTTB._circ_fft real part, bttb.py:108).       */
+int rl_gridop_spectrum_host(rl_gridop* g, int q, double* out);
+
+/* ---- SKI operator  K~ = W K_UU W^T + diag(eps)  ----------------------------
+ * Replaces SKI / Composition.matvec (runlmc/approx/ski.py:8-16,
+ * linalg/composition.py:14-17), Diag.matvec (linalg/diag.py:24-25) and the
+ * SumMatrix assembled by gen_grid_kernel (lmc/grid_kernel.py:70-74).
+ *   W   CSR n x (D*m)  (host; int32 indices; reference
+ *       approx/interpolation.py:119-176), WT its transpose in CSR.
+ * The handle keeps a pointer to `g` (not owned).                              */
+int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int* W_indices,
+                  const double* W_data, const int* WT_indptr, const int* WT_indices,
+                  const double* WT_data, rl_ski** out);
+int rl_ski_destroy(rl_ski* s);
+/* noise host [D], lens host [D] (sum lens == n): eps repeated per output
+ * (np.repeat(noise, lens), grid_kernel.py:70).                               */
+int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens);
+/* Y[v] = K~ X[v];  X, Y dev [nvec][n]; may not alias.                        */
+int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void* stream);
+/* G[v] = W^T X[v] (dev [nvec][D*m])  /  Y[v] = W G[v] (dev [nvec][n]).      */
+int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream);
+int rl_ski_apply_w(rl_ski* s, const double* G, double* Y, int nvec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUNLMC_HIP_H */

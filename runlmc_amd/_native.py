@@ -1,0 +1,200 @@
+"""Thin object wrappers over the C ABI handles (device-resident state).
+
+These are the only places that call into the native library.  torch tensors
+are used purely as device-memory handles (allocation + lifetime + streams).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import host_ptr, dev_ptr, as_f64
+
+
+def _vec_batch(lib, X, width, device):
+    """Accept (width,) / (k, width) numpy or torch input, return a contiguous
+    float64 tensor of shape (k, width) on `device` plus a flag telling
+    whether the input was a single vector."""
+    if isinstance(X, torch.Tensor):
+        t = X
+        if t.dtype != torch.float64:
+            raise TypeError('device vectors must be float64')
+    else:
+        t = torch.from_numpy(as_f64(X))
+    single = t.dim() == 1
+    if single:
+        t = t.unsqueeze(0)
+    if t.dim() != 2 or t.shape[1] != width:
+        raise ValueError('expected vectors of length %d, got shape %s'
+                         % (width, tuple(X.shape)))
+    return t.to(device).contiguous(), single
+
+
+class GridOp:
+    """Device handle of K_UU = sum_q B_q (x) T_q  (include/runlmc_hip.h)."""
+
+    def __init__(self, D, m, max_tops, device_index=0, lib=None):
+        self.lib = lib or _lib.get_library()
+        self.D, self.m, self.max_tops = int(D), int(m), int(max_tops)
+        self.device = self.lib.torch_device(device_index)
+        self.device_index = device_index
+        self._h = ctypes.c_void_p()
+        self.lib.call('rl_gridop_create', device_index, self.D, self.m,
+                      self.max_tops, ctypes.byref(self._h))
+        info = [ctypes.c_int() for _ in range(5)]
+        self.lib.call('rl_gridop_info', self._h, *[ctypes.byref(i) for i in info])
+        self.L, self.N1, self.N2, self.colsA, self.rowsB = [i.value for i in info]
+        self.Q = 0
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self.lib.cdll.rl_gridop_destroy(h)
+            self._h = ctypes.c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def width(self):
+        return self.D * self.m
+
+    def _tops(self, tops):
+        tops = as_f64(tops)
+        if tops.ndim != 2 or tops.shape[1] != self.m:
+            raise ValueError('tops must have shape (Q, %d), got %s'
+                             % (self.m, tops.shape))
+        return tops
+
+    def set_lmc(self, tops, coreg_vecs, coreg_diags):
+        """B_q = A_q^T A_q + diag(kappa_q); coreg_vecs[q] is (R_q, D) (or
+        empty), coreg_diags[q] is (D,)."""
+        tops = self._tops(tops)
+        Q = tops.shape[0]
+        if len(coreg_vecs) != Q or len(coreg_diags) != Q:
+            raise ValueError('need one coreg_vec block and one coreg_diag per kernel')
+        rows, ranks = [], []
+        for a in coreg_vecs:
+            a = np.zeros((0, self.D)) if a is None else np.atleast_2d(as_f64(a))
+            if a.size and a.shape[1] != self.D:
+                raise ValueError('coreg_vec block must be (R, %d)' % self.D)
+            ranks.append(a.shape[0] if a.size else 0)
+            if a.size:
+                rows.append(a)
+        vecs = (np.ascontiguousarray(np.vstack(rows)) if rows
+                else np.zeros((0, self.D)))
+        diags = np.ascontiguousarray(
+            np.vstack([as_f64(k).reshape(1, -1) for k in coreg_diags]))
+        if diags.shape != (Q, self.D):
+            raise ValueError('coreg_diags must be Q x D')
+        ranks = np.ascontiguousarray(np.array(ranks, dtype=np.int32))
+        self.lib.call('rl_gridop_set_lmc', self._h, Q, host_ptr(tops),
+                      host_ptr(ranks), host_ptr(vecs) if vecs.size else None,
+                      host_ptr(diags))
+        self.Q = Q
+
+    def set_dense(self, tops, Bs):
+        tops = self._tops(tops)
+        Q = tops.shape[0]
+        Bs = as_f64(Bs)
+        if Bs.shape != (Q, self.D, self.D):
+            raise ValueError('B must have shape (Q, D, D)')
+        self.lib.call('rl_gridop_set_dense', self._h, Q, host_ptr(tops),
+                      host_ptr(Bs))
+        self.Q = Q
+
+    def mvm(self, X, out=None, top=None):
+        """Device-side product; X: (k, D*m) tensor on self.device."""
+        k = X.shape[0]
+        if out is None:
+            out = torch.empty_like(X)
+        sp = self.lib.stream_ptr(self.device)
+        if top is None:
+            self.lib.call('rl_gridop_mvm', self._h, dev_ptr(X), dev_ptr(out), k, sp)
+        else:
+            self.lib.call('rl_gridop_mvm_top', self._h, int(top), dev_ptr(X),
+                          dev_ptr(out), k, sp)
+        return out
+
+    def matmat_host(self, X, top=None):
+        """numpy in, numpy out; X is (D*m,) or (k, D*m) (vectors as ROWS)."""
+        t, single = _vec_batch(self.lib, X, self.width, self.device)
+        y = self.mvm(t, top=top).cpu().numpy()
+        return y[0] if single else y
+
+    def spectrum(self, q):
+        out = np.empty(self.L)
+        self.lib.call('rl_gridop_spectrum_host', self._h, int(q), host_ptr(out))
+        return out
+
+
+class SkiOp:
+    """Device handle of K~ = W K_UU W^T + diag(eps)."""
+
+    def __init__(self, gridop, W, WT):
+        self.lib = gridop.lib
+        self.grid = gridop
+        self.device = gridop.device
+        n, ng = W.shape
+        if ng != gridop.width:
+            raise ValueError('W has %d columns, grid operator has %d points'
+                             % (ng, gridop.width))
+        if WT.shape != (ng, n):
+            raise ValueError('WT must be the transpose of W')
+        W = W.tocsr()
+        WT = WT.tocsr()
+        self.n = int(n)
+        arrs = [np.ascontiguousarray(W.indptr, dtype=np.int32),
+                np.ascontiguousarray(W.indices, dtype=np.int32),
+                as_f64(W.data),
+                np.ascontiguousarray(WT.indptr, dtype=np.int32),
+                np.ascontiguousarray(WT.indices, dtype=np.int32),
+                as_f64(WT.data)]
+        self._h = ctypes.c_void_p()
+        self.lib.call('rl_ski_create', gridop.handle, self.n,
+                      *[host_ptr(a) for a in arrs], ctypes.byref(self._h))
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self.lib.cdll.rl_ski_destroy(h)
+            self._h = ctypes.c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_noise(self, noise, lens):
+        noise = as_f64(noise)
+        lens = np.ascontiguousarray(np.asarray(lens), dtype=np.int32)
+        if noise.shape != (self.grid.D,) or lens.shape != (self.grid.D,):
+            raise ValueError('noise and lens must have one entry per output')
+        self.lib.call('rl_ski_set_noise', self._h, host_ptr(noise), host_ptr(lens))
+
+    def mvm(self, X, out=None):
+        if out is None:
+            out = torch.empty_like(X)
+        self.lib.call('rl_ski_mvm', self._h, dev_ptr(X), dev_ptr(out),
+                      X.shape[0], self.lib.stream_ptr(self.device))
+        return out
+
+    def apply_wt(self, X):
+        out = torch.empty((X.shape[0], self.grid.width), dtype=torch.float64,
+                          device=self.device)
+        self.lib.call('rl_ski_apply_wt', self._h, dev_ptr(X), dev_ptr(out),
+                      X.shape[0], self.lib.stream_ptr(self.device))
+        return out
+
+    def apply_w(self, G):
+        out = torch.empty((G.shape[0], self.n), dtype=torch.float64,
+                          device=self.device)
+        self.lib.call('rl_ski_apply_w', self._h, dev_ptr(G), dev_ptr(out),
+                      G.shape[0], self.lib.stream_ptr(self.device))
+        return out
+
+    def matmat_host(self, X):
+        t, single = _vec_batch(self.lib, X, self.n, self.device)
+        y = self.mvm(t).cpu().numpy()
+        return y[0] if single else y

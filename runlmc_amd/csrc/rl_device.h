@@ -1,0 +1,60 @@
+// Device-side basics shared by every kernel: complex fp64 helpers, the LDS
+// carve macro and the launch macro.
+//
+// The product build is hipcc --offload-arch=gfx950.  RL_EMU is defined only by
+// tests/emu (a thread-level emulator that runs this same source on the host
+// for debugging and sanitizers); nothing shipped is built that way.
+#pragma once
+
+#if defined(RL_EMU)
+#include "rl_emu.h"
+#define RL_SMEM(name) unsigned char* name = rl_emu_smem()
+#define RL_LAUNCH(kern, grid, block, smem, stream, ...) \
+    rl_emu_launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define RL_BACKEND_NAME "emu-host"
+#else
+#include <hip/hip_runtime.h>
+// all LDS lives in ONE dynamic array whose base is 16-byte aligned
+// (cdna_hip_programming.md guideline 17)
+#define RL_SMEM(name)                                                        \
+    extern __shared__ __attribute__((aligned(16))) unsigned char name##_lds[]; \
+    unsigned char* name = name##_lds
+#define RL_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define RL_BACKEND_NAME "hip-gfx950"
+#endif
+
+#include <stdint.h>
+
+struct __attribute__((aligned(16))) cplx {
+    double x, y;
+};
+
+__device__ __forceinline__ cplx c_make(double x, double y) {
+    cplx r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+__device__ __forceinline__ cplx c_add(cplx a, cplx b) { return c_make(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx c_sub(cplx a, cplx b) { return c_make(a.x - b.x, a.y - b.y); }
+// a * b
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b) {
+    return c_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+__device__ __forceinline__ cplx c_mulc(cplx a, cplx b) {
+    return c_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// multiply by -i (forward quarter turn) / +i
+__device__ __forceinline__ cplx c_mul_mi(cplx a) { return c_make(a.y, -a.x); }
+__device__ __forceinline__ cplx c_mul_pi(cplx a) { return c_make(-a.y, a.x); }
+__device__ __forceinline__ cplx c_scale(cplx a, double s) { return c_make(a.x * s, a.y * s); }
+
+#define RL_MAX_PASSES 8
+// Radix schedule of one power-of-two FFT; passed to kernels by value.
+struct FftPlan {
+    int n;
+    int npass;
+    int radix[RL_MAX_PASSES];
+};

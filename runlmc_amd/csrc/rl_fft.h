@@ -1,0 +1,151 @@
+// In-LDS FFT passes for side-by-side transforms.
+//
+// A tile holds `cols` independent length-N transforms side by side: element e
+// of transform c lives at tile[e * ld + c].  Threads walk (butterfly, column)
+// pairs with the column fastest, so a wavefront touches consecutive LDS
+// addresses in every pass (no bank conflicts at any stride).
+//
+// Forward = in-place decimation in frequency: natural order in, digit-scrambled
+// order out.  The inverse is the conjugate transpose of the same flow graph
+// (passes in reverse order, conjugate twiddle BEFORE the conjugate butterfly),
+// so it consumes exactly the scrambled order the forward produces and nothing
+// is ever bit-reversed.  tests/flow_model.py is the executable specification.
+#pragma once
+#include "rl_device.h"
+
+#define RL_SQRT1_2 0.70710678118654752440
+
+template <bool INV>
+__device__ __forceinline__ cplx c_quarter(cplx a) {
+    return INV ? c_mul_pi(a) : c_mul_mi(a);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft2(cplx& a, cplx& b) {
+    cplx t = c_sub(a, b);
+    a = c_add(a, b);
+    b = t;
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(cplx& v0, cplx& v1, cplx& v2, cplx& v3) {
+    cplx t0 = c_add(v0, v2), t1 = c_sub(v0, v2);
+    cplx t2 = c_add(v1, v3), t3 = c_quarter<INV>(c_sub(v1, v3));
+    v0 = c_add(t0, t2);
+    v1 = c_add(t1, t3);
+    v2 = c_sub(t0, t2);
+    v3 = c_sub(t1, t3);
+}
+
+// multiply by exp(-/+ i pi/4) and exp(-/+ 3 i pi/4)
+template <bool INV>
+__device__ __forceinline__ cplx c_eighth(cplx a) {
+    return INV ? c_make((a.x - a.y) * RL_SQRT1_2, (a.x + a.y) * RL_SQRT1_2)
+               : c_make((a.x + a.y) * RL_SQRT1_2, (a.y - a.x) * RL_SQRT1_2);
+}
+template <bool INV>
+__device__ __forceinline__ cplx c_three_eighths(cplx a) {
+    return INV ? c_make((-a.x - a.y) * RL_SQRT1_2, (a.x - a.y) * RL_SQRT1_2)
+               : c_make((a.y - a.x) * RL_SQRT1_2, (-a.x - a.y) * RL_SQRT1_2);
+}
+
+template <int R, bool INV>
+struct SmallDft;
+
+template <bool INV>
+struct SmallDft<2, INV> {
+    static __device__ __forceinline__ void run(cplx* v) { dft2<INV>(v[0], v[1]); }
+};
+template <bool INV>
+struct SmallDft<4, INV> {
+    static __device__ __forceinline__ void run(cplx* v) {
+        dft4<INV>(v[0], v[1], v[2], v[3]);
+    }
+};
+template <bool INV>
+struct SmallDft<8, INV> {
+    static __device__ __forceinline__ void run(cplx* v) {
+        cplx e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+        cplx o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+        dft4<INV>(e0, e1, e2, e3);
+        dft4<INV>(o0, o1, o2, o3);
+        o1 = c_eighth<INV>(o1);
+        o2 = c_quarter<INV>(o2);
+        o3 = c_three_eighths<INV>(o3);
+        v[0] = c_add(e0, o0);
+        v[4] = c_sub(e0, o0);
+        v[1] = c_add(e1, o1);
+        v[5] = c_sub(e1, o1);
+        v[2] = c_add(e2, o2);
+        v[6] = c_sub(e2, o2);
+        v[3] = c_add(e3, o3);
+        v[7] = c_sub(e3, o3);
+    }
+};
+
+// One radix-R pass over the whole tile.
+//   n    transform length, ns  current sub-transform length (n, n/R1, ...)
+//   cols side-by-side transforms, ld  leading dimension (>= cols)
+//   tw   table of exp(-2 pi i k / n), k in [0, n)
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass(cplx* tile, int n, int ns, int cols, int ld,
+                                         const cplx* tw, int tid, int nthr) {
+    const int sub = ns / R;          // distance between butterfly legs
+    const int twstep = n / ns;       // W_ns^j = tw[j * twstep]
+    const int work = (n / R) * cols;
+    for (int w = tid; w < work; w += nthr) {
+        const int c = w % cols;
+        const int bf = w / cols;
+        const int j = bf & (sub - 1);
+        const int g = (bf - j) * R;  // (bf / sub) * ns
+        cplx* p = tile + (size_t)(g + j) * ld + c;
+        const size_t leg = (size_t)sub * ld;
+        cplx v[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = p[i * leg];
+        if (INV) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k] = c_mulc(v[k], tw[j * k * twstep]);
+        }
+        SmallDft<R, INV>::run(v);
+        if (!INV) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k] = c_mul(v[k], tw[j * k * twstep]);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) p[i * leg] = v[i];
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_pass_any(int radix, cplx* tile, int n, int ns, int cols,
+                                             int ld, const cplx* tw, int tid, int nthr) {
+    if (radix == 8)
+        fft_pass<8, INV>(tile, n, ns, cols, ld, tw, tid, nthr);
+    else if (radix == 4)
+        fft_pass<4, INV>(tile, n, ns, cols, ld, tw, tid, nthr);
+    else
+        fft_pass<2, INV>(tile, n, ns, cols, ld, tw, tid, nthr);
+}
+
+// All forward passes; ends with a barrier.
+__device__ __forceinline__ void fft_tile_forward(cplx* tile, const FftPlan& plan, int cols,
+                                                 int ld, const cplx* tw, int tid, int nthr) {
+    int ns = plan.n;
+    for (int s = 0; s < plan.npass; ++s) {
+        fft_pass_any<false>(plan.radix[s], tile, plan.n, ns, cols, ld, tw, tid, nthr);
+        ns /= plan.radix[s];
+        __syncthreads();
+    }
+}
+
+// All adjoint passes (unnormalised inverse); ends with a barrier.
+__device__ __forceinline__ void fft_tile_adjoint(cplx* tile, const FftPlan& plan, int cols,
+                                                 int ld, const cplx* tw, int tid, int nthr) {
+    int ns = 1;
+    for (int s = plan.npass - 1; s >= 0; --s) {
+        ns *= plan.radix[s];
+        fft_pass_any<true>(plan.radix[s], tile, plan.n, ns, cols, ld, tw, tid, nthr);
+        __syncthreads();
+    }
+}

@@ -1,0 +1,282 @@
+// Kernels of the grid operator  K_UU = sum_q B_q (x) T_q  and of the SKI
+// wrapper  K~ = W K_UU W^T + diag(eps).
+//
+// Reference behaviour being replaced (vlad17/runlmc):
+//   runlmc/linalg/bttb.py:106-120,144-148   circulant embed + rfftn / irfftn
+//   runlmc/linalg/kronecker.py:39-46         (B (x) T) x
+//   runlmc/linalg/sum_matrix.py:31-32        sum over q
+//   runlmc/approx/ski.py:13-16               W . , W^T .
+//   runlmc/linalg/diag.py:24-25              eps * x
+//
+// Device formulation:
+//   * two real right-hand sides ride one complex transform (x1 + i x2): the
+//     circulant spectra and the coregionalisation mix are real, so the
+//     operator commutes with that packing and no real-FFT untangling exists;
+//   * the length-L complex FFT is split L = N1 x N2 (four-step): k_cols_fwd
+//     does the N1-point column transforms for a tile of columns in LDS and the
+//     inter-step twiddle, k_rows_mix does the N2-point row transforms for ALL
+//     D outputs of a few rows, applies the real D x D mix at every frequency in
+//     place, and runs the adjoint row transforms, k_cols_inv does the adjoint
+//     column transforms and the crop;
+//   * frequencies stay in the scrambled order the in-place passes produce; the
+//     spectra are made by the same forward graph (k_rows_spec).
+#pragma once
+#include "rl_fft.h"
+
+#define RL_THREADS 256
+
+// W_L^e from two short tables: e = hi * 2^shift + lo
+struct TwiddleL {
+    const cplx* lo;
+    const cplx* hi;
+    int shift;
+    int mask;
+};
+__device__ __forceinline__ cplx twiddle_L(const TwiddleL& t, int e) {
+    return c_mul(t.lo[e & t.mask], t.hi[e >> t.shift]);
+}
+
+__device__ __forceinline__ void load_table(cplx* dst, const cplx* src, int n, int tid, int nthr) {
+    for (int i = tid; i < n; i += nthr) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// k_cols_fwd: pad + pack two real vectors -> N1-point column FFTs -> twiddle.
+//   grid (N2 / C, D, npairs)   block RL_THREADS
+//   X     [nvec][D][m] real (mode 0)  or  tops [ntop][m] with D == 1 (mode 1:
+//         symmetric circulant column  c[n] = t[n] (n < m), t[L-n] (n > L-m))
+//   T     [npairs][D][N1][N2] complex, position r of a column holds frequency
+//         k1 = freq1[r]
+// LDS: tile [N1][C] + twiddle table [N1]
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RL_THREADS)
+k_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode, cplx* __restrict__ T,
+           int N1, int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1,
+           const int* __restrict__ freq1, TwiddleL twl) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    cplx* tw = tile + (size_t)N1 * C;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int c0 = blockIdx.x * C, b = blockIdx.y, pair = blockIdx.z;
+    const int L = N1 * N2;
+    const int v0 = 2 * pair, v1 = 2 * pair + 1;
+    const double* x0 = X + ((size_t)v0 * D + b) * m;
+    const double* x1 = X + ((size_t)v1 * D + b) * m;
+    const bool has1 = v1 < nvec;
+
+    load_table(tw, tw1, N1, tid, nthr);
+    for (int idx = tid; idx < N1 * C; idx += nthr) {
+        const int c = idx % C, n1 = idx / C;
+        const int n = n1 * N2 + c0 + c;
+        double re = 0.0, im = 0.0;
+        int src = -1;
+        if (n < m)
+            src = n;
+        else if (mode == 1 && n > L - m)
+            src = L - n;
+        if (src >= 0) {
+            re = x0[src];
+            if (has1) im = x1[src];
+        }
+        tile[idx] = c_make(re, im);
+    }
+    __syncthreads();
+    fft_tile_forward(tile, plan1, C, C, tw, tid, nthr);
+
+    cplx* out = T + ((size_t)pair * D + b) * L;
+    for (int idx = tid; idx < N1 * C; idx += nthr) {
+        const int c = idx % C, r = idx / C;
+        const int n2 = c0 + c;
+        const cplx w = twiddle_L(twl, freq1[r] * n2);
+        out[(size_t)r * N2 + n2] = c_mul(tile[idx], w);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_rows_spec: N2-point row FFTs of the packed circulant columns; real part ->
+// spectrum 2*pair, imaginary part -> spectrum 2*pair+1, both scaled by 1/L.
+//   grid (N1 / R, npairs)   T [npairs][1][N1][N2]   spec [ntop][N1*N2]
+// LDS: tile [N2][CB] (CB = R | 1) + twiddle table [N2]
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RL_THREADS)
+k_rows_spec(const cplx* __restrict__ T, double* __restrict__ spec, int ntop, int N1, int N2,
+            int R, FftPlan plan2, const cplx* __restrict__ tw2) {
+    RL_SMEM(smem);
+    const int CB = R | 1;
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    cplx* tw = tile + (size_t)N2 * CB;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int r0 = blockIdx.x * R, pair = blockIdx.y;
+    const size_t L = (size_t)N1 * N2;
+    const cplx* in = T + (size_t)pair * L;
+
+    load_table(tw, tw2, N2, tid, nthr);
+    for (int idx = tid; idx < R * N2; idx += nthr) {
+        const int n2 = idx % N2, rr = idx / N2;
+        tile[(size_t)n2 * CB + rr] = in[(size_t)(r0 + rr) * N2 + n2];
+    }
+    __syncthreads();
+    fft_tile_forward(tile, plan2, R, CB, tw, tid, nthr);
+    const double scale = 1.0 / (double)L;
+    const int q0 = 2 * pair, q1 = 2 * pair + 1;
+    for (int idx = tid; idx < R * N2; idx += nthr) {
+        const int pos = idx % N2, rr = idx / N2;
+        const cplx z = tile[(size_t)pos * CB + rr];
+        const size_t o = (size_t)(r0 + rr) * N2 + pos;
+        spec[(size_t)q0 * L + o] = z.x * scale;
+        if (q1 < ntop) spec[(size_t)q1 * L + o] = z.y * scale;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Frequency-domain coregionalisation mix, factored form
+//   B_q = sum_{f : facQ[f] == q} facW[f] a_f a_f^T + diag(kappa_q)
+//   Yhat_a = (sum_q kappa_q[a] s_q) Z_a + sum_f a_f[a] (facW[f] s_{q(f)}) (a_f . Z)
+// with s_q the (real, 1/L-scaled) circulant spectrum at this frequency.
+// ---------------------------------------------------------------------------
+struct MixParams {
+    int Q;
+    int nfac;
+    const double* spec;   // [Q][L]
+    const double* facA;   // [nfac][D]
+    const double* facW;   // [nfac]
+    const int* facQ;      // [nfac]
+    const double* kappa;  // [Q][D]
+};
+
+// ---------------------------------------------------------------------------
+// k_rows_mix<D>: for R rows and all D outputs: N2-point row FFTs, mix, adjoint
+// row FFTs, conjugate inter-step twiddle; in place on T.
+//   grid (N1 / R, npairs)
+// LDS: tile [N2][CB] (CB = (R*D) | 1) + twiddle table [N2]
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(RL_THREADS)
+k_rows_mix(cplx* __restrict__ T, int N1, int N2, int R, FftPlan plan2,
+           const cplx* __restrict__ tw2, const int* __restrict__ freq1, TwiddleL twl,
+           MixParams mp) {
+    RL_SMEM(smem);
+    const int cols = R * D;
+    const int CB = cols | 1;
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    cplx* tw = tile + (size_t)N2 * CB;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int r0 = blockIdx.x * R, pair = blockIdx.y;
+    const size_t L = (size_t)N1 * N2;
+    cplx* base = T + (size_t)pair * D * L;
+
+    load_table(tw, tw2, N2, tid, nthr);
+    for (int idx = tid; idx < cols * N2; idx += nthr) {
+        const int n2 = idx % N2, rb = idx / N2;
+        const int rr = rb / D, b = rb % D;
+        tile[(size_t)n2 * CB + rb] = base[(size_t)b * L + (size_t)(r0 + rr) * N2 + n2];
+    }
+    __syncthreads();
+    fft_tile_forward(tile, plan2, cols, CB, tw, tid, nthr);
+
+    for (int idx = tid; idx < R * N2; idx += nthr) {
+        const int pos = idx % N2, rr = idx / N2;
+        cplx* zp = tile + (size_t)pos * CB + rr * D;
+        const size_t o = (size_t)(r0 + rr) * N2 + pos;
+        cplx z[D], y[D];
+#pragma unroll
+        for (int b = 0; b < D; ++b) z[b] = zp[b];
+        double dc[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) dc[a] = 0.0;
+        for (int q = 0; q < mp.Q; ++q) {
+            const double s = mp.spec[(size_t)q * L + o];
+#pragma unroll
+            for (int a = 0; a < D; ++a) dc[a] = fma(mp.kappa[q * D + a], s, dc[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) y[a] = c_scale(z[a], dc[a]);
+        for (int f = 0; f < mp.nfac; ++f) {
+            const double* af = mp.facA + (size_t)f * D;
+            double sx = 0.0, sy = 0.0;
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                sx = fma(af[b], z[b].x, sx);
+                sy = fma(af[b], z[b].y, sy);
+            }
+            const double g = mp.facW[f] * mp.spec[(size_t)mp.facQ[f] * L + o];
+            sx *= g;
+            sy *= g;
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                y[a].x = fma(af[a], sx, y[a].x);
+                y[a].y = fma(af[a], sy, y[a].y);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) zp[a] = y[a];
+    }
+    __syncthreads();
+    fft_tile_adjoint(tile, plan2, cols, CB, tw, tid, nthr);
+
+    for (int idx = tid; idx < cols * N2; idx += nthr) {
+        const int n2 = idx % N2, rb = idx / N2;
+        const int rr = rb / D, b = rb % D;
+        const cplx w = twiddle_L(twl, freq1[r0 + rr] * n2);
+        base[(size_t)b * L + (size_t)(r0 + rr) * N2 + n2] =
+            c_mulc(tile[(size_t)n2 * CB + rb], w);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_cols_inv: adjoint N1-point column FFTs, crop to m, unpack the pair.
+//   grid (ceil(ncols_needed / C), D, npairs)
+//   Y [nvec][D][m];  beta == 0: Y = result, else Y += result
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RL_THREADS)
+k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, int m, int N1,
+           int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    cplx* tw = tile + (size_t)N1 * C;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int c0 = blockIdx.x * C, b = blockIdx.y, pair = blockIdx.z;
+    const size_t L = (size_t)N1 * N2;
+    const cplx* in = T + ((size_t)pair * D + b) * L;
+
+    load_table(tw, tw1, N1, tid, nthr);
+    for (int idx = tid; idx < N1 * C; idx += nthr) {
+        const int c = idx % C, r = idx / C;
+        tile[idx] = in[(size_t)r * N2 + c0 + c];
+    }
+    __syncthreads();
+    fft_tile_adjoint(tile, plan1, C, C, tw, tid, nthr);
+
+    const int v0 = 2 * pair, v1 = 2 * pair + 1;
+    double* y0 = Y + ((size_t)v0 * D + b) * m;
+    double* y1 = Y + ((size_t)v1 * D + b) * m;
+    const bool has1 = v1 < nvec;
+    for (int idx = tid; idx < N1 * C; idx += nthr) {
+        const int c = idx % C, n1 = idx / C;
+        const int n = n1 * N2 + c0 + c;
+        if (n < m) {
+            const cplx z = tile[idx];
+            y0[n] = z.x;
+            if (has1) y1[n] = z.y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// CSR gather SpMV over a batch of vectors:  Y[v] = A X[v]  (+ diag * X2[v])
+//   grid (ceil(nrows / RL_THREADS), nvec)
+// Used for W^T x (rows = D*m grid points) and for W g + eps * x (rows = n).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RL_THREADS)
+k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
+       const double* __restrict__ vals, int nrows, int ncols, const double* __restrict__ X,
+       double* __restrict__ Y, const double* __restrict__ diag, const double* __restrict__ X2) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (row >= nrows) return;
+    const double* x = X + (size_t)v * ncols;
+    double acc = 0.0;
+    for (int k = indptr[row]; k < indptr[row + 1]; ++k) acc = fma(vals[k], x[indices[k]], acc);
+    if (diag != nullptr) acc = fma(diag[row], X2[(size_t)v * nrows + row], acc);
+    Y[(size_t)v * nrows + row] = acc;
+}

@@ -1,0 +1,659 @@
+// C ABI of the MI355X-native LMC hot path (see include/runlmc_hip.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
+#include "../../include/runlmc_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rl_kernels.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define RL_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(RL_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+#define RL_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != RL_OK) return rc_; \
+    } while (0)
+
+extern "C" const char* rl_last_error(void) { return g_err.c_str(); }
+extern "C" const char* rl_backend(void) { return RL_BACKEND_NAME; }
+extern "C" int rl_device_count(int* count) {
+    if (!count) return fail(RL_EINVAL, "count is NULL");
+    RL_HIP(hipGetDeviceCount(count));
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small host helpers
+// ---------------------------------------------------------------------------
+static int ilog2(int x) {
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+static FftPlan make_plan(int n) {
+    FftPlan p;
+    p.n = n;
+    p.npass = 0;
+    for (int i = 0; i < RL_MAX_PASSES; ++i) p.radix[i] = 1;
+    int rem = n;
+    while (rem > 1) {
+        int r = 8;
+        while (rem % r) r /= 2;
+        p.radix[p.npass++] = r;
+        rem /= r;
+    }
+    return p;
+}
+
+// position -> frequency of the in-place DIF graph (tests/flow_model.py)
+static std::vector<int> position_to_freq(const FftPlan& p) {
+    std::vector<int> f(p.n);
+    for (int pos = 0; pos < p.n; ++pos) {
+        int rem = pos, ns = p.n, mult = 1, k = 0;
+        for (int s = 0; s < p.npass; ++s) {
+            int sub = ns / p.radix[s];
+            int d = rem / sub;
+            rem -= d * sub;
+            k += d * mult;
+            mult *= p.radix[s];
+            ns = sub;
+        }
+        f[pos] = k;
+    }
+    return f;
+}
+
+// exp(-2 pi i k / n), accurate to the last bit or so (long double + octant
+// symmetry through cosl/sinl of a reduced argument)
+static void root_of_unity(long k, long n, double* re, double* im) {
+    k %= n;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    // reduce to first octant for accuracy
+    long double ang = two_pi * (long double)k / (long double)n;
+    *re = (double)cosl(ang);
+    *im = (double)(-sinl(ang));
+}
+
+static std::vector<cplx> unity_table(long count, long stride, long n) {
+    std::vector<cplx> t(count);
+    for (long i = 0; i < count; ++i) root_of_unity(i * stride, n, &t[i].x, &t[i].y);
+    return t;
+}
+
+template <class T>
+static int upload(T** dev, const std::vector<T>& host) {
+    RL_HIP(hipMalloc((void**)dev, std::max<size_t>(host.size(), 1) * sizeof(T)));
+    if (!host.empty())
+        RL_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RL_OK;
+}
+
+static const size_t kLdsSoft = 76 * 1024;    // two workgroups per CU
+static const size_t kLdsHard = 156 * 1024;   // one workgroup per CU (160 KiB LDS)
+
+// ---------------------------------------------------------------------------
+// grid operator
+// ---------------------------------------------------------------------------
+struct rl_gridop {
+    int device = 0;
+    int D = 0, m = 0, L = 0, N1 = 0, N2 = 0;
+    int colsA = 0;   // columns per k_cols_* workgroup
+    int rowsB = 0;   // rows per k_rows_mix workgroup
+    int rowsS = 0;   // rows per k_rows_spec workgroup
+    int max_tops = 0;
+    FftPlan plan1, plan2;
+    cplx *tw1 = nullptr, *tw2 = nullptr, *twlo = nullptr, *twhi = nullptr;
+    int* freq1 = nullptr;
+    TwiddleL twl;
+    std::vector<int> h_freq1, h_freq2;
+    // parameters
+    int Q = 0, nfac = 0;
+    double* tops = nullptr;    // dev [max_tops][m]
+    double* spec = nullptr;    // dev [max_tops][L]
+    double* facA = nullptr;    // dev [max_fac][D]
+    double* facW = nullptr;    // dev [max_fac]
+    int* facQ = nullptr;       // dev [max_fac]
+    double* kappa = nullptr;   // dev [max_tops][D]
+    double* ones = nullptr;    // dev [D]  (identity mix for mvm_top)
+    int max_fac = 0;
+    // workspace: packed intermediates [pairs][D][L] complex
+    cplx* T = nullptr;
+    size_t T_pairs = 0;
+    size_t chunk_pairs = 1;
+};
+
+static size_t lds_cols(const rl_gridop* g) {
+    return ((size_t)g->N1 * g->colsA + g->N1) * sizeof(cplx);
+}
+static size_t lds_rows(int N2, int cols) {
+    return ((size_t)N2 * (cols | 1) + N2) * sizeof(cplx);
+}
+
+static int ensure_workspace(rl_gridop* g, size_t pairs) {
+    if (pairs <= g->T_pairs) return RL_OK;
+    if (g->T) RL_HIP(hipFree(g->T));
+    g->T = nullptr;
+    g->T_pairs = 0;
+    RL_HIP(hipMalloc((void**)&g->T, pairs * g->D * (size_t)g->L * sizeof(cplx)));
+    g->T_pairs = pairs;
+    return RL_OK;
+}
+
+template <int D>
+static void set_lds_attr_rows() {
+#if !defined(RL_EMU)
+    (void)hipFuncSetAttribute((const void*)k_rows_mix<D>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+}
+
+static void set_lds_attrs() {
+#if !defined(RL_EMU)
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute((const void*)k_cols_fwd,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_cols_inv,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_rows_spec,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set_lds_attr_rows<1>();  set_lds_attr_rows<2>();  set_lds_attr_rows<3>();
+    set_lds_attr_rows<4>();  set_lds_attr_rows<5>();  set_lds_attr_rows<6>();
+    set_lds_attr_rows<7>();  set_lds_attr_rows<8>();  set_lds_attr_rows<9>();
+    set_lds_attr_rows<10>(); set_lds_attr_rows<11>(); set_lds_attr_rows<12>();
+    set_lds_attr_rows<13>(); set_lds_attr_rows<14>(); set_lds_attr_rows<15>();
+    set_lds_attr_rows<16>();
+#endif
+}
+
+#define RL_MAX_D 16
+
+extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out) {
+    if (!out) return fail(RL_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (D < 1 || m < 1 || max_tops < 1)
+        return fail(RL_EINVAL, "rl_gridop_create: D, m, max_tops must be >= 1");
+    if (D > RL_MAX_D)
+        return fail(RL_ELIMIT, "rl_gridop_create: D > 16 outputs not supported");
+    if ((long)m > (1L << 27)) return fail(RL_ELIMIT, "rl_gridop_create: m too large");
+    RL_HIP(hipSetDevice(device));
+    set_lds_attrs();
+
+    rl_gridop* g = new rl_gridop;
+    g->device = device;
+    g->D = D;
+    g->m = m;
+    g->max_tops = max_tops;
+    int L = 16;
+    while (L < 2 * m) L *= 2;
+    g->L = L;
+    const int l = ilog2(L);
+    g->N2 = 1 << ((l + 1) / 2);
+    g->N1 = L / g->N2;
+    // rows per k_rows_mix workgroup: as many as fit the soft LDS budget; if even
+    // one row does not fit, shrink N2 (longer column transforms) before giving up
+    for (;;) {
+        int R = 0;
+        for (int r = g->N1; r >= 1; r /= 2)
+            if (lds_rows(g->N2, r * D) <= kLdsSoft) { R = r; break; }
+        if (R == 0 && lds_rows(g->N2, D) <= kLdsHard) R = 1;
+        if (R > 0) { g->rowsB = R; break; }
+        if (g->N2 <= 4) { delete g; return fail(RL_ELIMIT, "rl_gridop_create: D*L exceeds LDS"); }
+        g->N2 /= 2;
+        g->N1 *= 2;
+    }
+    // cap rows so that a launch still has a few hundred workgroups to spread
+    while (g->rowsB > 1 && g->N1 / g->rowsB < 16) g->rowsB /= 2;
+    g->rowsS = 1;
+    for (int r = g->N1; r >= 1; r /= 2)
+        if (lds_rows(g->N2, r) <= kLdsSoft) { g->rowsS = r; break; }
+    while (g->rowsS > 1 && g->N1 / g->rowsS < 16) g->rowsS /= 2;
+    // columns per k_cols_* workgroup
+    int C = std::min(32, g->N2);
+    while (C > 1 && ((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsSoft) C /= 2;
+    if (C < 8 && g->N2 >= 8) {
+        C = 8;
+        while (C > 1 && ((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsHard) C /= 2;
+    }
+    if (((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsHard) {
+        delete g;
+        return fail(RL_ELIMIT, "rl_gridop_create: grid too long for one LDS column tile");
+    }
+    g->colsA = C;
+
+    g->plan1 = make_plan(g->N1);
+    g->plan2 = make_plan(g->N2);
+    g->h_freq1 = position_to_freq(g->plan1);
+    g->h_freq2 = position_to_freq(g->plan2);
+
+    int rc;
+    if ((rc = upload(&g->tw1, unity_table(g->N1, 1, g->N1))) != RL_OK) return rc;
+    if ((rc = upload(&g->tw2, unity_table(g->N2, 1, g->N2))) != RL_OK) return rc;
+    const int shift = l / 2;
+    if ((rc = upload(&g->twlo, unity_table(1L << shift, 1, L))) != RL_OK) return rc;
+    if ((rc = upload(&g->twhi, unity_table((long)L >> shift, 1L << shift, L))) != RL_OK) return rc;
+    if ((rc = upload(&g->freq1, g->h_freq1)) != RL_OK) return rc;
+    g->twl.lo = g->twlo;
+    g->twl.hi = g->twhi;
+    g->twl.shift = shift;
+    g->twl.mask = (1 << shift) - 1;
+
+    g->max_fac = max_tops * D;
+    RL_HIP(hipMalloc((void**)&g->tops, (size_t)max_tops * m * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&g->spec, (size_t)max_tops * L * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&g->facA, (size_t)g->max_fac * D * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&g->facW, (size_t)g->max_fac * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&g->facQ, (size_t)g->max_fac * sizeof(int)));
+    RL_HIP(hipMalloc((void**)&g->kappa, (size_t)max_tops * D * sizeof(double)));
+    std::vector<double> ones(D, 1.0);
+    if ((rc = upload(&g->ones, ones)) != RL_OK) return rc;
+
+    // intermediates of one chunk should stay inside the 256 MiB Infinity Cache
+    size_t chunk_mb = 96;
+    if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
+    g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
+    *out = g;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_destroy(rl_gridop* g) {
+    if (!g) return RL_OK;
+    (void)hipSetDevice(g->device);
+    void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
+                    g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA,
+                              int* rowsB) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (L) *L = g->L;
+    if (N1) *N1 = g->N1;
+    if (N2) *N2 = g->N2;
+    if (colsA) *colsA = g->colsA;
+    if (rowsB) *rowsB = g->rowsB;
+    return RL_OK;
+}
+
+// spectra of tops [0, ntop) -> g->spec, on `stream`
+static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
+    const int npairs = (ntop + 1) / 2;
+    // the spectrum pass uses the workspace as [npairs][1][L]
+    const size_t need = ((size_t)npairs + g->D - 1) / g->D;
+    RL_TRY(ensure_workspace(g, std::max<size_t>(need, 1)));
+    dim3 gridA(g->N2 / g->colsA, 1, npairs);
+    RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, g->tops, ntop, 1, g->m,
+              1, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);
+    dim3 gridS(g->N1 / g->rowsS, npairs);
+    RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
+              g->spec, ntop, g->N1, g->N2, g->rowsS, g->plan2, g->tw2);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+static int set_common(rl_gridop* g, int Q, const double* tops) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (Q < 1 || Q > g->max_tops)
+        return fail(RL_EINVAL, "rl_gridop_set: Q outside [1, max_tops]");
+    if (!tops) return fail(RL_EINVAL, "rl_gridop_set: tops is NULL");
+    RL_HIP(hipSetDevice(g->device));
+    RL_HIP(hipMemcpy(g->tops, tops, (size_t)Q * g->m * sizeof(double), hipMemcpyHostToDevice));
+    RL_TRY(build_spectra(g, Q, nullptr));
+    g->Q = Q;
+    return RL_OK;
+}
+
+static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::vector<double>& W,
+                       const std::vector<int>& Qi, const std::vector<double>& kap) {
+    const int nfac = (int)W.size();
+    if (nfac > g->max_fac) return fail(RL_ELIMIT, "rl_gridop_set: total rank exceeds max_tops*D");
+    if (nfac) {
+        RL_HIP(hipMemcpy(g->facA, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(g->facW, W.data(), W.size() * sizeof(double), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(g->facQ, Qi.data(), Qi.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    RL_HIP(hipMemcpy(g->kappa, kap.data(), kap.size() * sizeof(double), hipMemcpyHostToDevice));
+    g->nfac = nfac;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_set_lmc(rl_gridop* g, int Q, const double* tops, const int* ranks,
+                                 const double* coreg_vecs, const double* coreg_diags) {
+    RL_TRY(set_common(g, Q, tops));
+    if (!ranks || !coreg_diags) return fail(RL_EINVAL, "rl_gridop_set_lmc: NULL argument");
+    const int D = g->D;
+    std::vector<double> A, W, kap(coreg_diags, coreg_diags + (size_t)Q * D);
+    std::vector<int> Qi;
+    size_t row = 0;
+    for (int q = 0; q < Q; ++q) {
+        if (ranks[q] < 0) return fail(RL_EINVAL, "rl_gridop_set_lmc: negative rank");
+        if (ranks[q] > 0 && !coreg_vecs)
+            return fail(RL_EINVAL, "rl_gridop_set_lmc: coreg_vecs is NULL");
+        for (int r = 0; r < ranks[q]; ++r, ++row) {
+            A.insert(A.end(), coreg_vecs + row * D, coreg_vecs + (row + 1) * D);
+            W.push_back(1.0);
+            Qi.push_back(q);
+        }
+    }
+    return set_factors(g, A, W, Qi, kap);
+}
+
+// cyclic Jacobi eigen-decomposition of a small symmetric matrix (row-major,
+// overwritten); V's COLUMNS are eigenvectors
+static void jacobi_eig(std::vector<double>& a, int n, std::vector<double>& w,
+                       std::vector<double>& V) {
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                (i == j ? diag : off) += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+        if (off <= 1e-34 * (diag + off) || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) /
+                                 (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+                    a[(size_t)k * n + p] = c * akp - s * akq;
+                    a[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+                    a[(size_t)p * n + k] = c * apk - s * aqk;
+                    a[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                    V[(size_t)k * n + p] = c * vkp - s * vkq;
+                    V[(size_t)k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
+}
+
+extern "C" int rl_gridop_set_dense(rl_gridop* g, int Q, const double* tops, const double* B) {
+    RL_TRY(set_common(g, Q, tops));
+    if (!B) return fail(RL_EINVAL, "rl_gridop_set_dense: B is NULL");
+    const int D = g->D;
+    std::vector<double> A, W, kap((size_t)Q * D, 0.0);
+    std::vector<int> Qi;
+    for (int q = 0; q < Q; ++q) {
+        std::vector<double> sym((size_t)D * D), w, V;
+        double asym = 0.0, scale = 0.0;
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                const double bij = B[((size_t)q * D + i) * D + j];
+                const double bji = B[((size_t)q * D + j) * D + i];
+                sym[(size_t)i * D + j] = 0.5 * (bij + bji);
+                asym = std::max(asym, std::fabs(bij - bji));
+                scale = std::max(scale, std::fabs(bij));
+            }
+        if (asym > 1e-12 * std::max(scale, 1e-300))
+            return fail(RL_EINVAL, "rl_gridop_set_dense: B_q is not symmetric");
+        jacobi_eig(sym, D, w, V);
+        for (int f = 0; f < D; ++f) {
+            if (w[f] == 0.0) continue;
+            for (int b = 0; b < D; ++b) A.push_back(V[(size_t)b * D + f]);
+            W.push_back(w[f]);
+            Qi.push_back(q);
+        }
+    }
+    return set_factors(g, A, W, Qi, kap);
+}
+
+template <int D>
+static void launch_rows_mix(rl_gridop* g, size_t pairs, hipStream_t stream, const MixParams& mp) {
+    dim3 gridB(g->N1 / g->rowsB, (unsigned)pairs);
+    RL_LAUNCH(k_rows_mix<D>, gridB, dim3(RL_THREADS), lds_rows(g->N2, g->rowsB * D), stream,
+              g->T, g->N1, g->N2, g->rowsB, g->plan2, g->tw2, g->freq1, g->twl, mp);
+}
+
+static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
+                        hipStream_t stream) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (nvec < 0) return fail(RL_EINVAL, "nvec < 0");
+    if (nvec == 0) return RL_OK;
+    if (!X || !Y) return fail(RL_EINVAL, "X or Y is NULL");
+    if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
+    if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
+    RL_HIP(hipSetDevice(g->device));
+    const size_t total_pairs = ((size_t)nvec + 1) / 2;
+    const size_t chunk = std::min(total_pairs, g->chunk_pairs);
+    RL_TRY(ensure_workspace(g, chunk));
+    const size_t vec_len = (size_t)g->D * g->m;
+    const int colsNeeded = std::min(g->m, g->N2);
+    const unsigned tilesInv = (colsNeeded + g->colsA - 1) / g->colsA;
+    for (size_t p0 = 0; p0 < total_pairs; p0 += chunk) {
+        const size_t pairs = std::min(chunk, total_pairs - p0);
+        const int v0 = (int)(2 * p0);
+        const int nv = std::min<int>(nvec - v0, (int)(2 * pairs));
+        const double* Xc = X + (size_t)v0 * vec_len;
+        double* Yc = Y + (size_t)v0 * vec_len;
+        dim3 gridA(g->N2 / g->colsA, g->D, (unsigned)pairs);
+        RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, Xc, nv, g->D, g->m,
+                  0, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);
+        switch (g->D) {
+#define RL_CASE(d) case d: launch_rows_mix<d>(g, pairs, stream, mp); break;
+            RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
+            RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
+            RL_CASE(14) RL_CASE(15) RL_CASE(16)
+#undef RL_CASE
+            default: return fail(RL_ELIMIT, "unsupported D");
+        }
+        dim3 gridI(tilesInv, g->D, (unsigned)pairs);
+        RL_LAUNCH(k_cols_inv, gridI, dim3(RL_THREADS), lds_cols(g), stream, g->T, Yc, nv, g->D,
+                  g->m, g->N1, g->N2, g->colsA, g->plan1, g->tw1);
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_mvm(rl_gridop* g, const double* X, double* Y, int nvec, void* stream) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa};
+    return mvm_with_mix(g, mp, X, Y, nvec, (hipStream_t)stream);
+}
+
+extern "C" int rl_gridop_mvm_top(rl_gridop* g, int q, const double* X, double* Y, int nvec,
+                                 void* stream) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_mvm_top: q out of range");
+    MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones};
+    return mvm_with_mix(g, mp, X, Y, nvec, (hipStream_t)stream);
+}
+
+extern "C" int rl_gridop_spectrum_host(rl_gridop* g, int q, double* out) {
+    if (!g || !out) return fail(RL_EINVAL, "NULL argument");
+    if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_spectrum_host: q out of range");
+    RL_HIP(hipSetDevice(g->device));
+    std::vector<double> scr(g->L);
+    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipMemcpy(scr.data(), g->spec + (size_t)q * g->L, (size_t)g->L * sizeof(double),
+                     hipMemcpyDeviceToHost));
+    for (int r = 0; r < g->N1; ++r)
+        for (int c = 0; c < g->N2; ++c)
+            out[g->h_freq1[r] + (size_t)g->N1 * g->h_freq2[c]] =
+                scr[(size_t)r * g->N2 + c] * (double)g->L;
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// SKI operator
+// ---------------------------------------------------------------------------
+struct rl_ski {
+    rl_gridop* g = nullptr;
+    int n = 0, ngrid = 0;
+    int *W_indptr = nullptr, *W_indices = nullptr;
+    double* W_data = nullptr;
+    int *WT_indptr = nullptr, *WT_indices = nullptr;
+    double* WT_data = nullptr;
+    double* noise_diag = nullptr;   // dev [n]
+    bool has_noise = false;
+    double *G1 = nullptr, *G2 = nullptr;   // dev [cap][D*m] grid-side temporaries
+    int cap = 0;
+};
+
+static int check_csr(const int* indptr, const int* indices, int nrows, int ncols,
+                     const char* what) {
+    if (!indptr || indptr[0] != 0) return fail(RL_EINVAL, std::string(what) + ": bad indptr[0]");
+    for (int i = 0; i < nrows; ++i)
+        if (indptr[i + 1] < indptr[i])
+            return fail(RL_EINVAL, std::string(what) + ": indptr not monotone");
+    const int nnz = indptr[nrows];
+    if (nnz > 0 && !indices) return fail(RL_EINVAL, std::string(what) + ": indices is NULL");
+    for (int k = 0; k < nnz; ++k)
+        if (indices[k] < 0 || indices[k] >= ncols)
+            return fail(RL_EINVAL, std::string(what) + ": column index out of range");
+    return RL_OK;
+}
+
+static int upload_raw(void** dev, const void* host, size_t bytes) {
+    RL_HIP(hipMalloc(dev, std::max<size_t>(bytes, 16)));
+    if (bytes) RL_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return RL_OK;
+}
+
+extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int* W_indices,
+                             const double* W_data, const int* WT_indptr, const int* WT_indices,
+                             const double* WT_data, rl_ski** out) {
+    if (!out) return fail(RL_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (n < 1) return fail(RL_EINVAL, "rl_ski_create: n < 1");
+    const int ngrid = g->D * g->m;
+    RL_TRY(check_csr(W_indptr, W_indices, n, ngrid, "W"));
+    RL_TRY(check_csr(WT_indptr, WT_indices, ngrid, n, "WT"));
+    if (W_indptr[n] != WT_indptr[ngrid])
+        return fail(RL_EINVAL, "rl_ski_create: W and WT have different nnz");
+    RL_HIP(hipSetDevice(g->device));
+    rl_ski* s = new rl_ski;
+    s->g = g;
+    s->n = n;
+    s->ngrid = ngrid;
+    const size_t nnz = W_indptr[n];
+    int rc = RL_OK;
+    if ((rc = upload_raw((void**)&s->W_indptr, W_indptr, (size_t)(n + 1) * sizeof(int)))) return rc;
+    if ((rc = upload_raw((void**)&s->W_indices, W_indices, nnz * sizeof(int)))) return rc;
+    if ((rc = upload_raw((void**)&s->W_data, W_data, nnz * sizeof(double)))) return rc;
+    if ((rc = upload_raw((void**)&s->WT_indptr, WT_indptr, (size_t)(ngrid + 1) * sizeof(int)))) return rc;
+    if ((rc = upload_raw((void**)&s->WT_indices, WT_indices, nnz * sizeof(int)))) return rc;
+    if ((rc = upload_raw((void**)&s->WT_data, WT_data, nnz * sizeof(double)))) return rc;
+    RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
+    RL_HIP(hipMemset(s->noise_diag, 0, (size_t)n * sizeof(double)));
+    *out = s;
+    return RL_OK;
+}
+
+extern "C" int rl_ski_destroy(rl_ski* s) {
+    if (!s) return RL_OK;
+    (void)hipSetDevice(s->g->device);
+    void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
+                    s->WT_data, s->noise_diag, s->G1, s->G2};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete s;
+    return RL_OK;
+}
+
+extern "C" int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens) {
+    if (!s || !noise || !lens) return fail(RL_EINVAL, "rl_ski_set_noise: NULL argument");
+    std::vector<double> diag;
+    diag.reserve(s->n);
+    for (int d = 0; d < s->g->D; ++d) {
+        if (lens[d] < 0) return fail(RL_EINVAL, "rl_ski_set_noise: negative length");
+        diag.insert(diag.end(), (size_t)lens[d], noise[d]);
+    }
+    if ((int)diag.size() != s->n)
+        return fail(RL_EINVAL, "rl_ski_set_noise: sum(lens) != n");
+    RL_HIP(hipSetDevice(s->g->device));
+    RL_HIP(hipMemcpy(s->noise_diag, diag.data(), diag.size() * sizeof(double),
+                     hipMemcpyHostToDevice));
+    s->has_noise = true;
+    return RL_OK;
+}
+
+static int ski_reserve(rl_ski* s, int nvec) {
+    if (nvec <= s->cap) return RL_OK;
+    if (s->G1) RL_HIP(hipFree(s->G1));
+    if (s->G2) RL_HIP(hipFree(s->G2));
+    s->G1 = s->G2 = nullptr;
+    s->cap = 0;
+    RL_HIP(hipMalloc((void**)&s->G1, (size_t)nvec * s->ngrid * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&s->G2, (size_t)nvec * s->ngrid * sizeof(double)));
+    s->cap = nvec;
+    return RL_OK;
+}
+
+extern "C" int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream) {
+    if (!s || !X || !G) return fail(RL_EINVAL, "rl_ski_apply_wt: NULL argument");
+    if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
+    RL_HIP(hipSetDevice(s->g->device));
+    dim3 grid((s->ngrid + RL_THREADS - 1) / RL_THREADS, nvec);
+    RL_LAUNCH(k_spmv, grid, dim3(RL_THREADS), 0, (hipStream_t)stream, s->WT_indptr,
+              s->WT_indices, s->WT_data, s->ngrid, s->n, X, G, (const double*)nullptr,
+              (const double*)nullptr);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+static int ski_apply_w_impl(rl_ski* s, const double* G, double* Y, int nvec, const double* diag,
+                            const double* X2, hipStream_t stream) {
+    dim3 grid((s->n + RL_THREADS - 1) / RL_THREADS, nvec);
+    RL_LAUNCH(k_spmv, grid, dim3(RL_THREADS), 0, stream, s->W_indptr, s->W_indices, s->W_data,
+              s->n, s->ngrid, G, Y, diag, X2);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_ski_apply_w(rl_ski* s, const double* G, double* Y, int nvec, void* stream) {
+    if (!s || !G || !Y) return fail(RL_EINVAL, "rl_ski_apply_w: NULL argument");
+    if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
+    RL_HIP(hipSetDevice(s->g->device));
+    return ski_apply_w_impl(s, G, Y, nvec, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void* stream) {
+    if (!s || !X || !Y) return fail(RL_EINVAL, "rl_ski_mvm: NULL argument");
+    if (X == Y) return fail(RL_EINVAL, "rl_ski_mvm: X and Y may not alias");
+    if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
+    RL_HIP(hipSetDevice(s->g->device));
+    RL_TRY(ski_reserve(s, nvec));
+    RL_TRY(rl_ski_apply_wt(s, X, s->G1, nvec, stream));
+    RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, stream));
+    return ski_apply_w_impl(s, s->G2, Y, nvec, s->has_noise ? s->noise_diag : nullptr, X,
+                            (hipStream_t)stream);
+}

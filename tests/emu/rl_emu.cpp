@@ -1,0 +1,169 @@
+// Fiber-based workgroup emulator (TEST INFRASTRUCTURE ONLY, see rl_emu.h).
+//
+// One OS thread runs one workgroup at a time.  Every GPU thread of the
+// workgroup is a ucontext fiber; the scheduler resumes fibers round-robin and
+// a fiber returns to it either by finishing or by reaching __syncthreads().
+// After one sweep every live fiber sits at the same barrier, which is the
+// barrier's semantics.  Workgroups of one launch are spread over a few OS
+// threads.
+#include "rl_emu.h"
+
+#include <ucontext.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+thread_local rl_emu_uint3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace {
+
+constexpr size_t kStackBytes = 96 * 1024;
+
+struct Worker {
+    ucontext_t sched;
+    std::vector<ucontext_t> ctx;
+    std::vector<unsigned char> stacks;
+    std::vector<char> done;
+    std::vector<unsigned char> smem;
+    const std::function<void()>* body = nullptr;
+    int current = -1;
+};
+
+thread_local Worker* tl_worker = nullptr;
+
+void fiber_entry() {
+    Worker* w = tl_worker;
+    (*w->body)();
+    w->done[w->current] = 1;
+    swapcontext(&w->ctx[w->current], &w->sched);
+}
+
+void run_block(Worker& w, dim3 block, size_t smem_bytes) {
+    const unsigned nthr = block.x * block.y * block.z;
+    if (w.ctx.size() < nthr) {
+        w.ctx.resize(nthr);
+        w.stacks.resize(size_t(nthr) * kStackBytes);
+    }
+    w.done.assign(nthr, 0);
+    w.smem.assign(smem_bytes + 64, 0xCD);  // poison: uninitialised LDS reads show up
+    for (unsigned t = 0; t < nthr; ++t) {
+        getcontext(&w.ctx[t]);
+        w.ctx[t].uc_stack.ss_sp = w.stacks.data() + size_t(t) * kStackBytes;
+        w.ctx[t].uc_stack.ss_size = kStackBytes;
+        w.ctx[t].uc_link = &w.sched;
+        makecontext(&w.ctx[t], fiber_entry, 0);
+    }
+    unsigned remaining = nthr;
+    while (remaining) {
+        for (unsigned t = 0; t < nthr; ++t) {
+            if (w.done[t]) continue;
+            threadIdx.x = t % block.x;
+            threadIdx.y = (t / block.x) % block.y;
+            threadIdx.z = t / (block.x * block.y);
+            w.current = int(t);
+            swapcontext(&w.sched, &w.ctx[t]);
+            if (w.done[t]) --remaining;
+        }
+    }
+}
+
+int g_device = 0;
+
+}  // namespace
+
+void rl_emu_syncthreads() {
+    Worker* w = tl_worker;
+    swapcontext(&w->ctx[w->current], &w->sched);
+}
+
+unsigned char* rl_emu_smem() {
+    // 16-byte aligned view of the block's LDS image
+    auto p = reinterpret_cast<uintptr_t>(tl_worker->smem.data());
+    return reinterpret_cast<unsigned char*>((p + 15) & ~uintptr_t(15));
+}
+
+void rl_emu_launch(dim3 grid, dim3 block, size_t smem_bytes,
+                   const std::function<void()>& body) {
+    const size_t nblocks = size_t(grid.x) * grid.y * grid.z;
+    if (nblocks == 0) return;
+    unsigned nworkers = std::thread::hardware_concurrency();
+    if (nworkers == 0) nworkers = 1;
+    if (nworkers > 8) nworkers = 8;
+    if (nworkers > nblocks) nworkers = unsigned(nblocks);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        Worker w;
+        w.body = &body;
+        tl_worker = &w;
+        gridDim = {grid.x, grid.y, grid.z};
+        blockDim = {block.x, block.y, block.z};
+        for (;;) {
+            size_t b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            blockIdx.x = unsigned(b % grid.x);
+            blockIdx.y = unsigned((b / grid.x) % grid.y);
+            blockIdx.z = unsigned(b / (size_t(grid.x) * grid.y));
+            run_block(w, block, smem_bytes);
+        }
+        tl_worker = nullptr;
+    };
+    if (nworkers == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nworkers; ++i) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+}
+
+// --- runtime API stand-ins --------------------------------------------------
+hipError_t hipMalloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (posix_memalign(p, 256, bytes) != 0) return hipErrorOutOfMemory;
+    std::memset(*p, 0xAB, bytes);  // device memory is not zero-initialised
+    return hipSuccess;
+}
+hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+    std::memmove(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k,
+                          hipStream_t) {
+    return hipMemcpy(d, s, n, k);
+}
+hipError_t hipMemset(void* p, int v, size_t n) {
+    std::memset(p, v, n);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    return hipMemset(p, v, n);
+}
+hipError_t hipSetDevice(int d) { g_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = g_device; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipPeekAtLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) {
+    return e == hipSuccess ? "hipSuccess" : "emulated HIP error";
+}
+
+struct rl_emu_event { std::chrono::steady_clock::time_point t; };
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new rl_emu_event; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    e->t = std::chrono::steady_clock::now();
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
