@@ -95,6 +95,50 @@ int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void* stream);
 int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream);
 int rl_ski_apply_w(rl_ski* s, const double* G, double* Y, int nvec, void* stream);
 
+/* ---- batched Krylov solves  K~ X = B  --------------------------------------
+ * Replaces Iterative.solve (runlmc/approx/iterative.py:23-62) and the N+1
+ * pool-mapped solves of StochasticDerivService._concurrent_solve
+ * (runlmc/lmc/stochastic_deriv.py:39-52).  All right-hand sides advance
+ * together, each with its own recurrence scalars and stopping state.
+ *   B, X      dev [nrhs][n]   (X is written; initial guess is 0 as in the
+ *                              reference)
+ *   method    RL_MINRES (reference default, stochastic_deriv.py:37) or RL_CG
+ *   tol       absolute residual target of the reference's rule; the inner
+ *             method runs with rtol = min(1e-10, tol) (iterative.py:50-51)
+ *   check_every  explicit-residual check period (reference: 100,
+ *             iterative.py:39); a system whose ||b - K~x||_2 < tol at a check
+ *             is frozen; 0 disables the rule
+ *   maxiter   <= 0 means n (iterative.py:51)
+ *   iters_out host [nrhs] iterations run (the reference's callback count),
+ *   resid_out host [nrhs] final ||b - K~x||_2 (iterative.py:54),
+ *   istop_out host [nrhs] exit reason: SciPy minres istop codes 1..6, -1;
+ *             10 = reference residual rule; 11 = zero right-hand side.
+ * Any of the three output pointers may be NULL.  Synchronises before it
+ * returns.  Non-convergence is NOT an error (the reference logs and returns
+ * the iterate, iterative.py:55-58).                                          */
+#define RL_MINRES 0
+#define RL_CG 1
+int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method, double tol,
+                   int check_every, int maxiter, int* iters_out, double* resid_out,
+                   int* istop_out, void* stream);
+
+/* ---- partial sums of the Hutchinson gradient --------------------------------
+ * Replace the P*(N+1) operator products of StochasticDeriv.d_normal_quadratic
+ * / d_logdet_K (runlmc/lmc/stochastic_deriv.py:69-78) driven by
+ * LMCLikelihood's loops (runlmc/lmc/likelihood.py:48-96): with u~ = W^T u
+ * reshaped D x m,  u^T W (dB (x) T) W^T v = sum_ab dB[a,b] u~_a . (T v~_b), so
+ * one D x D Gram matrix per (vector pair, top row) serves every
+ * coregionalisation parameter at once.
+ *   out[v][a][b] = sum_i U[v][a*m+i] * V[v][b*m+i];  U, V dev [nvec][D*m],
+ *   out dev [nvec][D][D].                                                     */
+int rl_cross_dots(const double* U, const double* V, int nvec, int D, int m, double* out,
+                  void* stream);
+/* out[v][d] = sum_{i in output d} U[v][i] * V[v][i] over data-space vectors
+ * (noise gradient, likelihood.py:89-96 with Diag(repeat(e_d, lens))):
+ * offsets dev int[D+1], U, V dev [nvec][n], out dev [nvec][D].                */
+int rl_segment_dots(const double* U, const double* V, const int* offsets, int nvec, int n,
+                    int D, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,3 +198,39 @@ class SkiOp:
         t, single = _vec_batch(self.lib, X, self.n, self.device)
         y = self.mvm(t).cpu().numpy()
         return y[0] if single else y
+
+
+MINRES, CG = 0, 1
+
+
+def solve_batch(ski, B, method=MINRES, tol=1e-4, check_every=100, maxiter=0):
+    """Device batched solve K~ X = B.  B: (k, n) tensor on ski.device.
+    Returns (X tensor, iterations int[k], residuals float[k], istop int[k])."""
+    k = B.shape[0]
+    X = torch.empty_like(B)
+    iters = np.zeros(k, dtype=np.int32)
+    istop = np.zeros(k, dtype=np.int32)
+    resid = np.zeros(k, dtype=np.float64)
+    ski.lib.call('rl_solve_batch', ski.handle, dev_ptr(B), dev_ptr(X), k,
+                 int(method), float(tol), int(check_every), int(maxiter),
+                 host_ptr(iters), host_ptr(resid), host_ptr(istop),
+                 ski.lib.stream_ptr(ski.device))
+    return X, iters, resid, istop
+
+
+def cross_dots(lib, U, V, D, m):
+    """out[v, a, b] = <U[v, a-th block], V[v, b-th block]> on the device."""
+    k = U.shape[0]
+    out = torch.empty((k, D, D), dtype=torch.float64, device=U.device)
+    lib.call('rl_cross_dots', dev_ptr(U), dev_ptr(V), k, int(D), int(m),
+             dev_ptr(out), lib.stream_ptr(U.device))
+    return out
+
+
+def segment_dots(lib, U, V, offsets_dev, D):
+    """out[v, d] = sum over output d's slice of U[v] * V[v]."""
+    k, n = U.shape
+    out = torch.empty((k, D), dtype=torch.float64, device=U.device)
+    lib.call('rl_segment_dots', dev_ptr(U), dev_ptr(V), dev_ptr(offsets_dev),
+             k, int(n), int(D), dev_ptr(out), lib.stream_ptr(U.device))
+    return out

@@ -1,0 +1,63 @@
+"""Krylov solve front end (mirror of reference
+runlmc/approx/iterative.py:19-62), batched on the device.
+
+``Iterative.solve(K, y, verbose=False, minres=True, tol=1e-4)`` keeps the
+reference's contract: inner method tolerance min(1e-10, tol), at most n
+iterations, an explicit ``||y - K x|| < tol`` exit every 100 iterations, a
+CRITICAL log (not an exception) on non-convergence.  ``y`` may also be an
+(k, n) block of right-hand sides (rows), which is how the N+1 solves of a
+gradient step are issued as ONE call (rl_solve_batch)."""
+import logging
+
+import numpy as np
+import torch
+
+from .._native import solve_batch, MINRES, CG
+from .._lib import as_f64
+
+_LOG = logging.getLogger(__name__)
+
+
+def _device_operator(K):
+    op = getattr(K, 'device_operator', None)
+    if op is None:
+        raise TypeError(
+            'Iterative.solve needs a device-resident operator (the result of '
+            'runlmc_amd.lmc.grid_kernel.gen_grid_kernel); got {}. runlmc_amd '
+            'has no host solver.'.format(type(K).__name__))
+    return op() if callable(op) else op
+
+
+class Iterative:
+    """Target solve() tolerance. Only errors > tol reported."""
+
+    CHECK_EVERY = 100      # reference iterative.py:39
+
+    @staticmethod
+    def solve_device(K, B, minres=True, tol=1e-4, maxiter=0):
+        """B: (k, n) float64 tensor on the operator's device.  Returns
+        (X tensor, iterations, residuals, istop) without leaving the GPU."""
+        ski = _device_operator(K)
+        return solve_batch(ski, B.contiguous(), MINRES if minres else CG,
+                           tol=tol, check_every=Iterative.CHECK_EVERY,
+                           maxiter=maxiter)
+
+    @staticmethod
+    def solve(K, y, verbose=False, minres=True, tol=1e-4):
+        ski = _device_operator(K)
+        y = as_f64(y)
+        single = y.ndim == 1
+        B = torch.from_numpy(np.atleast_2d(y)).to(ski.device)
+        if B.shape[1] != K.shape[0]:
+            raise ValueError('right-hand side has length {}, operator is {}'
+                             .format(B.shape[1], K.shape))
+        X, iters, resid, istop = Iterative.solve_device(K, B, minres, tol)
+        X = X.cpu().numpy()
+        n = K.shape[0]
+        for r, code in zip(resid, istop):
+            if r > tol or code == 6:
+                _LOG.critical('MINRES (n = %d) did not converge in n iterations.'
+                              ' Reconstruction error %e', n, r)
+        if single:
+            return (X[0], int(iters[0]), float(resid[0])) if verbose else X[0]
+        return (X, iters, resid) if verbose else X

@@ -1,0 +1,476 @@
+// Batched Krylov solves on the device: MINRES (Paige & Saunders) and CG for
+// many right-hand sides at once, one operator.
+//
+// Replaces Iterative.solve (reference runlmc/approx/iterative.py:23-62) and
+// the N+1 independent pool-mapped solves of StochasticDerivService
+// (runlmc/lmc/stochastic_deriv.py:39-52).  The reference delegates the
+// iteration itself to scipy.sparse.linalg.minres / cg; the recurrences and
+// stopping tests below follow those (SciPy 1.15.3 _isolve/minres.py,
+// _isolve/iterative.py), restated in oracle/solver.py, so that iterates,
+// iteration counts and exit reasons can be compared one to one.
+//
+// Every right-hand side keeps its own scalars in device memory; nothing
+// returns to the host inside an iteration.  A right-hand side that has met a
+// stopping rule is frozen (its x stops changing) while the others continue.
+// Dot products are two-stage and deterministic: each workgroup writes one
+// partial per (rhs, block), and the NEXT kernel sums the partials of its rhs
+// in a fixed order.
+#pragma once
+#include "rl_device.h"
+
+#define RL_SOLVER_THREADS 256
+
+// per-rhs scalar state (doubles)
+enum {
+    S_BETA1 = 0, S_OLDB, S_BETA, S_DBAR, S_EPSLN, S_PHIBAR, S_RHS1, S_RHS2, S_TNORM2,
+    S_GMAX, S_GMIN, S_CS, S_SN, S_ALFA, S_PHI, S_OLDEPS, S_DELTA, S_DENOM, S_ROOT,
+    S_GBAR, S_RESID, S_BNORM, S_RHO, S_RHO_PREV, S_CG_ATOL,
+    S_NFIELDS
+};
+// per-rhs integer state
+enum { I_ISTOP = 0, I_ITN, I_ACTIVE, I_NFIELDS };
+
+// exit reasons beyond SciPy's istop codes
+#define RL_ISTOP_RESIDUAL 10   // reference rule: ||b - A x|| < tol at a check
+#define RL_ISTOP_ZERO_RHS 11
+
+__device__ __forceinline__ double block_reduce_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ double sum_partials(const double* p, int nblk) {
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += p[i];
+    return s;
+}
+
+__device__ __forceinline__ void block_range(int n, int* lo, int* hi) {
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    *lo = blockIdx.x * per;
+    *hi = *lo + per < n ? *lo + per : n;
+}
+
+// ---- shared by both methods -------------------------------------------------
+// partial[rhs][blk] = sum_i a[i] * b[i]
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_dot_partial(const double* __restrict__ a, const double* __restrict__ b, int n,
+              double* __restrict__ partial) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const double* pa = a + (size_t)rhs * n;
+    const double* pb = b + (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = fma(pa[i], pb[i], acc);
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partial[(size_t)rhs * gridDim.x + blockIdx.x] = acc;
+}
+
+// partial[rhs][blk] = sum_i (b[i] - ax[i])^2
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_resid_partial(const double* __restrict__ b, const double* __restrict__ ax, int n,
+                double* __restrict__ partial) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const double* pb = b + (size_t)rhs * n;
+    const double* pa = ax + (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double r = pb[i] - pa[i];
+        acc = fma(r, r, acc);
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partial[(size_t)rhs * gridDim.x + blockIdx.x] = acc;
+}
+
+// one thread per rhs: residual norm from partials; optionally freeze
+__global__ void k_resid_finish(const double* __restrict__ partial, int nblk, int nrhs,
+                               double* __restrict__ S, int* __restrict__ I, double tol,
+                               int freeze) {
+    const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rhs >= nrhs) return;
+    const double r = sqrt(sum_partials(partial + (size_t)rhs * nblk, nblk));
+    S[(size_t)rhs * S_NFIELDS + S_RESID] = r;
+    if (freeze && I[rhs * I_NFIELDS + I_ACTIVE] && r < tol) {
+        I[rhs * I_NFIELDS + I_ACTIVE] = 0;
+        I[rhs * I_NFIELDS + I_ISTOP] = RL_ISTOP_RESIDUAL;
+    }
+}
+
+// *count = number of still-active right-hand sides
+__global__ void k_count_active(const int* __restrict__ I, int nrhs, int* __restrict__ count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int c = 0;
+        for (int r = 0; r < nrhs; ++r) c += I[r * I_NFIELDS + I_ACTIVE] ? 1 : 0;
+        *count = c;
+    }
+}
+
+// ---- MINRES -----------------------------------------------------------------
+// init: x = 0, r1 = r2 = b, w = w2 = 0, v = b / beta1; partial = b.b comes
+// from k_dot_partial(b, b).
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
+              double* __restrict__ x, double* __restrict__ r1, double* __restrict__ r2,
+              double* __restrict__ w1, double* __restrict__ w2, double* __restrict__ v,
+              double* __restrict__ S, int* __restrict__ I) {
+    const int rhs = blockIdx.y;
+    const int nblk = gridDim.x;
+    const double bb = sum_partials(partial + (size_t)rhs * nblk, nblk);
+    const double beta1 = sqrt(bb);
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    const double s = beta1 > 0.0 ? 1.0 / beta1 : 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double bi = b[off + i];
+        x[off + i] = 0.0;
+        r1[off + i] = bi;
+        r2[off + i] = bi;
+        w1[off + i] = 0.0;
+        w2[off + i] = 0.0;
+        v[off + i] = s * bi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double* st = S + (size_t)rhs * S_NFIELDS;
+        for (int f = 0; f < S_NFIELDS; ++f) st[f] = 0.0;
+        st[S_BETA1] = beta1;
+        st[S_BETA] = beta1;
+        st[S_PHIBAR] = beta1;
+        st[S_RHS1] = beta1;
+        st[S_GMIN] = 1.7976931348623157e308;
+        st[S_CS] = -1.0;
+        st[S_BNORM] = beta1;
+        int* it = I + rhs * I_NFIELDS;
+        it[I_ITN] = 0;
+        it[I_ISTOP] = beta1 > 0.0 ? 0 : RL_ISTOP_ZERO_RHS;
+        it[I_ACTIVE] = beta1 > 0.0 ? 1 : 0;
+    }
+}
+
+// step A (y = A v already computed): y -= (beta/oldb) r1 (itn >= 2);
+// partialA = v . y
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres_a(double* __restrict__ y, const double* __restrict__ v, const double* __restrict__ r1,
+           int n, const double* __restrict__ S, const int* __restrict__ I,
+           double* __restrict__ partialA) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    if (!I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    const double* st = S + (size_t)rhs * S_NFIELDS;
+    const int itn = I[rhs * I_NFIELDS + I_ITN] + 1;
+    const double coef = itn >= 2 ? st[S_BETA] / st[S_OLDB] : 0.0;
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        double yi = y[off + i];
+        if (itn >= 2) yi = yi - coef * r1[off + i];
+        y[off + i] = yi;
+        acc = fma(v[off + i], yi, acc);
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partialA[(size_t)rhs * gridDim.x + blockIdx.x] = acc;
+}
+
+// step B: alfa = sum partialA; y -= (alfa/beta) r2; partialB = y . y
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres_b(double* __restrict__ y, const double* __restrict__ r2, int n,
+           const double* __restrict__ S, const int* __restrict__ I,
+           const double* __restrict__ partialA, double* __restrict__ partialB) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    if (!I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    const int nblk = gridDim.x;
+    const double alfa = sum_partials(partialA + (size_t)rhs * nblk, nblk);
+    const double coef = alfa / S[(size_t)rhs * S_NFIELDS + S_BETA];
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double yi = y[off + i] - coef * r2[off + i];
+        y[off + i] = yi;
+        acc = fma(yi, yi, acc);
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partialB[(size_t)rhs * nblk + blockIdx.x] = acc;
+}
+
+// step C: scalar recurrences (every block recomputes them from Sin, block 0
+// publishes to Sout), w = (v - oldeps w1 - delta w2) / gamma (written over
+// w1, which becomes the newest w after the host rotates pointers),
+// x += phi w, partialC = x . x, v <- y / beta_new.
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres_c(const double* __restrict__ y, double* __restrict__ v, double* __restrict__ w1,
+           const double* __restrict__ w2, double* __restrict__ x, int n,
+           const double* __restrict__ Sin, double* __restrict__ Sout,
+           const int* __restrict__ I, const double* __restrict__ partialA,
+           const double* __restrict__ partialB, double* __restrict__ partialC) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    const int nblk = gridDim.x;
+    const double* si = Sin + (size_t)rhs * S_NFIELDS;
+    double* so = Sout + (size_t)rhs * S_NFIELDS;
+    if (!I[rhs * I_NFIELDS + I_ACTIVE]) {
+        // keep the ping-pong copies identical for frozen systems
+        if (blockIdx.x == 0 && threadIdx.x < S_NFIELDS) so[threadIdx.x] = si[threadIdx.x];
+        return;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double alfa = sum_partials(partialA + (size_t)rhs * nblk, nblk);
+    double beta = sum_partials(partialB + (size_t)rhs * nblk, nblk);
+    beta = sqrt(beta > 0.0 ? beta : 0.0);
+    const double oldb = si[S_BETA];
+    const double tnorm2 = si[S_TNORM2] + alfa * alfa + oldb * oldb + beta * beta;
+    const double cs0 = si[S_CS], sn0 = si[S_SN], dbar0 = si[S_DBAR];
+    const double oldeps = si[S_EPSLN];
+    const double delta = cs0 * dbar0 + sn0 * alfa;
+    const double gbar = sn0 * dbar0 - cs0 * alfa;
+    const double epsln = sn0 * beta;
+    const double dbar = -cs0 * beta;
+    const double root = hypot(gbar, dbar);
+    double gamma = hypot(gbar, beta);
+    gamma = gamma > eps ? gamma : eps;
+    const double cs = gbar / gamma;
+    const double sn = beta / gamma;
+    const double phi = cs * si[S_PHIBAR];
+    const double phibar = sn * si[S_PHIBAR];
+    const double denom = 1.0 / gamma;
+
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    const double sinv = beta > 0.0 ? 1.0 / beta : 0.0;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double wn = (v[off + i] - oldeps * w1[off + i] - delta * w2[off + i]) * denom;
+        w1[off + i] = wn;
+        const double xi = x[off + i] + phi * wn;
+        x[off + i] = xi;
+        acc = fma(xi, xi, acc);
+        v[off + i] = sinv * y[off + i];
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partialC[(size_t)rhs * nblk + blockIdx.x] = acc;
+
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int f = 0; f < S_NFIELDS; ++f) so[f] = si[f];
+        so[S_OLDB] = oldb;
+        so[S_BETA] = beta;
+        so[S_TNORM2] = tnorm2;
+        so[S_DBAR] = dbar;
+        so[S_EPSLN] = epsln;
+        so[S_CS] = cs;
+        so[S_SN] = sn;
+        so[S_PHIBAR] = phibar;
+        so[S_PHI] = phi;
+        so[S_ALFA] = alfa;
+        so[S_OLDEPS] = oldeps;
+        so[S_DELTA] = delta;
+        so[S_DENOM] = denom;
+        so[S_ROOT] = root;
+        so[S_GBAR] = gbar;
+        const double gmax = si[S_GMAX] > gamma ? si[S_GMAX] : gamma;
+        const double gmin = si[S_GMIN] < gamma ? si[S_GMIN] : gamma;
+        so[S_GMAX] = gmax;
+        so[S_GMIN] = gmin;
+        const double z = si[S_RHS1] / gamma;
+        so[S_RHS1] = si[S_RHS2] - delta * z;
+        so[S_RHS2] = -epsln * z;
+    }
+}
+
+// step D (one thread per rhs): ynorm from partialC, SciPy's stopping tests.
+__global__ void k_minres_test(double* __restrict__ S, int* __restrict__ I,
+                              const double* __restrict__ partialC, int nblk, int nrhs,
+                              double rtol, int maxiter) {
+    const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rhs >= nrhs) return;
+    int* it = I + rhs * I_NFIELDS;
+    if (!it[I_ACTIVE]) return;
+    const double eps = 2.220446049250313e-16;
+    const double* st = S + (size_t)rhs * S_NFIELDS;
+    const int itn = it[I_ITN] + 1;
+    it[I_ITN] = itn;
+    int istop = 0;
+    const double beta1 = st[S_BETA1];
+    if (itn == 1 && st[S_BETA] / beta1 <= 10 * eps) istop = -1;
+    const double Anorm = sqrt(st[S_TNORM2]);
+    const double ynorm = sqrt(sum_partials(partialC + (size_t)rhs * nblk, nblk));
+    const double epsx = Anorm * ynorm * eps;
+    const double rnorm = st[S_PHIBAR];
+    const double inf = 1.0 / 0.0;
+    const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? inf : rnorm / (Anorm * ynorm);
+    const double test2 = Anorm == 0.0 ? inf : st[S_ROOT] / Anorm;
+    const double Acond = st[S_GMAX] / st[S_GMIN];
+    if (istop == 0) {
+        const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+        if (t2 <= 1.0) istop = 2;
+        if (t1 <= 1.0) istop = 1;
+        if (itn >= maxiter) istop = 6;
+        if (Acond >= 0.1 / eps) istop = 4;
+        if (epsx >= beta1) istop = 3;
+        if (test2 <= rtol) istop = 2;
+        if (test1 <= rtol) istop = 1;
+    }
+    if (istop != 0) {
+        it[I_ISTOP] = istop;
+        it[I_ACTIVE] = 0;
+    }
+}
+
+// ---- CG ---------------------------------------------------------------------
+// init: x = 0, r = b, p = 0; partial = b.b
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_cg_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
+          double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+          double* __restrict__ S, int* __restrict__ I, double rtol) {
+    const int rhs = blockIdx.y;
+    const int nblk = gridDim.x;
+    const double bb = sum_partials(partial + (size_t)rhs * nblk, nblk);
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        x[off + i] = 0.0;
+        r[off + i] = b[off + i];
+        p[off + i] = 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double* st = S + (size_t)rhs * S_NFIELDS;
+        for (int f = 0; f < S_NFIELDS; ++f) st[f] = 0.0;
+        st[S_BNORM] = sqrt(bb);
+        st[S_CG_ATOL] = rtol * sqrt(bb);
+        st[S_RHO] = bb;        // r.r with r = b
+        int* it = I + rhs * I_NFIELDS;
+        it[I_ITN] = 0;
+        it[I_ISTOP] = bb > 0.0 ? 0 : RL_ISTOP_ZERO_RHS;
+        it[I_ACTIVE] = bb > 0.0 ? 1 : 0;
+    }
+}
+
+// loop head (one thread per rhs): rho = sum partial (r.r) unless first;
+// SciPy tests ||r|| < atol BEFORE the update; maxiter exhaustion
+__global__ void k_cg_head(double* __restrict__ S, int* __restrict__ I,
+                          const double* __restrict__ partialR, int nblk, int nrhs, int first,
+                          int maxiter) {
+    const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rhs >= nrhs) return;
+    int* it = I + rhs * I_NFIELDS;
+    if (!it[I_ACTIVE]) return;
+    double* st = S + (size_t)rhs * S_NFIELDS;
+    if (!first) {
+        st[S_RHO_PREV] = st[S_RHO];
+        st[S_RHO] = sum_partials(partialR + (size_t)rhs * nblk, nblk);
+    }
+    if (sqrt(st[S_RHO]) < st[S_CG_ATOL]) {
+        it[I_ISTOP] = 1;
+        it[I_ACTIVE] = 0;
+    } else if (it[I_ITN] >= maxiter) {
+        it[I_ISTOP] = 6;
+        it[I_ACTIVE] = 0;
+    }
+}
+
+// p = r + (rho/rho_prev) p   (p = r on the first iteration)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_cg_p(double* __restrict__ p, const double* __restrict__ r, int n,
+       const double* __restrict__ S, const int* __restrict__ I) {
+    const int rhs = blockIdx.y;
+    if (!I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    const double* st = S + (size_t)rhs * S_NFIELDS;
+    const int first = I[rhs * I_NFIELDS + I_ITN] == 0;
+    const double beta = first ? 0.0 : st[S_RHO] / st[S_RHO_PREV];
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x)
+        p[off + i] = first ? r[off + i] : beta * p[off + i] + r[off + i];
+}
+
+// alpha = rho / sum partialPQ; x += alpha p; r -= alpha q; partialR = r.r
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_cg_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+            const double* __restrict__ q, int n, const double* __restrict__ S,
+            int* __restrict__ I, const double* __restrict__ partialPQ,
+            double* __restrict__ partialR) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    if (!I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    const int nblk = gridDim.x;
+    const double pq = sum_partials(partialPQ + (size_t)rhs * nblk, nblk);
+    const double alpha = S[(size_t)rhs * S_NFIELDS + S_RHO] / pq;
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        x[off + i] += alpha * p[off + i];
+        const double ri = r[off + i] - alpha * q[off + i];
+        r[off + i] = ri;
+        acc = fma(ri, ri, acc);
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) partialR[(size_t)rhs * nblk + blockIdx.x] = acc;
+}
+
+// bump iteration counters of active systems (callback count in the reference)
+__global__ void k_count_iter(int* __restrict__ I, int nrhs) {
+    const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rhs >= nrhs) return;
+    if (I[rhs * I_NFIELDS + I_ACTIVE]) I[rhs * I_NFIELDS + I_ITN] += 1;
+}
+
+// ---- gradient partial sums --------------------------------------------------
+// out[v][a][b] = sum_i U[v][a*m + i] * V[v][b*m + i]   (D x D Gram per vector)
+//   grid (D*D, nvec)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_cross_dots(const double* __restrict__ U, const double* __restrict__ V, int D, int m,
+             double* __restrict__ out) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int a = blockIdx.x / D, b = blockIdx.x % D, v = blockIdx.y;
+    const double* u = U + ((size_t)v * D + a) * m;
+    const double* w = V + ((size_t)v * D + b) * m;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) acc = fma(u[i], w[i], acc);
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) out[((size_t)v * D + a) * D + b] = acc;
+}
+
+// out[v][d] = sum_{i in segment d} U[v][i] * V[v][i];  segments given by
+// offsets[D+1] (per-output slices of a data-space vector)   grid (D, nvec)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_segment_dots(const double* __restrict__ U, const double* __restrict__ V,
+               const int* __restrict__ offsets, int n, int D, double* __restrict__ out) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int d = blockIdx.x, v = blockIdx.y;
+    const double* u = U + (size_t)v * n;
+    const double* w = V + (size_t)v * n;
+    double acc = 0.0;
+    for (int i = offsets[d] + threadIdx.x; i < offsets[d + 1]; i += blockDim.x)
+        acc = fma(u[i], w[i], acc);
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) out[(size_t)v * D + d] = acc;
+}

@@ -657,3 +657,189 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
     return ski_apply_w_impl(s, s->G2, Y, nvec, s->has_noise ? s->noise_diag : nullptr, X,
                             (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------
+// batched Krylov solves
+// ---------------------------------------------------------------------------
+#include "rl_solver.h"
+
+struct SolverWork {
+    double* vec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* S[2] = {nullptr, nullptr};
+    int* I = nullptr;
+    double* part[3] = {nullptr, nullptr, nullptr};
+    int* count = nullptr;
+};
+// frees a SolverWork at scope exit (kept apart so the plain struct can be
+// copied into launch closures)
+struct SolverWorkGuard {
+    SolverWork* w;
+    explicit SolverWorkGuard(SolverWork* w_) : w(w_) {}
+    ~SolverWorkGuard() {
+        for (double* p : w->vec) if (p) (void)hipFree(p);
+        for (double* p : w->S) if (p) (void)hipFree(p);
+        for (double* p : w->part) if (p) (void)hipFree(p);
+        if (w->I) (void)hipFree(w->I);
+        if (w->count) (void)hipFree(w->count);
+    }
+};
+
+static int solver_alloc(SolverWork& w, int nvecs, int nrhs, int n, int nblk) {
+    for (int i = 0; i < nvecs; ++i)
+        RL_HIP(hipMalloc((void**)&w.vec[i], (size_t)nrhs * n * sizeof(double)));
+    for (int i = 0; i < 2; ++i)
+        RL_HIP(hipMalloc((void**)&w.S[i], (size_t)nrhs * S_NFIELDS * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&w.I, (size_t)nrhs * I_NFIELDS * sizeof(int)));
+    for (int i = 0; i < 3; ++i)
+        RL_HIP(hipMalloc((void**)&w.part[i], (size_t)nrhs * nblk * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&w.count, sizeof(int)));
+    return RL_OK;
+}
+
+static int active_count(SolverWork& w, int nrhs, hipStream_t st, int* out) {
+    RL_LAUNCH(k_count_active, dim3(1), dim3(64), 0, st, w.I, nrhs, w.count);
+    RL_HIP(hipMemcpyAsync(out, w.count, sizeof(int), hipMemcpyDeviceToHost, st));
+    RL_HIP(hipStreamSynchronize(st));
+    return RL_OK;
+}
+
+// explicit residual ||b - K x|| of every system into resid_dev[nrhs]; freeze
+// those below tol when `freeze`
+static int residual_check(rl_ski* s, SolverWork& w, const double* B, const double* X,
+                          double* scratch, int nrhs, int n, int nblk, double tol, int freeze,
+                          double* Scur, hipStream_t st) {
+    RL_TRY(rl_ski_mvm(s, X, scratch, nrhs, st));
+    dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
+    const size_t red = RL_SOLVER_THREADS * sizeof(double);
+    RL_LAUNCH(k_resid_partial, grid, blk, red, st, B, (const double*)scratch, n, w.part[2]);
+    RL_LAUNCH(k_resid_finish, dim3((nrhs + 63) / 64), dim3(64), 0, st,
+              (const double*)w.part[2], nblk, nrhs, Scur, w.I, tol, freeze);
+    return RL_OK;
+}
+
+extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method,
+                              double tol, int check_every, int maxiter, int* iters_out,
+                              double* resid_out, int* istop_out, void* stream) {
+    if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_batch: NULL argument");
+    if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_batch: nrhs < 0");
+    if (method != RL_MINRES && method != RL_CG)
+        return fail(RL_EINVAL, "rl_solve_batch: unknown method");
+    if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_batch: tol must be > 0");
+    if (check_every < 0) return fail(RL_EINVAL, "rl_solve_batch: check_every < 0");
+    if (nrhs == 0) return RL_OK;
+    RL_HIP(hipSetDevice(s->g->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int n = s->n;
+    if (maxiter <= 0) maxiter = n;
+    const double rtol = tol < 1e-10 ? tol : 1e-10;
+    int nblk = (n + 1023) / 1024;
+    nblk = std::max(1, std::min(nblk, 64));
+    dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
+    const size_t red = RL_SOLVER_THREADS * sizeof(double);
+    dim3 grid1((nrhs + 63) / 64), blk1(64);
+    const int poll_every = 10;
+
+    SolverWork w;
+    SolverWorkGuard guard(&w);
+    RL_TRY(solver_alloc(w, method == RL_MINRES ? 6 : 4, nrhs, n, nblk));
+    int cur = 0;   // index of the current scalar-state copy
+    int active = nrhs;
+
+    RL_LAUNCH(k_dot_partial, grid, blk, red, st, B, B, n, w.part[0]);
+    if (method == RL_MINRES) {
+        double *r1 = w.vec[0], *r2 = w.vec[1], *y = w.vec[2], *v = w.vec[3];
+        double *wa = w.vec[4], *wb = w.vec[5];
+        RL_LAUNCH(k_minres_init, grid, blk, 0, st, B, n, (const double*)w.part[0], X, r1, r2,
+                  wa, wb, v, w.S[0], w.I);
+        RL_HIP(hipMemcpyAsync(w.S[1], w.S[0], (size_t)nrhs * S_NFIELDS * sizeof(double),
+                              hipMemcpyDeviceToDevice, st));
+        RL_TRY(active_count(w, nrhs, st, &active));
+        for (int it = 1; it <= maxiter && active > 0; ++it) {
+            RL_TRY(rl_ski_mvm(s, v, y, nrhs, st));
+            RL_LAUNCH(k_minres_a, grid, blk, red, st, y, (const double*)v, (const double*)r1,
+                      n, (const double*)w.S[cur], (const int*)w.I, w.part[0]);
+            RL_LAUNCH(k_minres_b, grid, blk, red, st, y, (const double*)r2, n,
+                      (const double*)w.S[cur], (const int*)w.I, (const double*)w.part[0],
+                      w.part[1]);
+            RL_LAUNCH(k_minres_c, grid, blk, red, st, (const double*)y, v, wa,
+                      (const double*)wb, X, n, (const double*)w.S[cur], w.S[1 - cur],
+                      (const int*)w.I, (const double*)w.part[0], (const double*)w.part[1],
+                      w.part[2]);
+            cur = 1 - cur;
+            RL_LAUNCH(k_minres_test, grid1, blk1, 0, st, w.S[cur], w.I,
+                      (const double*)w.part[2], nblk, nrhs, rtol, maxiter);
+            // rotate: r1 <- r2, r2 <- y, y <- old r1 (free);  w_{k-2} <-> w_{k-1}
+            double* t = r1; r1 = r2; r2 = y; y = t;
+            t = wa; wa = wb; wb = t;
+            const bool check = check_every > 0 && it % check_every == 0;
+            if (check)
+                RL_TRY(residual_check(s, w, B, X, y, nrhs, n, nblk, tol, 1, w.S[cur], st));
+            if (check || it % poll_every == 0) RL_TRY(active_count(w, nrhs, st, &active));
+        }
+        RL_TRY(residual_check(s, w, B, X, y, nrhs, n, nblk, tol, 0, w.S[cur], st));
+    } else {
+        double *r = w.vec[0], *p = w.vec[1], *q = w.vec[2], *scratch = w.vec[3];
+        RL_LAUNCH(k_cg_init, grid, blk, 0, st, B, n, (const double*)w.part[0], X, r, p, w.S[0],
+                  w.I, rtol);
+        RL_TRY(active_count(w, nrhs, st, &active));
+        for (int it = 1; active > 0; ++it) {
+            RL_LAUNCH(k_cg_head, grid1, blk1, 0, st, w.S[0], w.I, (const double*)w.part[1],
+                      nblk, nrhs, it == 1 ? 1 : 0, maxiter);
+            RL_LAUNCH(k_cg_p, grid, blk, 0, st, p, (const double*)r, n, (const double*)w.S[0],
+                      (const int*)w.I);
+            RL_TRY(rl_ski_mvm(s, p, q, nrhs, st));
+            RL_LAUNCH(k_dot_partial, grid, blk, red, st, (const double*)p, (const double*)q, n,
+                      w.part[0]);
+            RL_LAUNCH(k_cg_update, grid, blk, red, st, X, r, (const double*)p,
+                      (const double*)q, n, (const double*)w.S[0], w.I,
+                      (const double*)w.part[0], w.part[1]);
+            RL_LAUNCH(k_count_iter, grid1, blk1, 0, st, w.I, nrhs);
+            const bool check = check_every > 0 && it % check_every == 0;
+            if (check)
+                RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 1, w.S[0], st));
+            if (check || it % poll_every == 0 || it > maxiter)
+                RL_TRY(active_count(w, nrhs, st, &active));
+            if (it > maxiter + 1) break;
+        }
+        RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 0, w.S[0], st));
+        cur = 0;
+    }
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(st));
+    std::vector<int> hI((size_t)nrhs * I_NFIELDS);
+    std::vector<double> hS((size_t)nrhs * S_NFIELDS);
+    RL_HIP(hipMemcpy(hI.data(), w.I, hI.size() * sizeof(int), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(hS.data(), w.S[cur], hS.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < nrhs; ++r) {
+        if (iters_out) iters_out[r] = hI[(size_t)r * I_NFIELDS + I_ITN];
+        if (istop_out) istop_out[r] = hI[(size_t)r * I_NFIELDS + I_ISTOP];
+        if (resid_out) resid_out[r] = hS[(size_t)r * S_NFIELDS + S_RESID];
+    }
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gradient partial sums
+// ---------------------------------------------------------------------------
+extern "C" int rl_cross_dots(const double* U, const double* V, int nvec, int D, int m,
+                             double* out, void* stream) {
+    if (!U || !V || !out) return fail(RL_EINVAL, "rl_cross_dots: NULL argument");
+    if (nvec < 0 || D < 1 || m < 1) return fail(RL_EINVAL, "rl_cross_dots: bad sizes");
+    if (nvec == 0) return RL_OK;
+    RL_LAUNCH(k_cross_dots, dim3(D * D, nvec), dim3(RL_SOLVER_THREADS),
+              RL_SOLVER_THREADS * sizeof(double), (hipStream_t)stream, U, V, D, m, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_segment_dots(const double* U, const double* V, const int* offsets, int nvec,
+                               int n, int D, double* out, void* stream) {
+    if (!U || !V || !offsets || !out) return fail(RL_EINVAL, "rl_segment_dots: NULL argument");
+    if (nvec < 0 || D < 1 || n < 1) return fail(RL_EINVAL, "rl_segment_dots: bad sizes");
+    if (nvec == 0) return RL_OK;
+    RL_LAUNCH(k_segment_dots, dim3(D, nvec), dim3(RL_SOLVER_THREADS),
+              RL_SOLVER_THREADS * sizeof(double), (hipStream_t)stream, U, V, offsets, n, D,
+              out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}

@@ -1,0 +1,152 @@
+"""Likelihood gradients for the LMC model (mirror of reference
+runlmc/lmc/likelihood.py:20-134), batched on the device.
+
+The reference builds one dK operator per hyper-parameter and spends N+1
+operator products on each (likelihood.py:48-96,112-131).  Every one of those
+dK is  W (dB (x) T) W^T  for a D x D matrix dB and a Toeplitz T that is either
+k_q or dk_q/dtheta, so with u~ = W^T u reshaped D x m
+
+    u^T dK v = sum_ab dB[a, b] * P_T(u, v)[a, b],   P_T(u, v)[a, b] = u~_a . T v~_b.
+
+One D x D matrix  G_T = (P_T(alpha, alpha) - mean_i P_T(K^-1 r_i, r_i)) / 2
+per top row T therefore yields every gradient that involves T:
+
+    d/dA_q     = A_q (G_q + G_q^T)          (dB = e_j a_i^T + a_i e_j^T)
+    d/dkappa_q = diag(G_q)                  (dB = e_i e_i^T)
+    d/dtheta   = sum_ab B_q[a, b] G'[a, b]  (T = dk_q/dtheta, dB = B_q)
+    d/deps_d   = (sum_{i in d} alpha_i^2 - mean_probe sum_{i in d} s_i r_i) / 2.
+
+Cost: (Q + sum_q p_q) batched Toeplitz products over the N+1 vectors instead
+of P (N+1) full operator products.  The probe sums are what the single
+all-reduce of a multi-GPU step carries.
+"""
+import numpy as np
+import torch
+
+from .._native import GridOp, cross_dots, segment_dots
+from .._lib import as_f64
+from ..util.dist import all_reduce_sum_
+
+
+class LMCLikelihood:
+    """Interface the functional kernel pulls gradients from."""
+
+    def __init__(self, functional_kernel, Ys):
+        self.functional_kernel = functional_kernel
+        self.y = np.hstack(Ys)
+        self.lens = [len(Y) for Y in Ys]
+
+    def alpha(self):
+        raise NotImplementedError
+
+    def coreg_vec_gradients(self):
+        raise NotImplementedError
+
+    def coreg_diags_gradients(self):
+        raise NotImplementedError
+
+    def kernel_gradients(self):
+        raise NotImplementedError
+
+    def noise_gradient(self):
+        raise NotImplementedError
+
+
+_GRAD_OPS = {}
+
+
+def _grad_operator(D, m, ntops, device_index):
+    """Top-row-only operators are parameter free apart from their spectra, so
+    one handle per shape is reused across optimiser steps."""
+    key = (D, m, device_index)
+    op = _GRAD_OPS.get(key)
+    if op is None or op.max_tops < ntops:
+        op = GridOp(D, m, ntops, device_index=device_index)
+        _GRAD_OPS[key] = op
+    return op
+
+
+class ApproxLMCLikelihood(LMCLikelihood):
+    def __init__(self, functional_kernel, grid_kern, grid_dists,
+                 interpolants, Ys, deriv, probes=None):
+        super().__init__(functional_kernel, Ys)
+        fk = functional_kernel
+        self.K = grid_kern
+        self.interpolants = interpolants
+        self.materialized_kernels = fk.eval_kernels(grid_dists)
+        self.materialized_grads = fk.eval_kernel_gradients(grid_dists)
+        if probes is None:
+            self.deriv = deriv.generate(self.K, self.y)
+        else:
+            self.deriv = deriv.generate(self.K, self.y, rs=probes)
+        self._parts = None
+
+    def alpha(self):
+        return self.deriv.alpha
+
+    # -- the batched partial sums ------------------------------------------------
+    def _partials(self):
+        if self._parts is not None:
+            return self._parts
+        fk = self.functional_kernel
+        D, Q = fk.D, fk.Q
+        dv = self.deriv
+        skiop = self.K.device_operator()
+        lib, dev = skiop.lib, skiop.device
+        tops = [as_f64(np.ravel(k)) for k in self.materialized_kernels]
+        dtops = [[as_f64(np.ravel(g)) for g in gl] for gl in self.materialized_grads]
+        flat_tops = tops + [g for gl in dtops for g in gl]
+        ntops = len(flat_tops)
+        m = flat_tops[0].shape[0]
+        gop = _grad_operator(D, m, ntops, skiop.grid.device_index)
+        gop.set_lmc(np.stack(flat_tops), [None] * ntops,
+                    [np.zeros(D)] * ntops)
+
+        nloc = dv.rs_dev.shape[0]
+        U = torch.cat([dv.alpha_dev[None, :], dv.inv_rs_dev], dim=0).contiguous()
+        V = torch.cat([dv.alpha_dev[None, :], dv.rs_dev], dim=0).contiguous()
+        Ut = skiop.apply_wt(U)
+        Vt = skiop.apply_wt(V)
+        P = torch.empty((ntops, nloc + 1, D, D), dtype=torch.float64, device=dev)
+        TV = torch.empty_like(Vt)
+        for t in range(ntops):
+            gop.mvm(Vt, out=TV, top=t)
+            P[t] = cross_dots(lib, Ut, TV, D, m)
+        offsets = torch.from_numpy(
+            np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int32)).to(dev)
+        seg = segment_dots(lib, U, V, offsets, D)          # (nloc + 1, D)
+
+        # alpha terms are identical on every rank; probe sums are reduced
+        probe = torch.cat([P[:, 1:].sum(dim=1).reshape(-1),
+                           seg[1:].sum(dim=0).reshape(-1)])
+        all_reduce_sum_(probe, dv._group)
+        N = dv._n_it
+        Psum = probe[:ntops * D * D].reshape(ntops, D, D)
+        ssum = probe[ntops * D * D:]
+        G = (0.5 * (P[:, 0] - Psum / N)).cpu().numpy()
+        noise = (0.5 * (seg[0] - ssum / N)).cpu().numpy()
+        self._parts = dict(G=G[:Q], Gd=G[Q:], noise=noise)
+        return self._parts
+
+    def coreg_vec_gradients(self):
+        G = self._partials()['G']
+        return [a.dot(G[q] + G[q].T)
+                for q, a in enumerate(self.functional_kernel.coreg_vecs)]
+
+    def coreg_diags_gradients(self):
+        G = self._partials()['G']
+        return [np.diag(G[q]).copy() for q in range(self.functional_kernel.Q)]
+
+    def kernel_gradients(self):
+        Gd = self._partials()['Gd']
+        out, t = [], 0
+        for q, B in enumerate(self.functional_kernel.coreg_mats()):
+            row = []
+            for _ in self.materialized_grads[q]:
+                row.append(float(np.sum(B * Gd[t])))
+                t += 1
+            out.append(row)
+        return out
+
+    def noise_gradient(self):
+        return self._partials()['noise'].copy()

@@ -1,0 +1,117 @@
+"""Probe generation, the N+1 solves and the Hutchinson estimator (mirror of
+reference runlmc/lmc/stochastic_deriv.py:12-78).
+
+``StochasticDerivService(metrics, pool, n_it, tol).generate(K, y)`` keeps the
+reference's signature; ``pool`` is accepted and ignored (the solves are one
+batched device call), and an optional torch.distributed ``group`` shards the
+probes over GPUs.
+"""
+import numpy as np
+import torch
+
+from .derivative import Derivative
+from ..approx.iterative import Iterative
+from ..util.dist import rank_world, shard_rows, all_reduce_sum_
+
+
+class StochasticDerivService:
+    def __init__(self, metrics, pool, n_it, tol, group=None):
+        self.metrics = metrics
+        self._pool = pool          # interface compatibility only
+        self._n_it = int(n_it)
+        self._tol = tol
+        self._group = group
+
+    def draw_probes(self, n):
+        """+-1 probes from NumPy's legacy global RNG exactly as the reference
+        draws them (stochastic_deriv.py:35); every rank draws the same
+        matrix (seed the RNG identically) and keeps its own rows."""
+        return np.random.randint(0, 2, (self._n_it, n)) * 2 - 1
+
+    def generate(self, K, y, rs=None):
+        """Solve K alpha = y and K s_i = r_i for this rank's probes.  `rs`
+        (n_it x n, entries +-1) may be passed explicitly (parity tests)."""
+        n = K.shape[0]
+        if rs is None:
+            rs = self.draw_probes(n)
+        rs = np.asarray(rs)
+        if rs.shape != (self._n_it, n):
+            raise ValueError('probes must have shape {}'.format((self._n_it, n)))
+        mine = shard_rows(self._n_it, self._group)
+        dev = K.device
+        rhs = np.vstack([np.asarray(y, dtype=np.float64)[None, :],
+                         rs[mine].astype(np.float64)])
+        B = torch.from_numpy(rhs).to(dev)
+        X, iters, resid, istop = Iterative.solve_device(
+            K, B, minres=True, tol=self._tol)
+        if self.metrics is not None:
+            stats = torch.tensor([float(iters.sum()), float(resid.sum()),
+                                  float(len(iters))], dtype=torch.float64)
+            # alpha is solved on every rank: count it once
+            _, world = rank_world(self._group)
+            if world > 1:
+                stats -= torch.tensor([float(iters[0]), float(resid[0]), 1.0],
+                                      dtype=torch.float64) * (
+                    0.0 if rank_world(self._group)[0] == 0 else 1.0)
+                all_reduce_sum_(stats, self._group)
+            self.metrics.iterations.append(float(stats[0] / stats[2]))
+            self.metrics.solv_error.append(float(stats[1] / stats[2]))
+        return StochasticDeriv(X[0], B[1:], X[1:], self._n_it, group=self._group,
+                               iterations=iters, residuals=resid, istop=istop)
+
+    def _concurrent_solve(self, ls):
+        """Reference entry point (stochastic_deriv.py:51-52): a list of
+        (K, rhs, verbose, minres, tol) tuples sharing one K."""
+        K = ls[0][0]
+        verbose, minres, tol = ls[0][2], ls[0][3], ls[0][4]
+        out = Iterative.solve(K, np.vstack([t[1] for t in ls]), verbose=True,
+                              minres=minres, tol=tol)
+        X, iters, resid = out
+        if verbose:
+            return [(X[i], int(iters[i]), float(resid[i])) for i in range(len(ls))]
+        return list(X)
+
+
+class StochasticDeriv(Derivative):
+    """alpha = K^-1 y, this rank's probes r_i and K^-1 r_i, all on the device.
+
+    ``n_it`` is the GLOBAL probe count (the 1/N of the estimator)."""
+
+    def __init__(self, alpha, rs, inv_rs, n_it, group=None, iterations=None,
+                 residuals=None, istop=None):
+        to_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(a, dtype=np.float64))
+        self.alpha_dev = to_t(alpha)
+        self.rs_dev = to_t(rs).to(self.alpha_dev.device)
+        self.inv_rs_dev = to_t(inv_rs).to(self.alpha_dev.device)
+        self._n_it = int(n_it)
+        self._group = group
+        self.iterations, self.residuals, self.istop = iterations, residuals, istop
+        self._alpha_host = None
+
+    @property
+    def alpha(self):
+        if self._alpha_host is None:
+            self._alpha_host = self.alpha_dev.cpu().numpy()
+        return self._alpha_host
+
+    @property
+    def _rs(self):
+        return self.rs_dev.cpu().numpy()
+
+    @property
+    def _inv_rs(self):
+        return self.inv_rs_dev.cpu().numpy()
+
+    # generic operator form, any Matrix dKdt (reference :69-78)
+    def d_normal_quadratic(self, dKdt):
+        return float(self.alpha.dot(dKdt.matvec(self.alpha)))
+
+    def d_logdet_K(self, dKdt):
+        rs, inv = self._rs, self._inv_rs
+        local = 0.0
+        if len(rs):
+            local = float(np.einsum('ij,ij->', inv, dKdt.matmat(rs.T.astype(float)).T))
+        tot = torch.tensor([local], dtype=torch.float64)
+        all_reduce_sum_(tot, self._group)
+        return float(tot[0]) / self._n_it

@@ -11,6 +11,8 @@
 #include <ucontext.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <thread>
@@ -25,7 +27,9 @@ constexpr size_t kStackBytes = 96 * 1024;
 struct Worker {
     ucontext_t sched;
     std::vector<ucontext_t> ctx;
-    std::vector<unsigned char> stacks;
+    unsigned char* stacks = nullptr;
+    size_t stacks_cap = 0;
+    ~Worker() { std::free(stacks); }
     std::vector<char> done;
     std::vector<unsigned char> smem;
     const std::function<void()>* body = nullptr;
@@ -43,15 +47,17 @@ void fiber_entry() {
 
 void run_block(Worker& w, dim3 block, size_t smem_bytes) {
     const unsigned nthr = block.x * block.y * block.z;
-    if (w.ctx.size() < nthr) {
-        w.ctx.resize(nthr);
-        w.stacks.resize(size_t(nthr) * kStackBytes);
+    if (w.ctx.size() < nthr) w.ctx.resize(nthr);
+    if (w.stacks_cap < size_t(nthr) * kStackBytes) {
+        std::free(w.stacks);
+        w.stacks_cap = size_t(nthr) * kStackBytes;
+        w.stacks = static_cast<unsigned char*>(std::malloc(w.stacks_cap));
     }
     w.done.assign(nthr, 0);
     w.smem.assign(smem_bytes + 64, 0xCD);  // poison: uninitialised LDS reads show up
     for (unsigned t = 0; t < nthr; ++t) {
         getcontext(&w.ctx[t]);
-        w.ctx[t].uc_stack.ss_sp = w.stacks.data() + size_t(t) * kStackBytes;
+        w.ctx[t].uc_stack.ss_sp = w.stacks + size_t(t) * kStackBytes;
         w.ctx[t].uc_stack.ss_size = kStackBytes;
         w.ctx[t].uc_link = &w.sched;
         makecontext(&w.ctx[t], fiber_entry, 0);
@@ -85,37 +91,113 @@ unsigned char* rl_emu_smem() {
     return reinterpret_cast<unsigned char*>((p + 15) & ~uintptr_t(15));
 }
 
-void rl_emu_launch(dim3 grid, dim3 block, size_t smem_bytes,
-                   const std::function<void()>& body) {
-    const size_t nblocks = size_t(grid.x) * grid.y * grid.z;
-    if (nblocks == 0) return;
-    unsigned nworkers = std::thread::hardware_concurrency();
-    if (nworkers == 0) nworkers = 1;
-    if (nworkers > 8) nworkers = 8;
-    if (nworkers > nblocks) nworkers = unsigned(nblocks);
+// Persistent pool: worker threads (and their fiber stacks) live for the whole
+// process; a launch publishes a job and every worker pulls block indices from
+// one atomic counter.
+namespace {
+
+struct Job {
+    dim3 grid, block;
+    size_t smem = 0;
+    const std::function<void()>* body = nullptr;
+    size_t nblocks = 0;
     std::atomic<size_t> next{0};
-    auto work = [&]() {
-        Worker w;
-        w.body = &body;
+};
+
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    std::vector<std::thread> threads;
+    Job* job = nullptr;
+    uint64_t generation = 0;
+    unsigned busy = 0;
+    bool stop = false;
+
+    static void drain(Job& j, Worker& w) {
+        w.body = j.body;
         tl_worker = &w;
-        gridDim = {grid.x, grid.y, grid.z};
-        blockDim = {block.x, block.y, block.z};
+        gridDim = {j.grid.x, j.grid.y, j.grid.z};
+        blockDim = {j.block.x, j.block.y, j.block.z};
         for (;;) {
-            size_t b = next.fetch_add(1);
-            if (b >= nblocks) break;
-            blockIdx.x = unsigned(b % grid.x);
-            blockIdx.y = unsigned((b / grid.x) % grid.y);
-            blockIdx.z = unsigned(b / (size_t(grid.x) * grid.y));
-            run_block(w, block, smem_bytes);
+            size_t b = j.next.fetch_add(1);
+            if (b >= j.nblocks) break;
+            blockIdx.x = unsigned(b % j.grid.x);
+            blockIdx.y = unsigned((b / j.grid.x) % j.grid.y);
+            blockIdx.z = unsigned(b / (size_t(j.grid.x) * j.grid.y));
+            run_block(w, j.block, j.smem);
         }
         tl_worker = nullptr;
-    };
-    if (nworkers == 1) {
-        work();
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned i = 0; i < nworkers; ++i) pool.emplace_back(work);
-        for (auto& t : pool) t.join();
+    }
+
+    void worker_main() {
+        Worker w;
+        uint64_t seen = 0;
+        for (;;) {
+            Job* j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_start.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                j = job;
+            }
+            drain(*j, w);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--busy == 0) cv_done.notify_all();
+            }
+        }
+    }
+
+    void ensure(unsigned n) {
+        while (threads.size() < n) threads.emplace_back([this] { worker_main(); });
+    }
+
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_start.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
+
+Pool& pool() {
+    static Pool p;
+    return p;
+}
+
+}  // namespace
+
+void rl_emu_launch(dim3 grid, dim3 block, size_t smem_bytes,
+                   const std::function<void()>& body) {
+    Job j;
+    j.grid = grid;
+    j.block = block;
+    j.smem = smem_bytes;
+    j.body = &body;
+    j.nblocks = size_t(grid.x) * grid.y * grid.z;
+    if (j.nblocks == 0) return;
+    static thread_local Worker main_worker;
+    unsigned helpers = std::thread::hardware_concurrency();
+    helpers = helpers > 1 ? helpers - 1 : 0;
+    if (helpers > 7) helpers = 7;
+    if (j.nblocks < 4) helpers = 0;
+    Pool& p = pool();
+    if (helpers) {
+        std::lock_guard<std::mutex> lk(p.mu);
+        p.ensure(helpers);
+        p.job = &j;
+        p.busy = unsigned(p.threads.size());
+        ++p.generation;
+    }
+    if (helpers) p.cv_start.notify_all();
+    Pool::drain(j, main_worker);
+    if (helpers) {
+        std::unique_lock<std::mutex> lk(p.mu);
+        p.cv_done.wait(lk, [&] { return p.busy == 0; });
+        p.job = nullptr;
     }
 }
 

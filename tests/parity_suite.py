@@ -1,0 +1,318 @@
+"""Parity checks shared by the GPU run (tests/test_gpu_suite.py, real HIP
+library on an MI355X) and the CPU run (tests/test_emu_suite.py, same kernel
+source under the thread-level emulator).  Every function takes no arguments
+and uses whichever native library is active.
+
+What is compared with what:
+  * mirror classes (runlmc_amd.linalg ...) vs golden vectors produced by the
+    reference itself (tests/golden/*.npz) and vs the CPU oracle;
+  * tolerances: 1e-10 relative to max|result| for products, the
+    reference's own 1e-6 where its tests use that.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from oracle import operators as ops
+from oracle import likelihood as olik
+from oracle.solver import iterative_solve
+from cases import Case, GOLDEN
+
+from runlmc_amd.linalg.bttb import BTTB
+from runlmc_amd.linalg.toeplitz import Toeplitz
+from runlmc_amd.linalg.kronecker import Kronecker
+from runlmc_amd.linalg.numpy_matrix import NumpyMatrix
+from runlmc_amd.linalg.sum_matrix import SumMatrix
+from runlmc_amd.linalg.diag import Diag
+from runlmc_amd.linalg.identity import Identity
+from runlmc_amd.linalg.composition import Composition
+from runlmc_amd.linalg.block_diag import BlockDiag
+from runlmc_amd.linalg.block_matrix import SymmSquareBlockMatrix
+from runlmc_amd.linalg.matrix import Matrix
+from runlmc_amd.approx.ski import SKI
+from runlmc_amd.approx.iterative import Iterative
+from runlmc_amd.kern.stationary import RBF, Matern32, StdPeriodic
+from runlmc_amd.lmc.functional_kernel import FunctionalKernel
+from runlmc_amd.lmc.grid_kernel import gen_grid_kernel, GridKernel
+from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService, StochasticDeriv
+
+REL = 1e-10
+
+
+def _close(got, ref, rel=REL):
+    scale = max(np.abs(ref).max(), 1e-300)
+    err = np.abs(np.asarray(got) - np.asarray(ref)).max() / scale
+    assert err < rel, 'relative error %.3e >= %.1e' % (err, rel)
+
+
+def _lin():
+    return np.load(os.path.join(GOLDEN, 'linalg.npz'))
+
+
+# --- reference unit-test examples (test_bttb.py, test_toeplitz.py,
+#     test_matrix_base.py:33-47) -------------------------------------------------
+def check_bttb_examples():
+    lin = _lin()
+    for i in range(int(lin['bttb_count'])):
+        top, sizes = lin[f'bttb{i}_top'], lin[f'bttb{i}_sizes']
+        if len(sizes) != 1:
+            try:
+                BTTB(top, sizes)
+            except NotImplementedError:
+                continue
+            raise AssertionError('N-D BTTB should be refused for now')
+        M = BTTB(top, sizes)
+        n = top.size
+        np.testing.assert_array_equal(M.as_numpy(), lin[f'bttb{i}_dense'])
+        x = np.arange(n) + 1
+        X = np.arange(2 * n).reshape(-1, 2)
+        _close(M.matvec(x), lin[f'bttb{i}_matvec'])
+        _close(M.matmat(X), lin[f'bttb{i}_matmat'])
+        # the reference's own assertions (rtol = atol = 1e-6 vs dense)
+        np.testing.assert_allclose(M.matvec(x), M.as_numpy().dot(x),
+                                   rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(M.matmat(X), M.as_numpy().dot(X),
+                                   rtol=1e-6, atol=1e-6)
+        assert M.matvec(x).shape == (n,) and M.dtype == np.float64
+
+
+def check_toeplitz_examples():
+    lin = _lin()
+    for i in range(int(lin['toep_count'])):
+        top = lin[f'toep{i}_top']
+        n = len(top)
+        M = Toeplitz(top)
+        np.testing.assert_array_equal(M.as_numpy(), lin[f'toep{i}_dense'])
+        x = np.arange(n) + 1
+        X = np.arange(2 * n).reshape(-1, 2)
+        ref_v, ref_m = lin[f'toep{i}_matvec'], lin[f'toep{i}_matmat']
+        tol = 1e-10 * max(np.abs(ref_m).max(), 1.0)
+        np.testing.assert_allclose(M.matvec(x), ref_v, rtol=0, atol=tol)
+        np.testing.assert_allclose(M.matmat(X), ref_m, rtol=0, atol=tol)
+
+
+def check_operator_errors():
+    import pytest
+    two_d = np.arange(8).reshape(2, 4)
+    empty = np.array([])
+    for bad in ((two_d, two_d.shape), (empty, empty.shape), (two_d, empty.shape),
+                (two_d.ravel(), (3, 4))):
+        with pytest.raises(ValueError):
+            BTTB(*bad)
+    with pytest.raises(ValueError):
+        Toeplitz(two_d)
+    with pytest.raises(ValueError):
+        Toeplitz(empty)
+    with pytest.raises(TypeError):
+        BTTB(np.arange(5) * 1j, (5,))
+    with pytest.raises(TypeError):
+        Toeplitz(np.arange(5) * 1j)
+    with pytest.raises(ValueError):
+        SumMatrix([])
+    with pytest.raises(ValueError):
+        SumMatrix([Identity(3), Identity(4)])
+    with pytest.raises(ValueError):
+        Diag(np.ones((2, 2)))
+    with pytest.raises(ValueError):
+        NumpyMatrix(np.ones(3))
+    with pytest.raises(ValueError):
+        Toeplitz(np.ones(4)).matvec(np.ones(5))
+
+
+def check_kronecker_and_sum():
+    lin = _lin()
+    for i in range(int(lin['kron_count'])):
+        B, top = lin[f'kron{i}_B'], lin[f'kron{i}_top']
+        K = Kronecker(NumpyMatrix(B), BTTB(top, top.shape))
+        n = K.shape[0]
+        _close(K.matvec(np.arange(n) + 1), lin[f'kron{i}_matvec'])
+        _close(K.matmat(np.arange(2 * n).reshape(-1, 2)), lin[f'kron{i}_matmat'])
+        np.testing.assert_allclose(K.as_numpy(), lin[f'kron{i}_dense'], rtol=1e-13)
+    Bs, tops, x = lin['sum_Bs'], lin['sum_tops'], lin['sum_x']
+    S = SumMatrix([Kronecker(NumpyMatrix(B), BTTB(t, t.shape))
+                   for B, t in zip(Bs, tops)])
+    _close(S.matvec(x), lin['sum_matvec'])
+    assert S._try_fuse() is not None           # one device operator
+    # generic (non-fusable) operands still work: rectangular / non-symmetric
+    rng = np.random.RandomState(3)
+    A, B2 = rng.rand(2, 3), rng.rand(3, 2)
+    K = Kronecker(NumpyMatrix(A), NumpyMatrix(B2))
+    xv = rng.randn(6)
+    np.testing.assert_allclose(K.matvec(xv), np.kron(A, B2).dot(xv), rtol=1e-12)
+    T = Toeplitz(np.exp(-np.arange(7.0)))
+    K = Kronecker(T, NumpyMatrix(rng.rand(3, 3)))
+    xv = rng.randn(21)
+    np.testing.assert_allclose(K.matvec(xv), K.as_numpy().dot(xv), rtol=1e-10)
+
+
+def check_small_algebra():
+    rng = np.random.RandomState(4)
+    t1, t2 = np.exp(-np.arange(6.0)), np.exp(-0.5 * np.arange(4.0))
+    bd = BlockDiag([Toeplitz(t1), Toeplitz(t2)])
+    x = rng.randn(10)
+    np.testing.assert_allclose(bd.matvec(x), bd.as_numpy().dot(x), rtol=1e-10)
+    T = Toeplitz(t1)
+    sb = SymmSquareBlockMatrix([[T, Toeplitz(0.5 * t1)], [Toeplitz(0.5 * t1), T]])
+    x = rng.randn(12)
+    np.testing.assert_allclose(sb.matvec(x), sb.as_numpy().dot(x), rtol=1e-10)
+    comp = Composition([T, Diag(np.arange(6.0) + 1), Identity(6)])
+    x = rng.randn(6)
+    np.testing.assert_allclose(comp.matvec(x), T.as_numpy().dot((np.arange(6) + 1) * x),
+                               rtol=1e-10)
+    lo = T.as_linear_operator()
+    np.testing.assert_allclose(lo.matvec(x), T.as_numpy().dot(x), rtol=1e-10)
+    again = pickle.loads(pickle.dumps(T))       # picklable, handle rebuilt lazily
+    np.testing.assert_allclose(again.matvec(x), T.matvec(x), rtol=1e-14)
+    w = Matrix.wrap((6, 6), lambda v: 2 * v)
+    np.testing.assert_array_equal(w.matvec(x), 2 * x)
+
+
+# --- LMC operator -------------------------------------------------------------
+def _kernel(desc):
+    parts = str(desc).split(';')
+    kind, vals = parts[0], [float(v) for v in parts[1:]]
+    return {'rbf': RBF, 'matern': Matern32, 'periodic': StdPeriodic}[kind](*vals)
+
+
+def functional_kernel_for(c):
+    """Build the package's FunctionalKernel from a stored case (all kernels
+    of the golden cases are LMC kernels)."""
+    fk = FunctionalKernel(D=c.D, lmc_kernels=[_kernel(k) for k in c.kdesc],
+                          lmc_ranks=[len(a) for a in c.coreg_vecs])
+    fk.coreg_vecs = c.coreg_vecs
+    fk.coreg_diags = c.coreg_diags
+    fk.noise = c.noise
+    fk.set_input_dim(1)
+    return fk
+
+
+def build_operator(c):
+    fk = functional_kernel_for(c)
+    ad = (0,)
+    K, gks = gen_grid_kernel(fk, {ad: c.grid_dists}, {ad: (c.W, c.WT)}, c.lens)
+    return fk, K, gks[ad]
+
+
+def check_lmc_operator(name):
+    c = Case(name)
+    fk, K, gk = build_operator(c)
+    np.testing.assert_allclose(fk.eval_kernels_fixed_dim(c.grid_dists, (0,)),
+                               c.g['tops'], rtol=1e-13, atol=1e-300)
+    gx = c.g['grid_x']
+    got = gk.grid_K.matmat(gx.T).T
+    for kt in ('sum', 'bt', 'slfm'):
+        _close(got, c.g[f'grid_mv_{kt}'])
+    _close(gk.grid_K.matvec(gx[0]), c.g['grid_mv_sum'][0])
+    _close(K.matmat(c.g['full_x'].T).T, c.g['full_mv'])
+    _close(K.matvec(c.g['full_x'][0]), c.g['full_mv'][0])
+    # noise-free part + Diag == full operator; SumMatrix protocol kept
+    assert K.Ks[0] is gk and isinstance(K.Ks[1], Diag)
+    x = c.g['full_x'][0]
+    _close(gk.matvec(x) + K.Ks[1].matvec(x), c.g['full_mv'][0])
+    assert K.shape == (c.n, c.n) and K.dtype == np.float64
+    if 'K_dense' in c.g:
+        Kd = K.as_numpy()
+        _close(0.5 * (Kd + Kd.T), c.g['K_dense'])
+
+
+def check_solver(name, minres=True):
+    c = Case(name)
+    fk, K, gk = build_operator(c)
+    op = olik.LMCOperatorOracle(c.spec(), c.grid_dists, c.W, c.WT, c.lens)
+    B = np.vstack([c.y] + [r.astype(float) for r in c.rs[:3]])
+    X, iters, resid = Iterative.solve(K, B, verbose=True, minres=minres, tol=1e-4)
+    for i in range(len(B)):
+        xo, ito, erro, _ = iterative_solve(op.matvec, B[i], tol=1e-4, minres=minres)
+        # stopping tests sit on roundoff: a few iterations of slack
+        assert abs(int(iters[i]) - ito) <= max(3, ito // 10), (iters[i], ito)
+        true_res = np.linalg.norm(B[i] - op.matvec(X[i]))
+        assert abs(true_res - resid[i]) <= 1e-9 + 1e-6 * true_res
+        assert resid[i] <= 1e-4                       # reference target met
+        _close(X[i], xo, rel=1e-5)
+    if 'alpha_dense' in c.g:
+        # alpha against a dense Cholesky solve of the same K~
+        _close(X[0], c.g['alpha_dense'], rel=1e-5)
+    # single right-hand side form and verbose tuple, as the reference returns
+    x1, it1, err1 = Iterative.solve(K, c.y, verbose=True, minres=minres, tol=1e-4)
+    # two right-hand sides share one complex transform, so a vector's
+    # roundoff depends on its batch neighbour; Krylov stopping amplifies that
+    # to the solver-tolerance level
+    _close(x1, X[0], rel=1e-5)
+    assert abs(it1 - iters[0]) <= max(3, iters[0] // 10) and err1 <= 1e-4
+    assert Iterative.solve(K, c.y, minres=minres).shape == (c.n,)
+
+
+def check_solver_edge_cases():
+    c = Case('lmc_q1')
+    fk, K, gk = build_operator(c)
+    X, iters, resid = Iterative.solve(K, np.zeros((2, c.n)), verbose=True)
+    assert np.all(X == 0) and np.all(iters == 0) and np.all(resid == 0)
+    import pytest
+    with pytest.raises(ValueError):
+        Iterative.solve(K, np.ones(c.n + 1))
+    with pytest.raises(TypeError):
+        Iterative.solve(Identity(3), np.ones(3))
+
+
+class _FixedDeriv:
+    """Hands the likelihood pre-computed (dense) solves, as the golden
+    generator did with the reference's ApproxLMCLikelihood."""
+
+    def __init__(self, alpha, rs, inv_rs, device):
+        self.args = (alpha, rs, inv_rs)
+        self.device = device
+
+    def generate(self, K, y, rs=None):
+        a, r, s = self.args
+        t = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(self.device)
+        return StochasticDeriv(t(a), t(r), t(s), len(r))
+
+
+def _compare_grads(lik, c, rel):
+    gv, gd = lik.coreg_vec_gradients(), lik.coreg_diags_gradients()
+    gk, gn = lik.kernel_gradients(), lik.noise_gradient()
+    scale = max(max(np.abs(c.g[f'grad_A{q}']).max() for q in range(c.Q)), 1.0)
+    for q in range(c.Q):
+        assert gv[q].shape == c.g[f'grad_A{q}'].shape
+        assert np.abs(gv[q] - c.g[f'grad_A{q}']).max() < rel * scale
+        assert np.abs(gd[q] - c.g[f'grad_kappa{q}']).max() < rel * scale
+        assert np.abs(np.array(gk[q]) - c.g[f'grad_kern{q}']).max() < rel * scale
+    assert np.abs(gn - c.g['grad_noise']).max() < rel * scale
+
+
+def check_gradients_fixed_solves(name):
+    """Gradient assembly alone: dense solves and stored probes in, the
+    reference's per-parameter loops' output expected (deterministic)."""
+    c = Case(name)
+    fk, K, gk = build_operator(c)
+    ad = (0,)
+    fixed = _FixedDeriv(c.g['alpha_dense'], c.rs, c.g['inv_rs_dense'], K.device)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
+                              c.Ys, fixed)
+    _compare_grads(lik, c, rel=1e-9)
+    # the sink protocol of the functional kernel
+    fk.update_gradient(lik)
+    np.testing.assert_allclose(fk.noise_grad, c.g['grad_noise'], rtol=1e-7, atol=1e-9)
+    assert fk.kernels[0].gradient is not None
+
+
+def check_gradients_end_to_end(name):
+    """Full step: device MINRES solves (tol 1e-4 rule, inner 1e-10) for alpha
+    and the stored probes, then gradients; compared with the gradients from
+    dense solves.  Tolerance reflects the solver residual, not the kernels."""
+    c = Case(name)
+    fk, K, gk = build_operator(c)
+    ad = (0,)
+    svc = StochasticDerivService(None, None, len(c.rs), 1e-4)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
+                              c.Ys, svc, probes=c.rs)
+    _close(lik.alpha(), c.g['alpha_dense'], rel=1e-5)
+    _compare_grads(lik, c, rel=1e-4)
+    # generic operator form of the estimator still works (reference API)
+    d = np.zeros(c.D)
+    d[0] = 1
+    dK = Diag(np.repeat(d, c.lens))
+    assert abs(lik.deriv.derivative(dK) - lik.noise_gradient()[0]) < 1e-9

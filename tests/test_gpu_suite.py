@@ -1,0 +1,66 @@
+"""GPU run of the parity suite: real HIP library on an MI355X, through the C
+ABI.  pytest -m gpu."""
+import pytest
+
+import parity_suite as ps
+from cases import DENSE_CASES, ALL_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def hip_library():
+    from runlmc_amd import _lib
+    _lib.use_library(None)
+    lib = _lib.get_library()
+    assert lib.is_hip, 'GPU tests must run against librunlmc_hip.so'
+    return lib
+
+
+def test_bttb_examples():
+    ps.check_bttb_examples()
+
+
+def test_toeplitz_examples():
+    ps.check_toeplitz_examples()
+
+
+def test_operator_errors():
+    ps.check_operator_errors()
+
+
+def test_kronecker_and_sum():
+    ps.check_kronecker_and_sum()
+
+
+def test_small_algebra():
+    ps.check_small_algebra()
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_lmc_operator(name):
+    ps.check_lmc_operator(name)
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_solver_minres(name):
+    ps.check_solver(name, minres=True)
+
+
+@pytest.mark.parametrize('name', DENSE_CASES)
+def test_solver_cg(name):
+    ps.check_solver(name, minres=False)
+
+
+def test_solver_edge_cases():
+    ps.check_solver_edge_cases()
+
+
+@pytest.mark.parametrize('name', DENSE_CASES)
+def test_gradients_fixed_solves(name):
+    ps.check_gradients_fixed_solves(name)
+
+
+@pytest.mark.parametrize('name', DENSE_CASES)
+def test_gradients_end_to_end(name):
+    ps.check_gradients_end_to_end(name)
