@@ -227,7 +227,9 @@ def check_solver(name, minres=True):
     for i in range(len(B)):
         xo, ito, erro, _ = iterative_solve(op.matvec, B[i], tol=1e-4, minres=minres)
         # stopping tests sit on roundoff: a few iterations of slack
-        assert abs(int(iters[i]) - ito) <= max(3, ito // 10), (iters[i], ito)
+        # (CG runs to 1e-10 relative, deep in its roundoff plateau: wider)
+        slack = max(3, ito // 10) if minres else max(6, ito // 5)
+        assert abs(int(iters[i]) - ito) <= slack, (iters[i], ito)
         true_res = np.linalg.norm(B[i] - op.matvec(X[i]))
         assert abs(true_res - resid[i]) <= 1e-9 + 1e-6 * true_res
         # the reference target is met wherever the reference itself meets it
