@@ -13,7 +13,7 @@ Rules (enforced by tests/test_layout.py):
   * it is never the thing that is measured as the product or shipped.
 
 Parity is PINNED: ``tests/golden/make_golden.py`` imports the real reference
-from ``/root/reference`` (build container only) and stores its outputs as
+from the read-only reference checkout (build container only) and stores its outputs as
 ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function
 here against those vectors.
 

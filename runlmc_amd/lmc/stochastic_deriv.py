@@ -11,7 +11,7 @@ import torch
 
 from .derivative import Derivative
 from ..approx.iterative import Iterative
-from ..util.dist import rank_world, shard_rows, all_reduce_sum_
+from ..util.dist import rank_world, shard_rows, all_reduce_sum_, broadcast_
 
 
 class StochasticDerivService:
@@ -44,19 +44,21 @@ class StochasticDerivService:
         B = torch.from_numpy(rhs).to(dev)
         X, iters, resid, istop = Iterative.solve_device(
             K, B, minres=True, tol=self._tol)
+        rank, world = rank_world(self._group)
         if self.metrics is not None:
-            stats = torch.tensor([float(iters.sum()), float(resid.sum()),
-                                  float(len(iters))], dtype=torch.float64)
-            # alpha is solved on every rank: count it once
-            _, world = rank_world(self._group)
-            if world > 1:
-                stats -= torch.tensor([float(iters[0]), float(resid[0]), 1.0],
-                                      dtype=torch.float64) * (
-                    0.0 if rank_world(self._group)[0] == 0 else 1.0)
-                all_reduce_sum_(stats, self._group)
-            self.metrics.iterations.append(float(stats[0] / stats[2]))
-            self.metrics.solv_error.append(float(stats[1] / stats[2]))
-        return StochasticDeriv(X[0], B[1:], X[1:], self._n_it, group=self._group,
+            # mean over the N+1 systems; alpha (solved everywhere) counted once
+            lo = 0 if rank == 0 else 1
+            stats = torch.tensor([float(np.sum(iters[lo:])),
+                                  float(np.sum(resid[lo:]))], dtype=torch.float64)
+            all_reduce_sum_(stats, self._group)
+            self.metrics.iterations.append(float(stats[0]) / (self._n_it + 1))
+            self.metrics.solv_error.append(float(stats[1]) / (self._n_it + 1))
+        alpha = X[0].clone()
+        # two right-hand sides share one complex transform, so alpha's
+        # roundoff depends on the probe it was packed with; make every rank
+        # use rank 0's alpha so gradients are bit-identical across ranks
+        broadcast_(alpha, 0, self._group)
+        return StochasticDeriv(alpha, B[1:], X[1:], self._n_it, group=self._group,
                                iterations=iters, residuals=resid, istop=istop)
 
     def _concurrent_solve(self, ls):

@@ -4,8 +4,10 @@
 The reference's only parallel axis is the N+1 independent solves mapped over a
 process pool (runlmc/lmc/stochastic_deriv.py:39-52).  Here the N probes are
 dealt round-robin to the ranks, every rank holds a replica of the operator and
-solves for alpha itself, and ONE all-reduce of the summed gradient partials
-(a few KB) closes the step.  There is no collective inside the solve."""
+solves for alpha itself (rank 0's alpha is then broadcast, n doubles, so that
+all ranks assemble bit-identical gradients), and ONE all-reduce of the summed
+gradient partials (a few KB) closes the step.  There is no collective inside
+the solve."""
 import torch
 import torch.distributed as dist
 
@@ -20,6 +22,21 @@ def shard_rows(count, group=None):
     """Indices of the probes this rank owns: rank, rank + world, ..."""
     rank, world = rank_world(group)
     return list(range(rank, count, world))
+
+
+def broadcast_(t, src=0, group=None):
+    """In-place broadcast from rank `src`; no-op for one rank."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return t
+    backend = dist.get_backend(group)
+    if backend == 'gloo' and t.device.type != 'cpu':
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
 
 
 def all_reduce_sum_(flat, group=None):

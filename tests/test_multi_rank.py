@@ -1,0 +1,88 @@
+"""Probe sharding over ranks (the N > 1 path): two gloo processes on CPU, the
+kernels running under the emulator, must reproduce the one-process gradients:
+probes dealt round-robin, alpha solved on every rank, one all-reduce of the
+partial sums."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _grads(world_group=None):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import parity_suite as ps
+    from cases import Case
+    from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+    from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
+    c = Case('lmc_small')
+    fk, K, gk = ps.build_operator(c)
+    ad = (0,)
+    svc = StochasticDerivService(None, None, len(c.rs), 1e-4, group=world_group)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
+                              c.Ys, svc, probes=c.rs)
+    flat = np.concatenate([np.ravel(g) for g in lik.coreg_vec_gradients()] +
+                          [np.ravel(g) for g in lik.coreg_diags_gradients()] +
+                          [np.ravel(g) for g in lik.kernel_gradients()] +
+                          [lik.noise_gradient()])
+    return flat, lik.deriv.rs_dev.shape[0]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.EMU_LIB)
+    flat, nloc = _grads()
+    q.put((rank, flat, nloc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_probe_sharding():
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.build_emu())
+    try:
+        ref, nall = _grads()
+    finally:
+        _lib.use_library(None)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert got[0][2] + got[1][2] == nall          # every probe owned once
+    assert got[0][2] == (nall + 1) // 2
+    # both ranks end with the same, full gradient
+    np.testing.assert_allclose(got[0][1], got[1][1], rtol=0, atol=1e-11 * np.abs(ref).max())
+    # batching changes which vectors share a transform -> solver-level noise
+    scale = np.abs(ref).max()
+    assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
+
+
+def test_shard_rows_partition():
+    from runlmc_amd.util.dist import shard_rows, rank_world
+    assert rank_world() == (0, 1)
+    assert shard_rows(5) == [0, 1, 2, 3, 4]
