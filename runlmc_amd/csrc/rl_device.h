@@ -10,7 +10,7 @@
 #include "rl_emu.h"
 #define RL_SMEM(name) unsigned char* name = rl_emu_smem()
 #define RL_LAUNCH(kern, grid, block, smem, stream, ...) \
-    rl_emu_launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+    rl_emu_launch((grid), (block), (smem), [=]() { (kern)(__VA_ARGS__); })
 #define RL_BACKEND_NAME "emu-host"
 #else
 #include <hip/hip_runtime.h>
@@ -50,6 +50,16 @@ __device__ __forceinline__ cplx c_mulc(cplx a, cplx b) {
 __device__ __forceinline__ cplx c_mul_mi(cplx a) { return c_make(a.y, -a.x); }
 __device__ __forceinline__ cplx c_mul_pi(cplx a) { return c_make(-a.y, a.x); }
 __device__ __forceinline__ cplx c_scale(cplx a, double s) { return c_make(a.x * s, a.y * s); }
+
+// q = w / d for small w via a precomputed magic = floor(2^32 / d) + 1
+// (exact while w * d < 2^32); the host passes `magic`
+__device__ __forceinline__ unsigned fast_div(unsigned w, unsigned magic) {
+#if defined(RL_EMU)
+    return (unsigned)(((unsigned long long)w * magic) >> 32);
+#else
+    return __umulhi(w, magic);
+#endif
+}
 
 #define RL_MAX_PASSES 8
 // Radix schedule of one power-of-two FFT; passed to kernels by value.

@@ -83,19 +83,64 @@ struct SmallDft<8, INV> {
     }
 };
 
+// 16 = 4 x 4: a radix-4 stage over elements 4 apart, the W16^{jk} twiddles, a
+// radix-4 stage over contiguous quads, outputs renamed to natural order.
+#define RL_COS_PI_8 0.92387953251128673848
+#define RL_SIN_PI_8 0.38268343236508978178
+template <bool INV>
+__device__ __forceinline__ cplx c_twc(cplx a, double re, double im_fwd) {
+    // a * (re + i*im) with im = im_fwd forward, -im_fwd inverse
+    const double im = INV ? -im_fwd : im_fwd;
+    return c_make(a.x * re - a.y * im, a.x * im + a.y * re);
+}
+template <bool INV>
+struct SmallDft<16, INV> {
+    static __device__ __forceinline__ void run(cplx* v) {
+        cplx s[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j][0] = v[j];
+            s[j][1] = v[j + 4];
+            s[j][2] = v[j + 8];
+            s[j][3] = v[j + 12];
+            dft4<INV>(s[j][0], s[j][1], s[j][2], s[j][3]);
+        }
+        // twiddles W16^{j k}, j = butterfly index, k = output of stage 1
+        s[1][1] = c_twc<INV>(s[1][1], RL_COS_PI_8, -RL_SIN_PI_8);      // W^1
+        s[1][2] = c_eighth<INV>(s[1][2]);                              // W^2
+        s[1][3] = c_twc<INV>(s[1][3], RL_SIN_PI_8, -RL_COS_PI_8);      // W^3
+        s[2][1] = c_eighth<INV>(s[2][1]);                              // W^2
+        s[2][2] = c_quarter<INV>(s[2][2]);                             // W^4
+        s[2][3] = c_three_eighths<INV>(s[2][3]);                       // W^6
+        s[3][1] = c_twc<INV>(s[3][1], RL_SIN_PI_8, -RL_COS_PI_8);      // W^3
+        s[3][2] = c_three_eighths<INV>(s[3][2]);                       // W^6
+        s[3][3] = c_twc<INV>(s[3][3], -RL_COS_PI_8, RL_SIN_PI_8);      // W^9
+        // stage 2: for each k, DFT4 over j; result (k, k2) is frequency k + 4 k2
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dft4<INV>(s[0][k], s[1][k], s[2][k], s[3][k]);
+            v[k] = s[0][k];
+            v[k + 4] = s[1][k];
+            v[k + 8] = s[2][k];
+            v[k + 12] = s[3][k];
+        }
+    }
+};
+
 // One radix-R pass over the whole tile.
 //   n    transform length, ns  current sub-transform length (n, n/R1, ...)
 //   cols side-by-side transforms, ld  leading dimension (>= cols)
 //   tw   table of exp(-2 pi i k / n), k in [0, n)
 template <int R, bool INV>
 __device__ __forceinline__ void fft_pass(cplx* tile, int n, int ns, int cols, int ld,
-                                         const cplx* tw, int tid, int nthr) {
+                                         const cplx* tw, int tid, int nthr,
+                                         unsigned cols_magic = 0) {
     const int sub = ns / R;          // distance between butterfly legs
     const int twstep = n / ns;       // W_ns^j = tw[j * twstep]
     const int work = (n / R) * cols;
     for (int w = tid; w < work; w += nthr) {
-        const int c = w % cols;
-        const int bf = w / cols;
+        const int bf = cols_magic ? (int)fast_div((unsigned)w, cols_magic) : w / cols;
+        const int c = w - bf * cols;
         const int j = bf & (sub - 1);
         const int g = (bf - j) * R;  // (bf / sub) * ns
         cplx* p = tile + (size_t)(g + j) * ld + c;
@@ -103,12 +148,12 @@ __device__ __forceinline__ void fft_pass(cplx* tile, int n, int ns, int cols, in
         cplx v[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) v[i] = p[i * leg];
-        if (INV) {
+        if (INV && sub > 1) {      // sub == 1: every twiddle is W^0
 #pragma unroll
             for (int k = 1; k < R; ++k) v[k] = c_mulc(v[k], tw[j * k * twstep]);
         }
         SmallDft<R, INV>::run(v);
-        if (!INV) {
+        if (!INV && sub > 1) {
 #pragma unroll
             for (int k = 1; k < R; ++k) v[k] = c_mul(v[k], tw[j * k * twstep]);
         }
@@ -119,13 +164,16 @@ __device__ __forceinline__ void fft_pass(cplx* tile, int n, int ns, int cols, in
 
 template <bool INV>
 __device__ __forceinline__ void fft_pass_any(int radix, cplx* tile, int n, int ns, int cols,
-                                             int ld, const cplx* tw, int tid, int nthr) {
-    if (radix == 8)
-        fft_pass<8, INV>(tile, n, ns, cols, ld, tw, tid, nthr);
+                                             int ld, const cplx* tw, int tid, int nthr,
+                                             unsigned cols_magic = 0) {
+    if (radix == 16)
+        fft_pass<16, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
+    else if (radix == 8)
+        fft_pass<8, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
     else if (radix == 4)
-        fft_pass<4, INV>(tile, n, ns, cols, ld, tw, tid, nthr);
+        fft_pass<4, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
     else
-        fft_pass<2, INV>(tile, n, ns, cols, ld, tw, tid, nthr);
+        fft_pass<2, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
 }
 
 // All forward passes; ends with a barrier.

@@ -1,0 +1,274 @@
+// Second-generation grid-product kernels: the FIRST radix pass of every
+// transform is done in registers straight from the global load and the LAST
+// one in registers straight into the global store (or the mix), so a two-pass
+// transform (N <= 256) crosses LDS once and a three-pass one twice, instead of
+// once per pass plus once each for staging in and out.  Every thread issues its
+// RA (8 or 16) independent global loads before it touches any of them.
+//
+// Same flow graph, same scrambled orders, same intermediates layout as
+// rl_kernels.h (which stays as the fallback for transform lengths without a
+// fused instantiation); see tests/flow_model.py.
+//
+// Plan convention: plan.radix[0] == RA (first pass), plan.radix[npass-1] == RB
+// (last pass), whatever sits between runs in LDS (fft_pass_any).
+#pragma once
+#include "rl_kernels.h"
+
+struct Tile2 {
+    int N1, N2;
+    int C, logC;        // columns per k2_cols_* workgroup (power of two)
+    int R;              // rows per k2_rows_mix workgroup (power of two)
+    unsigned colsMagic; // fast_div magic of R * D
+};
+
+// middle passes (everything but first and last), forward / adjoint
+__device__ __forceinline__ void middle_forward(cplx* tile, const FftPlan& plan, int cols, int ld,
+                                               const cplx* tw, int tid, int nthr,
+                                               unsigned magic) {
+    int ns = plan.n / plan.radix[0];
+    for (int s = 1; s < plan.npass - 1; ++s) {
+        fft_pass_any<false>(plan.radix[s], tile, plan.n, ns, cols, ld, tw, tid, nthr, magic);
+        ns /= plan.radix[s];
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void middle_adjoint(cplx* tile, const FftPlan& plan, int cols, int ld,
+                                               const cplx* tw, int tid, int nthr,
+                                               unsigned magic) {
+    int ns = plan.radix[plan.npass - 1];
+    for (int s = plan.npass - 2; s >= 1; --s) {
+        ns *= plan.radix[s];
+        fft_pass_any<true>(plan.radix[s], tile, plan.n, ns, cols, ld, tw, tid, nthr, magic);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k2_cols_fwd<RA, RB>: as k_cols_fwd.  grid (N2 / C, D, npairs)
+// LDS: tile [N1][C]
+// ---------------------------------------------------------------------------
+template <int RA, int RB>
+__global__ void __launch_bounds__(RL_THREADS)
+k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
+            cplx* __restrict__ T, Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1,
+            const int* __restrict__ freq1, TwiddleL twl) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
+    const int c0 = blockIdx.x * C, b = blockIdx.y, pair = blockIdx.z;
+    const int L = N1 * N2;
+    const int v0 = 2 * pair, v1 = 2 * pair + 1;
+    const double* x0 = X + ((size_t)v0 * D + b) * m;
+    const double* x1 = X + ((size_t)v1 * D + b) * m;
+    const bool has1 = v1 < nvec;
+    const int sub = N1 / RA;
+
+    for (int w = tid; w < sub * C; w += nthr) {
+        const int c = w & (C - 1), j = w >> tp.logC;
+        cplx v[RA];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int n = (j + sub * i) * N2 + c0 + c;
+            int src = -1;
+            if (n < m)
+                src = n;
+            else if (mode == 1 && n > L - m)
+                src = L - n;
+            double re = 0.0, im = 0.0;
+            if (src >= 0) {
+                re = x0[src];
+                if (has1) im = x1[src];
+            }
+            v[i] = c_make(re, im);
+        }
+        SmallDft<RA, false>::run(v);
+#pragma unroll
+        for (int k = 1; k < RA; ++k) v[k] = c_mul(v[k], tw1[j * k]);
+#pragma unroll
+        for (int k = 0; k < RA; ++k) tile[(size_t)(j + sub * k) * C + c] = v[k];
+    }
+    __syncthreads();
+    middle_forward(tile, plan1, C, C, tw1, tid, nthr, 0);
+
+    cplx* out = T + ((size_t)pair * D + b) * L;
+    for (int w = tid; w < (N1 / RB) * C; w += nthr) {
+        const int c = w & (C - 1), g = (w >> tp.logC) * RB;
+        cplx v[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) v[i] = tile[(size_t)(g + i) * C + c];
+        SmallDft<RB, false>::run(v);
+        const int n2 = c0 + c;
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int r = g + k;
+            out[(size_t)r * N2 + n2] = c_mul(v[k], twiddle_L(twl, freq1[r] * n2));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k2_cols_inv<RA, RB>: as k_cols_inv.  grid (tiles, D, npairs)
+// ---------------------------------------------------------------------------
+template <int RA, int RB>
+__global__ void __launch_bounds__(RL_THREADS)
+k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, int m,
+            Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
+    const int c0 = blockIdx.x * C, b = blockIdx.y, pair = blockIdx.z;
+    const size_t L = (size_t)N1 * N2;
+    const cplx* in = T + ((size_t)pair * D + b) * L;
+
+    // adjoint of the last forward pass, straight from global
+    for (int w = tid; w < (N1 / RB) * C; w += nthr) {
+        const int c = w & (C - 1), g = (w >> tp.logC) * RB;
+        cplx v[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) v[k] = in[(size_t)(g + k) * N2 + c0 + c];
+        SmallDft<RB, true>::run(v);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) tile[(size_t)(g + i) * C + c] = v[i];
+    }
+    __syncthreads();
+    middle_adjoint(tile, plan1, C, C, tw1, tid, nthr, 0);
+
+    // adjoint of the first forward pass, straight into the cropped output
+    const int sub = N1 / RA;
+    const int v0 = 2 * pair, v1 = 2 * pair + 1;
+    double* y0 = Y + ((size_t)v0 * D + b) * m;
+    double* y1 = Y + ((size_t)v1 * D + b) * m;
+    const bool has1 = v1 < nvec;
+    // rows n1 >= ceil((m - c0) / N2) of this tile are cropped away entirely
+    for (int w = tid; w < sub * C; w += nthr) {
+        const int c = w & (C - 1), j = w >> tp.logC;
+        if (j * N2 + c0 + c >= m) continue;          // even the first leg is outside
+        cplx v[RA];
+#pragma unroll
+        for (int k = 0; k < RA; ++k) v[k] = tile[(size_t)(j + sub * k) * C + c];
+#pragma unroll
+        for (int k = 1; k < RA; ++k) v[k] = c_mulc(v[k], tw1[j * k]);
+        SmallDft<RA, true>::run(v);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int n = (j + sub * i) * N2 + c0 + c;
+            if (n < m) {
+                y0[n] = v[i].x;
+                if (has1) y1[n] = v[i].y;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the per-frequency mix on D complex values held in registers
+// ---------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void mix_point(cplx* z, const MixParams& mp, size_t L, size_t o) {
+    cplx y[D];
+    double dc[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) dc[a] = 0.0;
+    for (int q = 0; q < mp.Q; ++q) {
+        const double s = mp.spec[(size_t)q * L + o];
+#pragma unroll
+        for (int a = 0; a < D; ++a) dc[a] = fma(mp.kappa[q * D + a], s, dc[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) y[a] = c_scale(z[a], dc[a]);
+    for (int f = 0; f < mp.nfac; ++f) {
+        const double* af = mp.facA + (size_t)f * D;
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            sx = fma(af[b], z[b].x, sx);
+            sy = fma(af[b], z[b].y, sy);
+        }
+        const double g = mp.facW[f] * mp.spec[(size_t)mp.facQ[f] * L + o];
+        sx *= g;
+        sy *= g;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            y[a].x = fma(af[a], sx, y[a].x);
+            y[a].y = fma(af[a], sy, y[a].y);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) z[a] = y[a];
+}
+
+// ---------------------------------------------------------------------------
+// k2_rows_mix<D, RA, RB>: as k_rows_mix.  grid (N1 / R, npairs)
+// LDS: tile [N2][ld], ld = (R*D) | 1
+// First pass from global with the transform index fastest across lanes
+// (coalesced 16-byte elements); LDS passes with the column fastest.
+// ---------------------------------------------------------------------------
+template <int D, int RA, int RB>
+__global__ void __launch_bounds__(RL_THREADS)
+k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restrict__ tw2,
+            const int* __restrict__ freq1, TwiddleL twl, MixParams mp) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N1 = tp.N1, N2 = tp.N2, R = tp.R;
+    const int cols = R * D;
+    const int ld = cols | 1;
+    const int r0 = blockIdx.x * R, pair = blockIdx.y;
+    const size_t L = (size_t)N1 * N2;
+    cplx* base = T + (size_t)pair * D * L;
+    const int sub = N2 / RA;
+    const int logsub = 31 - __builtin_clz(sub);
+
+    for (int w = tid; w < sub * cols; w += nthr) {
+        const int j = w & (sub - 1), col = w >> logsub;
+        const int rr = col / D, b = col - rr * D;
+        const cplx* src = base + (size_t)b * L + (size_t)(r0 + rr) * N2;
+        cplx v[RA];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) v[i] = src[j + sub * i];
+        SmallDft<RA, false>::run(v);
+#pragma unroll
+        for (int k = 1; k < RA; ++k) v[k] = c_mul(v[k], tw2[j * k]);
+#pragma unroll
+        for (int k = 0; k < RA; ++k) tile[(size_t)(j + sub * k) * ld + col] = v[k];
+    }
+    __syncthreads();
+    middle_forward(tile, plan2, cols, ld, tw2, tid, nthr, tp.colsMagic);
+    fft_pass<RB, false>(tile, N2, RB, cols, ld, tw2, tid, nthr, tp.colsMagic);
+    __syncthreads();
+
+    for (int idx = tid; idx < R * N2; idx += nthr) {
+        const int pos = idx & (N2 - 1), rr = idx / N2;
+        cplx* zp = tile + (size_t)pos * ld + rr * D;
+        cplx z[D];
+#pragma unroll
+        for (int b = 0; b < D; ++b) z[b] = zp[b];
+        mix_point<D>(z, mp, L, (size_t)(r0 + rr) * N2 + pos);
+#pragma unroll
+        for (int a = 0; a < D; ++a) zp[a] = z[a];
+    }
+    __syncthreads();
+    fft_pass<RB, true>(tile, N2, RB, cols, ld, tw2, tid, nthr, tp.colsMagic);
+    __syncthreads();
+    middle_adjoint(tile, plan2, cols, ld, tw2, tid, nthr, tp.colsMagic);
+
+    for (int w = tid; w < sub * cols; w += nthr) {
+        const int j = w & (sub - 1), col = w >> logsub;
+        const int rr = col / D, b = col - rr * D;
+        cplx* dst = base + (size_t)b * L + (size_t)(r0 + rr) * N2;
+        const int k1 = freq1[r0 + rr];
+        cplx v[RA];
+#pragma unroll
+        for (int k = 0; k < RA; ++k) v[k] = tile[(size_t)(j + sub * k) * ld + col];
+#pragma unroll
+        for (int k = 1; k < RA; ++k) v[k] = c_mulc(v[k], tw2[j * k]);
+        SmallDft<RA, true>::run(v);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int n2 = j + sub * i;
+            dst[n2] = c_mulc(v[i], twiddle_L(twl, k1 * n2));
+        }
+    }
+}

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "rl_kernels.h"
+#include "rl_kernels2.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -52,11 +53,29 @@ static int ilog2(int x) {
     return l;
 }
 
+// Transform lengths with a fused (register first/last pass) instantiation and
+// their radix schedules; code = 1: (8,8)  2: (8,16)  3: (16,16), 0: none.
+static int fused_code(int n) {
+    switch (n) {
+        case 64: case 512: return 1;
+        case 128: case 1024: return 2;
+        case 256: return 3;
+        default: return 0;
+    }
+}
+
 static FftPlan make_plan(int n) {
     FftPlan p;
     p.n = n;
     p.npass = 0;
     for (int i = 0; i < RL_MAX_PASSES; ++i) p.radix[i] = 1;
+    const int fixed[5][4] = {{64, 8, 8, 0}, {128, 8, 16, 0}, {256, 16, 16, 0},
+                             {512, 8, 8, 8}, {1024, 8, 8, 16}};
+    for (const auto& f : fixed)
+        if (f[0] == n) {
+            for (int i = 1; i < 4 && f[i]; ++i) p.radix[p.npass++] = f[i];
+            return p;
+        }
     int rem = n;
     while (rem > 1) {
         int r = 8;
@@ -122,6 +141,8 @@ struct rl_gridop {
     int colsA = 0;   // columns per k_cols_* workgroup
     int rowsB = 0;   // rows per k_rows_mix workgroup
     int rowsS = 0;   // rows per k_rows_spec workgroup
+    int code1 = 0, code2 = 0;   // fused_code(N1), fused_code(N2); both != 0 -> v2 kernels
+    bool v2 = false;
     int max_tops = 0;
     FftPlan plan1, plan2;
     cplx *tw1 = nullptr, *tw2 = nullptr, *twlo = nullptr, *twhi = nullptr;
@@ -166,6 +187,21 @@ static void set_lds_attr_rows() {
 #if !defined(RL_EMU)
     (void)hipFuncSetAttribute((const void*)k_rows_mix<D>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k2_rows_mix<D, 8, 8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k2_rows_mix<D, 8, 16>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k2_rows_mix<D, 16, 16>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+}
+template <int RA, int RB>
+static void set_lds_attr_cols2() {
+#if !defined(RL_EMU)
+    (void)hipFuncSetAttribute((const void*)k2_cols_fwd<RA, RB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k2_cols_inv<RA, RB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
 }
 
@@ -180,6 +216,7 @@ static void set_lds_attrs() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_rows_spec,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set_lds_attr_cols2<8, 8>(); set_lds_attr_cols2<8, 16>(); set_lds_attr_cols2<16, 16>();
     set_lds_attr_rows<1>();  set_lds_attr_rows<2>();  set_lds_attr_rows<3>();
     set_lds_attr_rows<4>();  set_lds_attr_rows<5>();  set_lds_attr_rows<6>();
     set_lds_attr_rows<7>();  set_lds_attr_rows<8>();  set_lds_attr_rows<9>();
@@ -246,6 +283,9 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
 
     g->plan1 = make_plan(g->N1);
     g->plan2 = make_plan(g->N2);
+    g->code1 = fused_code(g->N1);
+    g->code2 = fused_code(g->N2);
+    g->v2 = g->code1 != 0 && g->code2 != 0 && getenv("RUNLMC_FORCE_V1") == nullptr;
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
 
@@ -442,6 +482,97 @@ static void launch_rows_mix(rl_gridop* g, size_t pairs, hipStream_t stream, cons
               g->T, g->N1, g->N2, g->rowsB, g->plan2, g->tw2, g->freq1, g->twl, mp);
 }
 
+// ---- second-generation kernels: dispatch ------------------------------------
+// 0 means "divide normally" (d == 1 has no 32-bit magic)
+static unsigned div_magic(unsigned d) {
+    return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u;
+}
+
+// tile widths for a launch over `pairs` vector pairs: as large as LDS allows
+// while the launch still has enough workgroups to cover the 256 CUs
+static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
+    tp->N1 = g->N1;
+    tp->N2 = g->N2;
+    // column tiles: 16 columns = 256-byte rows of T; 32 when there is plenty of work
+    int C = std::min(16, g->N2);
+    if (g->N2 >= 32 && (size_t)g->N1 * 32 * sizeof(cplx) <= kLdsSoft &&
+        (size_t)(g->N2 / 32) * g->D * pairs >= 1024)
+        C = 32;
+    while ((size_t)g->N1 * C * sizeof(cplx) > kLdsSoft && C > 8) C /= 2;
+    while ((size_t)g->N1 * C * sizeof(cplx) > kLdsHard && C > 1) C /= 2;
+    tp->C = C;
+    tp->logC = ilog2(C);
+    // row tiles: enough side-by-side transforms that the first pass gives every
+    // one of the RL_THREADS threads a butterfly, more while work is plentiful
+    const int sub = g->N2 / g->plan2.radix[0];
+    auto lds = [&](int R) { return (size_t)g->N2 * ((R * g->D) | 1) * sizeof(cplx); };
+    int R = 1;
+    while (R * 2 <= g->N1 && R * g->D * sub < RL_THREADS && lds(2 * R) <= kLdsSoft) R *= 2;
+    while (R * 2 <= g->N1 && lds(2 * R) <= 40 * 1024 &&
+           (size_t)(g->N1 / (2 * R)) * pairs >= 2048)
+        R *= 2;
+    tp->R = R;
+    tp->colsMagic = div_magic((unsigned)(R * g->D));
+}
+
+template <int RA, int RB>
+static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
+                             const double* X, int nv, int D, int mode) {
+    dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
+    RL_LAUNCH((k2_cols_fwd<RA, RB>), grid, dim3(RL_THREADS), (size_t)g->N1 * tp.C * sizeof(cplx),
+              st, X, nv, D, g->m, mode, g->T, tp, g->plan1, g->tw1, g->freq1, g->twl);
+}
+template <int RA, int RB>
+static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
+                             double* Y, int nv) {
+    const int colsNeeded = std::min(g->m, g->N2);
+    dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
+    RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(RL_THREADS), (size_t)g->N1 * tp.C * sizeof(cplx),
+              st, g->T, Y, nv, g->D, g->m, tp, g->plan1, g->tw1);
+}
+template <int D, int RA, int RB>
+static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
+                         const MixParams& mp) {
+    dim3 grid(g->N1 / tp.R, (unsigned)pairs);
+    const size_t lds = (size_t)g->N2 * ((tp.R * D) | 1) * sizeof(cplx);
+    RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(RL_THREADS), lds, st, g->T, tp, g->plan2,
+              g->tw2, g->freq1, g->twl, mp);
+}
+template <int D>
+static void launch2_rows_code(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
+                              const MixParams& mp) {
+    switch (g->code2) {
+        case 1: launch2_rows<D, 8, 8>(g, tp, pairs, st, mp); break;
+        case 2: launch2_rows<D, 8, 16>(g, tp, pairs, st, mp); break;
+        default: launch2_rows<D, 16, 16>(g, tp, pairs, st, mp); break;
+    }
+}
+
+static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, double* Yc, int nv,
+                        size_t pairs, hipStream_t st) {
+    Tile2 tp;
+    choose_tiles(g, pairs, &tp);
+    switch (g->code1) {
+        case 1: launch2_cols_fwd<8, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 2: launch2_cols_fwd<8, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        default: launch2_cols_fwd<16, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+    }
+    switch (g->D) {
+#define RL_CASE(d) case d: launch2_rows_code<d>(g, tp, pairs, st, mp); break;
+        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
+        RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
+        RL_CASE(14) RL_CASE(15) RL_CASE(16)
+#undef RL_CASE
+        default: return fail(RL_ELIMIT, "unsupported D");
+    }
+    switch (g->code1) {
+        case 1: launch2_cols_inv<8, 8>(g, tp, pairs, st, Yc, nv); break;
+        case 2: launch2_cols_inv<8, 16>(g, tp, pairs, st, Yc, nv); break;
+        default: launch2_cols_inv<16, 16>(g, tp, pairs, st, Yc, nv); break;
+    }
+    return RL_OK;
+}
+
 static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
                         hipStream_t stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
@@ -463,6 +594,10 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         const int nv = std::min<int>(nvec - v0, (int)(2 * pairs));
         const double* Xc = X + (size_t)v0 * vec_len;
         double* Yc = Y + (size_t)v0 * vec_len;
+        if (g->v2) {
+            RL_TRY(mvm_chunk_v2(g, mp, Xc, Yc, nv, pairs, stream));
+            continue;
+        }
         dim3 gridA(g->N2 / g->colsA, g->D, (unsigned)pairs);
         RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, Xc, nv, g->D, g->m,
                   0, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);

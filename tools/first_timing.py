@@ -1,5 +1,6 @@
 """Scratch: first timings of the grid MVM on the GPU (not a test)."""
-import sys, time
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from runlmc_amd._native import GridOp
 def run(D,Q,m,nvec,reps=20):
