@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box: one rocprofv3 --pmc pass per counter group over bench.py.
+#   tools/pmc.sh <tag> "<counters pass 1>" ["<counters pass 2>" ...] -- [bench args]
+# Counter passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one
+# pass on gfx950); never combined with sys/hip/hsa tracing.
+set -u
+tag=$1; shift
+passes=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do passes+=("$1"); shift; done
+[ $# -gt 0 ] && shift
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for p in "${passes[@]}"; do
+  out=$root/gpurun_out/pmc_${tag}/pass$i
+  mkdir -p "$out"
+  rocprofv3 --pmc $p --kernel-trace --output-format csv -d "$out" -- \
+      python3 "$root/bench.py" --no-cpu --no-nll "$@" > "$out/bench.json" 2> "$out/stderr.txt"
+  i=$((i+1))
+done
+python3 "$root/tools/pmc_summary.py" "$root/gpurun_out/pmc_${tag}"
