@@ -264,19 +264,40 @@ k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, 
 
 // ---------------------------------------------------------------------------
 // CSR gather SpMV over a batch of vectors:  Y[v] = A X[v]  (+ diag * X2[v])
-//   grid (ceil(nrows / RL_THREADS), nvec)
+//   grid (ceil(nrows / RL_THREADS), ceil(nvec / VB))
+// Each thread owns one row and VB vectors: the row's CSR entries (12 bytes per
+// non-zero) are fetched once and reused for every vector, so the matrix
+// structure is streamed nvec / VB times instead of nvec times.
 // Used for W^T x (rows = D*m grid points) and for W g + eps * x (rows = n).
 // ---------------------------------------------------------------------------
+template <int RL_SPMV_VB>
 __global__ void __launch_bounds__(RL_THREADS)
 k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
-       const double* __restrict__ vals, int nrows, int ncols, const double* __restrict__ X,
-       double* __restrict__ Y, const double* __restrict__ diag, const double* __restrict__ X2) {
+       const double* __restrict__ vals, int nrows, int ncols, int nvec,
+       const double* __restrict__ X, double* __restrict__ Y, const double* __restrict__ diag,
+       const double* __restrict__ X2) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    const int v = blockIdx.y;
+    const int v0 = blockIdx.y * RL_SPMV_VB;
     if (row >= nrows) return;
-    const double* x = X + (size_t)v * ncols;
-    double acc = 0.0;
-    for (int k = indptr[row]; k < indptr[row + 1]; ++k) acc = fma(vals[k], x[indices[k]], acc);
-    if (diag != nullptr) acc = fma(diag[row], X2[(size_t)v * nrows + row], acc);
-    Y[(size_t)v * nrows + row] = acc;
+    const int nv = nvec - v0 < RL_SPMV_VB ? nvec - v0 : RL_SPMV_VB;
+    double acc[RL_SPMV_VB];
+#pragma unroll
+    for (int j = 0; j < RL_SPMV_VB; ++j) acc[j] = 0.0;
+    const double* x = X + (size_t)v0 * ncols;
+    const int k1 = indptr[row + 1];
+    for (int k = indptr[row]; k < k1; ++k) {
+        const double a = vals[k];
+        const double* xc = x + indices[k];
+#pragma unroll
+        for (int j = 0; j < RL_SPMV_VB; ++j)
+            if (j < nv) acc[j] = fma(a, xc[(size_t)j * ncols], acc[j]);
+    }
+    const double dg = diag != nullptr ? diag[row] : 0.0;
+#pragma unroll
+    for (int j = 0; j < RL_SPMV_VB; ++j)
+        if (j < nv) {
+            double r = acc[j];
+            if (diag != nullptr) r = fma(dg, X2[(size_t)(v0 + j) * nrows + row], r);
+            Y[(size_t)(v0 + j) * nrows + row] = r;
+        }
 }

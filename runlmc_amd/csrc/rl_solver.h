@@ -99,12 +99,12 @@ k_resid_partial(const double* __restrict__ b, const double* __restrict__ ax, int
 
 // one thread per rhs: residual norm from partials; optionally freeze
 __global__ void k_resid_finish(const double* __restrict__ partial, int nblk, int nrhs,
-                               double* __restrict__ S, int* __restrict__ I, double tol,
+                               double* __restrict__ resid, int* __restrict__ I, double tol,
                                int freeze) {
     const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
     if (rhs >= nrhs) return;
     const double r = sqrt(sum_partials(partial + (size_t)rhs * nblk, nblk));
-    S[(size_t)rhs * S_NFIELDS + S_RESID] = r;
+    resid[rhs] = r;
     if (freeze && I[rhs * I_NFIELDS + I_ACTIVE] && r < tol) {
         I[rhs * I_NFIELDS + I_ACTIVE] = 0;
         I[rhs * I_NFIELDS + I_ISTOP] = RL_ISTOP_RESIDUAL;
@@ -121,13 +121,30 @@ __global__ void k_count_active(const int* __restrict__ I, int nrhs, int* __restr
 }
 
 // ---- MINRES -----------------------------------------------------------------
-// init: x = 0, r1 = r2 = b, w = w2 = 0, v = b / beta1; partial = b.b comes
-// from k_dot_partial(b, b).
+// Buffers of one batched MINRES run.  Which of the rotating buffers plays which
+// role is derived ON THE DEVICE from the global iteration counter, so every
+// iteration is launched with identical arguments and a captured hipGraph of a
+// few iterations can be replayed any number of times:
+//   it = *giter (iterations completed);  p3 = it % 3;  p2 = it & 1
+//   r1 = tri[p3], r2 = tri[p3+1], new y -> tri[p3+2]      (indices mod 3)
+//   w_{k-2} = w[p2] (overwritten by the new w), w_{k-1} = w[1-p2]
+//   scalar state: read S[p2], write S[1-p2]
+struct MinresBufs {
+    double* tri[3];
+    double* w[2];
+    double* v;      // Lanczos vector, input of the operator product
+    double* q;      // A v, output of the operator product
+    double* x;
+    double* S[2];
+    int* I;
+    int* giter;
+};
+
+// init: x = 0, r1 = r2 = b, w = 0, v = b / beta1; partial = b.b comes from
+// k_dot_partial(b, b).
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
-              double* __restrict__ x, double* __restrict__ r1, double* __restrict__ r2,
-              double* __restrict__ w1, double* __restrict__ w2, double* __restrict__ v,
-              double* __restrict__ S, int* __restrict__ I) {
+              MinresBufs mb) {
     const int rhs = blockIdx.y;
     const int nblk = gridDim.x;
     const double bb = sum_partials(partial + (size_t)rhs * nblk, nblk);
@@ -138,52 +155,57 @@ k_minres_init(const double* __restrict__ b, int n, const double* __restrict__ pa
     const double s = beta1 > 0.0 ? 1.0 / beta1 : 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const double bi = b[off + i];
-        x[off + i] = 0.0;
-        r1[off + i] = bi;
-        r2[off + i] = bi;
-        w1[off + i] = 0.0;
-        w2[off + i] = 0.0;
-        v[off + i] = s * bi;
+        mb.x[off + i] = 0.0;
+        mb.tri[0][off + i] = bi;
+        mb.tri[1][off + i] = bi;
+        mb.w[0][off + i] = 0.0;
+        mb.w[1][off + i] = 0.0;
+        mb.v[off + i] = s * bi;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double* st = S + (size_t)rhs * S_NFIELDS;
-        for (int f = 0; f < S_NFIELDS; ++f) st[f] = 0.0;
-        st[S_BETA1] = beta1;
-        st[S_BETA] = beta1;
-        st[S_PHIBAR] = beta1;
-        st[S_RHS1] = beta1;
-        st[S_GMIN] = 1.7976931348623157e308;
-        st[S_CS] = -1.0;
-        st[S_BNORM] = beta1;
-        int* it = I + rhs * I_NFIELDS;
+        for (int c = 0; c < 2; ++c) {
+            double* st = mb.S[c] + (size_t)rhs * S_NFIELDS;
+            for (int f = 0; f < S_NFIELDS; ++f) st[f] = 0.0;
+            st[S_BETA1] = beta1;
+            st[S_BETA] = beta1;
+            st[S_PHIBAR] = beta1;
+            st[S_RHS1] = beta1;
+            st[S_GMIN] = 1.7976931348623157e308;
+            st[S_CS] = -1.0;
+            st[S_BNORM] = beta1;
+        }
+        int* it = mb.I + rhs * I_NFIELDS;
         it[I_ITN] = 0;
         it[I_ISTOP] = beta1 > 0.0 ? 0 : RL_ISTOP_ZERO_RHS;
         it[I_ACTIVE] = beta1 > 0.0 ? 1 : 0;
+        if (rhs == 0) *mb.giter = 0;
     }
 }
 
-// step A (y = A v already computed): y -= (beta/oldb) r1 (itn >= 2);
-// partialA = v . y
+// step A (q = A v already computed): y = q - (beta/oldb) r1 (itn >= 2; y = q
+// on the first iteration); partialA = v . y
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
-k_minres_a(double* __restrict__ y, const double* __restrict__ v, const double* __restrict__ r1,
-           int n, const double* __restrict__ S, const int* __restrict__ I,
-           double* __restrict__ partialA) {
+k_minres_a(MinresBufs mb, int n, double* __restrict__ partialA) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y;
-    if (!I[rhs * I_NFIELDS + I_ACTIVE]) return;
-    const double* st = S + (size_t)rhs * S_NFIELDS;
-    const int itn = I[rhs * I_NFIELDS + I_ITN] + 1;
+    if (!mb.I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    const int it = *mb.giter;
+    const int p3 = it % 3;
+    const double* st = mb.S[it & 1] + (size_t)rhs * S_NFIELDS;
+    const double* r1 = mb.tri[p3];
+    double* y = mb.tri[(p3 + 2) % 3];
+    const int itn = mb.I[rhs * I_NFIELDS + I_ITN] + 1;
     const double coef = itn >= 2 ? st[S_BETA] / st[S_OLDB] : 0.0;
     int lo, hi;
     block_range(n, &lo, &hi);
     const size_t off = (size_t)rhs * n;
     double acc = 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        double yi = y[off + i];
+        double yi = mb.q[off + i];
         if (itn >= 2) yi = yi - coef * r1[off + i];
         y[off + i] = yi;
-        acc = fma(v[off + i], yi, acc);
+        acc = fma(mb.v[off + i], yi, acc);
     }
     acc = block_reduce_sum(acc, red);
     if (threadIdx.x == 0) partialA[(size_t)rhs * gridDim.x + blockIdx.x] = acc;
@@ -191,16 +213,19 @@ k_minres_a(double* __restrict__ y, const double* __restrict__ v, const double* _
 
 // step B: alfa = sum partialA; y -= (alfa/beta) r2; partialB = y . y
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
-k_minres_b(double* __restrict__ y, const double* __restrict__ r2, int n,
-           const double* __restrict__ S, const int* __restrict__ I,
-           const double* __restrict__ partialA, double* __restrict__ partialB) {
+k_minres_b(MinresBufs mb, int n, const double* __restrict__ partialA,
+           double* __restrict__ partialB) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y;
-    if (!I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    if (!mb.I[rhs * I_NFIELDS + I_ACTIVE]) return;
+    const int it = *mb.giter;
+    const int p3 = it % 3;
+    const double* r2 = mb.tri[(p3 + 1) % 3];
+    double* y = mb.tri[(p3 + 2) % 3];
     const int nblk = gridDim.x;
     const double alfa = sum_partials(partialA + (size_t)rhs * nblk, nblk);
-    const double coef = alfa / S[(size_t)rhs * S_NFIELDS + S_BETA];
+    const double coef = alfa / mb.S[it & 1][(size_t)rhs * S_NFIELDS + S_BETA];
     int lo, hi;
     block_range(n, &lo, &hi);
     const size_t off = (size_t)rhs * n;
@@ -214,27 +239,28 @@ k_minres_b(double* __restrict__ y, const double* __restrict__ r2, int n,
     if (threadIdx.x == 0) partialB[(size_t)rhs * nblk + blockIdx.x] = acc;
 }
 
-// step C: scalar recurrences (every block recomputes them from Sin, block 0
-// publishes to Sout), w = (v - oldeps w1 - delta w2) / gamma (written over
-// w1, which becomes the newest w after the host rotates pointers),
+// step C: scalar recurrences (every block recomputes them from the current
+// state copy, block 0 publishes to the other copy), new w over w_{k-2},
 // x += phi w, partialC = x . x, v <- y / beta_new.
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
-k_minres_c(const double* __restrict__ y, double* __restrict__ v, double* __restrict__ w1,
-           const double* __restrict__ w2, double* __restrict__ x, int n,
-           const double* __restrict__ Sin, double* __restrict__ Sout,
-           const int* __restrict__ I, const double* __restrict__ partialA,
+k_minres_c(MinresBufs mb, int n, const double* __restrict__ partialA,
            const double* __restrict__ partialB, double* __restrict__ partialC) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y;
     const int nblk = gridDim.x;
-    const double* si = Sin + (size_t)rhs * S_NFIELDS;
-    double* so = Sout + (size_t)rhs * S_NFIELDS;
-    if (!I[rhs * I_NFIELDS + I_ACTIVE]) {
-        // keep the ping-pong copies identical for frozen systems
+    const int it = *mb.giter;
+    const int p3 = it % 3, p2 = it & 1;
+    const double* si = mb.S[p2] + (size_t)rhs * S_NFIELDS;
+    double* so = mb.S[1 - p2] + (size_t)rhs * S_NFIELDS;
+    if (!mb.I[rhs * I_NFIELDS + I_ACTIVE]) {
+        // keep the two copies identical for frozen systems
         if (blockIdx.x == 0 && threadIdx.x < S_NFIELDS) so[threadIdx.x] = si[threadIdx.x];
         return;
     }
+    const double* y = mb.tri[(p3 + 2) % 3];
+    double* w1 = mb.w[p2];
+    const double* w2 = mb.w[1 - p2];
     const double eps = 2.220446049250313e-16;
     const double alfa = sum_partials(partialA + (size_t)rhs * nblk, nblk);
     double beta = sum_partials(partialB + (size_t)rhs * nblk, nblk);
@@ -262,12 +288,12 @@ k_minres_c(const double* __restrict__ y, double* __restrict__ v, double* __restr
     const double sinv = beta > 0.0 ? 1.0 / beta : 0.0;
     double acc = 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const double wn = (v[off + i] - oldeps * w1[off + i] - delta * w2[off + i]) * denom;
+        const double wn = (mb.v[off + i] - oldeps * w1[off + i] - delta * w2[off + i]) * denom;
         w1[off + i] = wn;
-        const double xi = x[off + i] + phi * wn;
-        x[off + i] = xi;
+        const double xi = mb.x[off + i] + phi * wn;
+        mb.x[off + i] = xi;
         acc = fma(xi, xi, acc);
-        v[off + i] = sinv * y[off + i];
+        mb.v[off + i] = sinv * y[off + i];
     }
     acc = block_reduce_sum(acc, red);
     if (threadIdx.x == 0) partialC[(size_t)rhs * nblk + blockIdx.x] = acc;
@@ -299,43 +325,49 @@ k_minres_c(const double* __restrict__ y, double* __restrict__ v, double* __restr
     }
 }
 
-// step D (one thread per rhs): ynorm from partialC, SciPy's stopping tests.
-__global__ void k_minres_test(double* __restrict__ S, int* __restrict__ I,
-                              const double* __restrict__ partialC, int nblk, int nrhs,
-                              double rtol, int maxiter) {
-    const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rhs >= nrhs) return;
-    int* it = I + rhs * I_NFIELDS;
-    if (!it[I_ACTIVE]) return;
-    const double eps = 2.220446049250313e-16;
-    const double* st = S + (size_t)rhs * S_NFIELDS;
-    const int itn = it[I_ITN] + 1;
-    it[I_ITN] = itn;
-    int istop = 0;
-    const double beta1 = st[S_BETA1];
-    if (itn == 1 && st[S_BETA] / beta1 <= 10 * eps) istop = -1;
-    const double Anorm = sqrt(st[S_TNORM2]);
-    const double ynorm = sqrt(sum_partials(partialC + (size_t)rhs * nblk, nblk));
-    const double epsx = Anorm * ynorm * eps;
-    const double rnorm = st[S_PHIBAR];
-    const double inf = 1.0 / 0.0;
-    const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? inf : rnorm / (Anorm * ynorm);
-    const double test2 = Anorm == 0.0 ? inf : st[S_ROOT] / Anorm;
-    const double Acond = st[S_GMAX] / st[S_GMIN];
-    if (istop == 0) {
-        const double t1 = 1.0 + test1, t2 = 1.0 + test2;
-        if (t2 <= 1.0) istop = 2;
-        if (t1 <= 1.0) istop = 1;
-        if (itn >= maxiter) istop = 6;
-        if (Acond >= 0.1 / eps) istop = 4;
-        if (epsx >= beta1) istop = 3;
-        if (test2 <= rtol) istop = 2;
-        if (test1 <= rtol) istop = 1;
+// step D (ONE workgroup): ynorm from partialC, SciPy's stopping tests for every
+// system, then the global iteration counter advances (after every thread of
+// this single workgroup has read it).
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres_test(MinresBufs mb, const double* __restrict__ partialC, int nblk, int nrhs,
+              double rtol, int maxiter) {
+    const int it0 = *mb.giter;
+    const double* S = mb.S[1 - (it0 & 1)];      // the copy step C just wrote
+    for (int rhs = threadIdx.x; rhs < nrhs; rhs += blockDim.x) {
+        int* it = mb.I + rhs * I_NFIELDS;
+        if (!it[I_ACTIVE]) continue;
+        const double eps = 2.220446049250313e-16;
+        const double* st = S + (size_t)rhs * S_NFIELDS;
+        const int itn = it[I_ITN] + 1;
+        it[I_ITN] = itn;
+        int istop = 0;
+        const double beta1 = st[S_BETA1];
+        if (itn == 1 && st[S_BETA] / beta1 <= 10 * eps) istop = -1;
+        const double Anorm = sqrt(st[S_TNORM2]);
+        const double ynorm = sqrt(sum_partials(partialC + (size_t)rhs * nblk, nblk));
+        const double epsx = Anorm * ynorm * eps;
+        const double rnorm = st[S_PHIBAR];
+        const double inf = 1.0 / 0.0;
+        const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? inf : rnorm / (Anorm * ynorm);
+        const double test2 = Anorm == 0.0 ? inf : st[S_ROOT] / Anorm;
+        const double Acond = st[S_GMAX] / st[S_GMIN];
+        if (istop == 0) {
+            const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+            if (t2 <= 1.0) istop = 2;
+            if (t1 <= 1.0) istop = 1;
+            if (itn >= maxiter) istop = 6;
+            if (Acond >= 0.1 / eps) istop = 4;
+            if (epsx >= beta1) istop = 3;
+            if (test2 <= rtol) istop = 2;
+            if (test1 <= rtol) istop = 1;
+        }
+        if (istop != 0) {
+            it[I_ISTOP] = istop;
+            it[I_ACTIVE] = 0;
+        }
     }
-    if (istop != 0) {
-        it[I_ISTOP] = istop;
-        it[I_ACTIVE] = 0;
-    }
+    __syncthreads();
+    if (threadIdx.x == 0) *mb.giter = it0 + 1;
 }
 
 // ---- CG ---------------------------------------------------------------------

@@ -163,6 +163,7 @@ struct rl_gridop {
     cplx* T = nullptr;
     size_t T_pairs = 0;
     size_t chunk_pairs = 1;
+    size_t xcd_pairs = 0;   // pairs per XCD-affine chunk (0: affinity off)
 };
 
 static size_t lds_cols(const rl_gridop* g) {
@@ -315,6 +316,14 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     size_t chunk_mb = 96;
     if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
+    // XCD affinity: a pair's intermediates (D*L*16 B) must sit in one XCD's 4 MiB L2
+    {
+        double l2_mb = 3.0;
+        if (const char* e = getenv("RUNLMC_XCD_L2_MB")) l2_mb = atof(e);
+        const size_t per_pair = (size_t)D * L * sizeof(cplx);
+        const size_t ppx = (size_t)(l2_mb * 1048576.0) / per_pair;
+        g->xcd_pairs = ppx >= 1 ? 8 * ppx : 0;
+    }
     *out = g;
     return RL_OK;
 }
@@ -513,12 +522,17 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
         R *= 2;
     tp->R = R;
     tp->colsMagic = div_magic((unsigned)(R * g->D));
+    tp->pairs = (int)pairs;
+    tp->tilesC = g->N2 / C;
+    tp->tilesR = g->N1 / R;
+    tp->xcd = (g->xcd_pairs > 0 && pairs >= 16) ? 1 : 0;
 }
 
 template <int RA, int RB>
 static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                              const double* X, int nv, int D, int mode) {
     dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
+    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * D));
     RL_LAUNCH((k2_cols_fwd<RA, RB>), grid, dim3(RL_THREADS), (size_t)g->N1 * tp.C * sizeof(cplx),
               st, X, nv, D, g->m, mode, g->T, tp, g->plan1, g->tw1, g->freq1, g->twl);
 }
@@ -527,6 +541,7 @@ static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
                              double* Y, int nv) {
     const int colsNeeded = std::min(g->m, g->N2);
     dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
+    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * g->D));
     RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(RL_THREADS), (size_t)g->N1 * tp.C * sizeof(cplx),
               st, g->T, Y, nv, g->D, g->m, tp, g->plan1, g->tw1);
 }
@@ -534,6 +549,7 @@ template <int D, int RA, int RB>
 static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                          const MixParams& mp) {
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
+    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
     const size_t lds = (size_t)g->N2 * ((tp.R * D) | 1) * sizeof(cplx);
     RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(RL_THREADS), lds, st, g->T, tp, g->plan2,
               g->tw2, g->freq1, g->twl, mp);
@@ -583,7 +599,8 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_HIP(hipSetDevice(g->device));
     const size_t total_pairs = ((size_t)nvec + 1) / 2;
-    const size_t chunk = std::min(total_pairs, g->chunk_pairs);
+    size_t chunk = std::min(total_pairs, g->chunk_pairs);
+    if (g->v2 && g->xcd_pairs > 0 && total_pairs >= 16) chunk = std::min(chunk, g->xcd_pairs);
     RL_TRY(ensure_workspace(g, chunk));
     const size_t vec_len = (size_t)g->D * g->m;
     const int colsNeeded = std::min(g->m, g->N2);
@@ -660,7 +677,24 @@ struct rl_ski {
     bool has_noise = false;
     double *G1 = nullptr, *G2 = nullptr;   // dev [cap][D*m] grid-side temporaries
     int cap = 0;
+    hipStream_t solver_stream = nullptr;   // capturable stream of rl_solve_batch
 };
+
+// Small batches want every (row, vector) on its own thread (latency-bound);
+// large ones want the CSR entries reused across a block of vectors
+// (bandwidth-bound: the structure is 12 bytes per non-zero per pass).
+static void launch_spmv(const int* indptr, const int* indices, const double* vals, int nrows,
+                        int ncols, int nvec, const double* X, double* Y, const double* diag,
+                        const double* X2, hipStream_t st) {
+    const unsigned gx = (nrows + RL_THREADS - 1) / RL_THREADS;
+    if ((size_t)nrows * nvec >= ((size_t)1 << 22)) {
+        RL_LAUNCH(k_spmv<8>, dim3(gx, (nvec + 7) / 8), dim3(RL_THREADS), 0, st, indptr, indices,
+                  vals, nrows, ncols, nvec, X, Y, diag, X2);
+    } else {
+        RL_LAUNCH(k_spmv<1>, dim3(gx, nvec), dim3(RL_THREADS), 0, st, indptr, indices, vals,
+                  nrows, ncols, nvec, X, Y, diag, X2);
+    }
+}
 
 static int check_csr(const int* indptr, const int* indices, int nrows, int ncols,
                      const char* what) {
@@ -716,6 +750,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
 extern "C" int rl_ski_destroy(rl_ski* s) {
     if (!s) return RL_OK;
     (void)hipSetDevice(s->g->device);
+    if (s->solver_stream) (void)hipStreamDestroy(s->solver_stream);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2};
     for (void* p : ptrs)
@@ -757,19 +792,16 @@ extern "C" int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, 
     if (!s || !X || !G) return fail(RL_EINVAL, "rl_ski_apply_wt: NULL argument");
     if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
     RL_HIP(hipSetDevice(s->g->device));
-    dim3 grid((s->ngrid + RL_THREADS - 1) / RL_THREADS, nvec);
-    RL_LAUNCH(k_spmv, grid, dim3(RL_THREADS), 0, (hipStream_t)stream, s->WT_indptr,
-              s->WT_indices, s->WT_data, s->ngrid, s->n, X, G, (const double*)nullptr,
-              (const double*)nullptr);
+    launch_spmv(s->WT_indptr, s->WT_indices, s->WT_data, s->ngrid, s->n, nvec, X, G, nullptr,
+                nullptr, (hipStream_t)stream);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
 
 static int ski_apply_w_impl(rl_ski* s, const double* G, double* Y, int nvec, const double* diag,
                             const double* X2, hipStream_t stream) {
-    dim3 grid((s->n + RL_THREADS - 1) / RL_THREADS, nvec);
-    RL_LAUNCH(k_spmv, grid, dim3(RL_THREADS), 0, stream, s->W_indptr, s->W_indices, s->W_data,
-              s->n, s->ngrid, G, Y, diag, X2);
+    launch_spmv(s->W_indptr, s->W_indices, s->W_data, s->n, s->ngrid, nvec, G, Y, diag, X2,
+                stream);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -799,23 +831,29 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
 #include "rl_solver.h"
 
 struct SolverWork {
-    double* vec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double* S[2] = {nullptr, nullptr};
     int* I = nullptr;
     double* part[3] = {nullptr, nullptr, nullptr};
-    int* count = nullptr;
+    int* count = nullptr;   // [0] active systems, [1] global iteration counter
+    double* resid = nullptr; // [nrhs] explicit residual norms
 };
-// frees a SolverWork at scope exit (kept apart so the plain struct can be
-// copied into launch closures)
+// frees a SolverWork (and a captured graph) at scope exit; kept apart so the
+// plain struct can be copied into launch closures
 struct SolverWorkGuard {
     SolverWork* w;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
     explicit SolverWorkGuard(SolverWork* w_) : w(w_) {}
     ~SolverWorkGuard() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
         for (double* p : w->vec) if (p) (void)hipFree(p);
         for (double* p : w->S) if (p) (void)hipFree(p);
         for (double* p : w->part) if (p) (void)hipFree(p);
         if (w->I) (void)hipFree(w->I);
         if (w->count) (void)hipFree(w->count);
+        if (w->resid) (void)hipFree(w->resid);
     }
 };
 
@@ -827,7 +865,9 @@ static int solver_alloc(SolverWork& w, int nvecs, int nrhs, int n, int nblk) {
     RL_HIP(hipMalloc((void**)&w.I, (size_t)nrhs * I_NFIELDS * sizeof(int)));
     for (int i = 0; i < 3; ++i)
         RL_HIP(hipMalloc((void**)&w.part[i], (size_t)nrhs * nblk * sizeof(double)));
-    RL_HIP(hipMalloc((void**)&w.count, sizeof(int)));
+    RL_HIP(hipMalloc((void**)&w.count, 2 * sizeof(int)));
+    RL_HIP(hipMalloc((void**)&w.resid, (size_t)nrhs * sizeof(double)));
+    RL_HIP(hipMemset(w.resid, 0, (size_t)nrhs * sizeof(double)));
     return RL_OK;
 }
 
@@ -838,17 +878,52 @@ static int active_count(SolverWork& w, int nrhs, hipStream_t st, int* out) {
     return RL_OK;
 }
 
-// explicit residual ||b - K x|| of every system into resid_dev[nrhs]; freeze
-// those below tol when `freeze`
+// explicit residual ||b - K x|| of every system into w.resid; freeze those
+// below tol when `freeze`
 static int residual_check(rl_ski* s, SolverWork& w, const double* B, const double* X,
                           double* scratch, int nrhs, int n, int nblk, double tol, int freeze,
-                          double* Scur, hipStream_t st) {
+                          hipStream_t st) {
     RL_TRY(rl_ski_mvm(s, X, scratch, nrhs, st));
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
     RL_LAUNCH(k_resid_partial, grid, blk, red, st, B, (const double*)scratch, n, w.part[2]);
     RL_LAUNCH(k_resid_finish, dim3((nrhs + 63) / 64), dim3(64), 0, st,
-              (const double*)w.part[2], nblk, nrhs, Scur, w.I, tol, freeze);
+              (const double*)w.part[2], nblk, nrhs, w.resid, w.I, tol, freeze);
+    return RL_OK;
+}
+
+// one MINRES iteration: identical arguments every time (buffer roles rotate on
+// the device), so a captured run of these can be replayed
+static int minres_iteration(rl_ski* s, const MinresBufs& mb, SolverWork& w, int nrhs, int n,
+                            int nblk, double rtol, int maxiter, hipStream_t st) {
+    dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
+    const size_t red = RL_SOLVER_THREADS * sizeof(double);
+    RL_TRY(rl_ski_mvm(s, mb.v, mb.q, nrhs, st));
+    RL_LAUNCH(k_minres_a, grid, blk, red, st, mb, n, w.part[0]);
+    RL_LAUNCH(k_minres_b, grid, blk, red, st, mb, n, (const double*)w.part[0], w.part[1]);
+    RL_LAUNCH(k_minres_c, grid, blk, red, st, mb, n, (const double*)w.part[0],
+              (const double*)w.part[1], w.part[2]);
+    RL_LAUNCH(k_minres_test, dim3(1), blk, 0, st, mb, (const double*)w.part[2], nblk, nrhs,
+              rtol, maxiter);
+    return RL_OK;
+}
+
+static int cg_iteration(rl_ski* s, SolverWork& w, double* X, int nrhs, int n, int nblk,
+                        int first, int maxiter, hipStream_t st) {
+    dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
+    const size_t red = RL_SOLVER_THREADS * sizeof(double);
+    dim3 grid1((nrhs + 63) / 64), blk1(64);
+    double *r = w.vec[0], *p = w.vec[1], *q = w.vec[2];
+    RL_LAUNCH(k_cg_head, grid1, blk1, 0, st, w.S[0], w.I, (const double*)w.part[1], nblk, nrhs,
+              first, maxiter);
+    RL_LAUNCH(k_cg_p, grid, blk, 0, st, p, (const double*)r, n, (const double*)w.S[0],
+              (const int*)w.I);
+    RL_TRY(rl_ski_mvm(s, p, q, nrhs, st));
+    RL_LAUNCH(k_dot_partial, grid, blk, red, st, (const double*)p, (const double*)q, n,
+              w.part[0]);
+    RL_LAUNCH(k_cg_update, grid, blk, red, st, X, r, (const double*)p, (const double*)q, n,
+              (const double*)w.S[0], w.I, (const double*)w.part[0], w.part[1]);
+    RL_LAUNCH(k_count_iter, grid1, blk1, 0, st, w.I, nrhs);
     return RL_OK;
 }
 
@@ -863,7 +938,12 @@ extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, i
     if (check_every < 0) return fail(RL_EINVAL, "rl_solve_batch: check_every < 0");
     if (nrhs == 0) return RL_OK;
     RL_HIP(hipSetDevice(s->g->device));
-    hipStream_t st = (hipStream_t)stream;
+    // the iteration is captured into a hipGraph, which needs a capturable
+    // stream: run on the handle's own stream, ordered after the caller's
+    RL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (!s->solver_stream)
+        RL_HIP(hipStreamCreateWithFlags(&s->solver_stream, hipStreamNonBlocking));
+    hipStream_t st = s->solver_stream;
     const int n = s->n;
     if (maxiter <= 0) maxiter = n;
     const double rtol = tol < 1e-10 ? tol : 1e-10;
@@ -871,84 +951,109 @@ extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, i
     nblk = std::max(1, std::min(nblk, 64));
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
-    dim3 grid1((nrhs + 63) / 64), blk1(64);
-    const int poll_every = 10;
+
+    // iterations per graph replay: a divisor of check_every, at most 10
+    int per_graph = 10;
+    if (check_every > 0) {
+        per_graph = 1;
+        for (int d = 1; d <= 10; ++d)
+            if (check_every % d == 0) per_graph = d;
+    }
+    const bool use_graph = getenv("RUNLMC_NO_GRAPH") == nullptr;
 
     SolverWork w;
     SolverWorkGuard guard(&w);
-    RL_TRY(solver_alloc(w, method == RL_MINRES ? 6 : 4, nrhs, n, nblk));
-    int cur = 0;   // index of the current scalar-state copy
+    RL_TRY(solver_alloc(w, method == RL_MINRES ? 7 : 4, nrhs, n, nblk));
+    // everything the operator product allocates lazily must exist before capture
+    RL_TRY(ski_reserve(s, nrhs));
+    RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
     int active = nrhs;
+    int done = 0;          // iterations issued so far
 
     RL_LAUNCH(k_dot_partial, grid, blk, red, st, B, B, n, w.part[0]);
     if (method == RL_MINRES) {
-        double *r1 = w.vec[0], *r2 = w.vec[1], *y = w.vec[2], *v = w.vec[3];
-        double *wa = w.vec[4], *wb = w.vec[5];
-        RL_LAUNCH(k_minres_init, grid, blk, 0, st, B, n, (const double*)w.part[0], X, r1, r2,
-                  wa, wb, v, w.S[0], w.I);
-        RL_HIP(hipMemcpyAsync(w.S[1], w.S[0], (size_t)nrhs * S_NFIELDS * sizeof(double),
-                              hipMemcpyDeviceToDevice, st));
+        MinresBufs mb;
+        mb.tri[0] = w.vec[0]; mb.tri[1] = w.vec[1]; mb.tri[2] = w.vec[2];
+        mb.w[0] = w.vec[3]; mb.w[1] = w.vec[4];
+        mb.v = w.vec[5];
+        mb.q = w.vec[6];
+        mb.x = X;
+        mb.S[0] = w.S[0]; mb.S[1] = w.S[1];
+        mb.I = w.I;
+        mb.giter = w.count + 1;
+        RL_LAUNCH(k_minres_init, grid, blk, 0, st, B, n, (const double*)w.part[0], mb);
         RL_TRY(active_count(w, nrhs, st, &active));
-        for (int it = 1; it <= maxiter && active > 0; ++it) {
-            RL_TRY(rl_ski_mvm(s, v, y, nrhs, st));
-            RL_LAUNCH(k_minres_a, grid, blk, red, st, y, (const double*)v, (const double*)r1,
-                      n, (const double*)w.S[cur], (const int*)w.I, w.part[0]);
-            RL_LAUNCH(k_minres_b, grid, blk, red, st, y, (const double*)r2, n,
-                      (const double*)w.S[cur], (const int*)w.I, (const double*)w.part[0],
-                      w.part[1]);
-            RL_LAUNCH(k_minres_c, grid, blk, red, st, (const double*)y, v, wa,
-                      (const double*)wb, X, n, (const double*)w.S[cur], w.S[1 - cur],
-                      (const int*)w.I, (const double*)w.part[0], (const double*)w.part[1],
-                      w.part[2]);
-            cur = 1 - cur;
-            RL_LAUNCH(k_minres_test, grid1, blk1, 0, st, w.S[cur], w.I,
-                      (const double*)w.part[2], nblk, nrhs, rtol, maxiter);
-            // rotate: r1 <- r2, r2 <- y, y <- old r1 (free);  w_{k-2} <-> w_{k-1}
-            double* t = r1; r1 = r2; r2 = y; y = t;
-            t = wa; wa = wb; wb = t;
-            const bool check = check_every > 0 && it % check_every == 0;
-            if (check)
-                RL_TRY(residual_check(s, w, B, X, y, nrhs, n, nblk, tol, 1, w.S[cur], st));
-            if (check || it % poll_every == 0) RL_TRY(active_count(w, nrhs, st, &active));
+        if (use_graph && active > 0) {
+            RL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = RL_OK;
+            for (int k = 0; k < per_graph && rc == RL_OK; ++k)
+                rc = minres_iteration(s, mb, w, nrhs, n, nblk, rtol, maxiter, st);
+            hipError_t e = hipStreamEndCapture(st, &guard.graph);
+            if (rc != RL_OK) return rc;
+            RL_HIP(e);
+            RL_HIP(hipGraphInstantiate(&guard.exec, guard.graph, nullptr, nullptr, 0));
         }
-        RL_TRY(residual_check(s, w, B, X, y, nrhs, n, nblk, tol, 0, w.S[cur], st));
+        while (done < maxiter && active > 0) {
+            if (guard.exec) {
+                RL_HIP(hipGraphLaunch(guard.exec, st));
+                done += per_graph;
+            } else {
+                RL_TRY(minres_iteration(s, mb, w, nrhs, n, nblk, rtol, maxiter, st));
+                done += 1;
+            }
+            const bool check = check_every > 0 && done % check_every == 0;
+            // the free slot of the rotating triple is scratch for the check
+            if (check)
+                RL_TRY(residual_check(s, w, B, X, mb.q, nrhs, n, nblk, tol, 1, st));
+            if (check || guard.exec || done % 10 == 0)
+                RL_TRY(active_count(w, nrhs, st, &active));
+        }
+        RL_TRY(residual_check(s, w, B, X, mb.q, nrhs, n, nblk, tol, 0, st));
     } else {
-        double *r = w.vec[0], *p = w.vec[1], *q = w.vec[2], *scratch = w.vec[3];
+        double *r = w.vec[0], *p = w.vec[1], *scratch = w.vec[3];
         RL_LAUNCH(k_cg_init, grid, blk, 0, st, B, n, (const double*)w.part[0], X, r, p, w.S[0],
                   w.I, rtol);
         RL_TRY(active_count(w, nrhs, st, &active));
-        for (int it = 1; active > 0; ++it) {
-            RL_LAUNCH(k_cg_head, grid1, blk1, 0, st, w.S[0], w.I, (const double*)w.part[1],
-                      nblk, nrhs, it == 1 ? 1 : 0, maxiter);
-            RL_LAUNCH(k_cg_p, grid, blk, 0, st, p, (const double*)r, n, (const double*)w.S[0],
-                      (const int*)w.I);
-            RL_TRY(rl_ski_mvm(s, p, q, nrhs, st));
-            RL_LAUNCH(k_dot_partial, grid, blk, red, st, (const double*)p, (const double*)q, n,
-                      w.part[0]);
-            RL_LAUNCH(k_cg_update, grid, blk, red, st, X, r, (const double*)p,
-                      (const double*)q, n, (const double*)w.S[0], w.I,
-                      (const double*)w.part[0], w.part[1]);
-            RL_LAUNCH(k_count_iter, grid1, blk1, 0, st, w.I, nrhs);
-            const bool check = check_every > 0 && it % check_every == 0;
-            if (check)
-                RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 1, w.S[0], st));
-            if (check || it % poll_every == 0 || it > maxiter)
-                RL_TRY(active_count(w, nrhs, st, &active));
-            if (it > maxiter + 1) break;
+        // first iteration eagerly (its head skips the rho update), the rest from a graph
+        if (active > 0) {
+            RL_TRY(cg_iteration(s, w, X, nrhs, n, nblk, 1, maxiter, st));
+            done = 1;
+            if (check_every == 1)
+                RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 1, st));
+            RL_TRY(active_count(w, nrhs, st, &active));
         }
-        RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 0, w.S[0], st));
-        cur = 0;
+        if (use_graph && active > 0 && per_graph > 1) {
+            RL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = cg_iteration(s, w, X, nrhs, n, nblk, 0, maxiter, st);
+            hipError_t e = hipStreamEndCapture(st, &guard.graph);
+            if (rc != RL_OK) return rc;
+            RL_HIP(e);
+            RL_HIP(hipGraphInstantiate(&guard.exec, guard.graph, nullptr, nullptr, 0));
+        }
+        while (done <= maxiter && active > 0) {
+            if (guard.exec)
+                RL_HIP(hipGraphLaunch(guard.exec, st));
+            else
+                RL_TRY(cg_iteration(s, w, X, nrhs, n, nblk, 0, maxiter, st));
+            done += 1;
+            const bool check = check_every > 0 && done % check_every == 0;
+            if (check)
+                RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 1, st));
+            if (check || done % 10 == 0 || done > maxiter)
+                RL_TRY(active_count(w, nrhs, st, &active));
+        }
+        RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 0, st));
     }
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(st));
     std::vector<int> hI((size_t)nrhs * I_NFIELDS);
-    std::vector<double> hS((size_t)nrhs * S_NFIELDS);
+    std::vector<double> hR((size_t)nrhs);
     RL_HIP(hipMemcpy(hI.data(), w.I, hI.size() * sizeof(int), hipMemcpyDeviceToHost));
-    RL_HIP(hipMemcpy(hS.data(), w.S[cur], hS.size() * sizeof(double), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(hR.data(), w.resid, hR.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int r = 0; r < nrhs; ++r) {
         if (iters_out) iters_out[r] = hI[(size_t)r * I_NFIELDS + I_ITN];
         if (istop_out) istop_out[r] = hI[(size_t)r * I_NFIELDS + I_ISTOP];
-        if (resid_out) resid_out[r] = hS[(size_t)r * S_NFIELDS + S_RESID];
+        if (resid_out) resid_out[r] = hR[r];
     }
     return RL_OK;
 }

@@ -170,8 +170,28 @@ Pool& pool() {
 
 }  // namespace
 
+struct rl_emu_graph {
+    std::vector<std::function<void()>> nodes;
+    int refs = 1;
+};
+static rl_emu_graph* g_capture = nullptr;
+
+static void run_launch(dim3 grid, dim3 block, size_t smem_bytes,
+                       const std::function<void()>& body);
+
 void rl_emu_launch(dim3 grid, dim3 block, size_t smem_bytes,
                    const std::function<void()>& body) {
+    if (g_capture) {
+        std::function<void()> copy = body;
+        g_capture->nodes.push_back(
+            [=]() { run_launch(grid, block, smem_bytes, copy); });
+        return;
+    }
+    run_launch(grid, block, smem_bytes, body);
+}
+
+static void run_launch(dim3 grid, dim3 block, size_t smem_bytes,
+                       const std::function<void()>& body) {
     Job j;
     j.grid = grid;
     j.block = block;
@@ -216,6 +236,10 @@ hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
 }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k,
                           hipStream_t) {
+    if (g_capture) {
+        g_capture->nodes.push_back([=]() { std::memmove(d, s, n); });
+        return hipSuccess;
+    }
     return hipMemcpy(d, s, n, k);
 }
 hipError_t hipMemset(void* p, int v, size_t n) {
@@ -249,3 +273,33 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+    *s = reinterpret_cast<hipStream_t>(uintptr_t(0x51));
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    if (g_capture) return hipErrorInvalidValue;
+    g_capture = new rl_emu_graph;
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* graph) {
+    *graph = g_capture;
+    g_capture = nullptr;
+    return *graph ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, void*, void*, size_t) {
+    graph->refs += 1;
+    *exec = graph;
+    return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t) {
+    for (auto& node : exec->nodes) node();
+    return hipSuccess;
+}
+static void graph_unref(rl_emu_graph* g) {
+    if (g && --g->refs == 0) delete g;
+}
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec) { graph_unref(exec); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t graph) { graph_unref(graph); return hipSuccess; }

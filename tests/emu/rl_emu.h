@@ -68,4 +68,19 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipFuncSetAttribute(const void* f, int attr, int value);
+// streams + graph capture: while a capture is open, launches and async copies
+// are recorded (not run); hipGraphLaunch runs the recording.
+typedef struct rl_emu_graph* hipGraph_t;
+typedef struct rl_emu_graph* hipGraphExec_t;
+enum { hipStreamNonBlocking = 1 };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal,
+                            hipStreamCaptureModeRelaxed };
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode mode);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph);
+hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, void*, void*, size_t);
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t s);
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec);
+hipError_t hipGraphDestroy(hipGraph_t graph);
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
