@@ -74,6 +74,23 @@ class StdPeriodicSpec:
         return [e * -0.5 * sq, e * -1 * s * ds]
 
 
+class ScaledSpec:
+    """scale * k(r) with `scale` a differentiable parameter appended last
+    (reference runlmc/kern/scaled.py:13-37)."""
+
+    def __init__(self, k, scale=1.0):
+        self.k = k
+        self.scale = float(scale)
+        self.active_dims = k.active_dims
+        self.n_params = k.n_params + 1
+
+    def from_dist(self, d):
+        return self.scale * self.k.from_dist(d)
+
+    def kernel_gradient(self, d):
+        return [self.scale * g for g in self.k.kernel_gradient(d)] + [self.k.from_dist(d)]
+
+
 class KernelSpec:
     """Paramz-free stand-in for the reference FunctionalKernel, LMC kernels
     only or LMC + SLFM + independent (reference functional_kernel.py:86-302).

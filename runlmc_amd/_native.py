@@ -80,6 +80,9 @@ class GridOp:
             a = np.zeros((0, self.D)) if a is None else np.atleast_2d(as_f64(a))
             if a.size and a.shape[1] != self.D:
                 raise ValueError('coreg_vec block must be (R, %d)' % self.D)
+            if a.size:
+                # all-zero rows (independent-GP kernels carry one) add nothing
+                a = a[np.any(a != 0.0, axis=1)]
             ranks.append(a.shape[0] if a.size else 0)
             if a.size:
                 rows.append(a)

@@ -105,3 +105,33 @@ class StdPeriodic(StationaryKern):
 
     def set_params(self, p):
         self.inv_lengthscale, self.period = float(p[0]), float(p[1])
+
+
+class Scaled(StationaryKern):
+    """scale * k(r); the scale is the LAST parameter (reference
+    runlmc/kern/scaled.py:13-37)."""
+
+    def __init__(self, k, scale=1.0):
+        super().__init__('scaled_' + k.name, k.active_dims)
+        self.k = k
+        self.scale = float(scale)
+
+    def from_dist(self, dists):
+        return self.scale * self.k.from_dist(dists)
+
+    def kernel_gradient(self, dists):
+        return ([self.scale * g for g in self.k.kernel_gradient(dists)] +
+                [self.k.from_dist(dists)])
+
+    def update_gradient(self, grad):
+        grad = np.asarray(grad, dtype=float)
+        self.gradient = grad
+        self.k.update_gradient(grad[:-1])
+
+    @property
+    def param_array(self):
+        return np.concatenate([self.k.param_array, [self.scale]])
+
+    def set_params(self, p):
+        self.k.set_params(p[:-1])
+        self.scale = float(p[-1])

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import scipy.sparse
 
-from oracle.kernels import KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec
+from oracle.kernels import (KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec,
+                            ScaledSpec)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -22,6 +23,8 @@ def kernel_from_desc(desc):
         return Matern32Spec(*vals)
     if kind == 'periodic':
         return StdPeriodicSpec(*vals)
+    if kind == 'scaled_rbf':
+        return ScaledSpec(RBFSpec(vals[0]), vals[1])
     raise ValueError(kind)
 
 
@@ -33,6 +36,8 @@ class Case:
         self.g = g
         self.name = name
         self.D, self.Q, self.m = int(g['D']), int(g['Q']), int(g['m'])
+        self.num_lmc = int(g['num_lmc']) if 'num_lmc' in g else self.Q
+        self.num_slfm = int(g['num_slfm']) if 'num_slfm' in g else 0
         self.lens = [int(v) for v in g['lens']]
         self.n = sum(self.lens)
         self.grid_dists = g['grid_dists']
@@ -54,7 +59,8 @@ class Case:
 
     def spec(self):
         sp = KernelSpec(self.D, [kernel_from_desc(k) for k in self.kdesc],
-                        self.coreg_vecs, self.coreg_diags, self.noise)
+                        self.coreg_vecs, self.coreg_diags, self.noise,
+                        num_lmc=self.num_lmc, num_slfm=self.num_slfm)
         sp.set_input_dim(1)
         return sp
 
@@ -66,3 +72,5 @@ class Case:
 
 ALL_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid']
 DENSE_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1']
+# the reference's real-data workloads (BASELINE configs 3 and 4)
+DATASET_CASES = ['fx2007', 'weather']

@@ -338,7 +338,178 @@ def gen_lmc():
               n_probes=2, dense=False, n_mv=2)
 
 
+def _main():
+    if '--datasets-only' not in sys.argv:
+        gen_linalg()
+        gen_interp()
+        gen_lmc()
+    gen_datasets()
+
+
+# ---------------------------------------------------------------------------
+# 4. The reference's real-data workloads (BASELINE configs 3 and 4): inputs
+#    derived from data/fx and data/weather with the reference's own loaders
+#    restated (benchmarks/benchlib/standard_tester.py:69-148; they need paramz
+#    and `git clone`, so they cannot be imported), outputs from the reference
+#    operator / solver / gradient code at the model's INITIAL parameters
+#    (FunctionalKernel defaults, functional_kernel.py:113-133,168-210).
+# ---------------------------------------------------------------------------
+def load_fx2007():
+    import pandas as pd
+    d = os.path.join(REF, 'data', 'fx')
+    fx = pd.concat([pd.read_csv(os.path.join(d, f), index_col=1)
+                    for f in ('2007-2009.csv', '2010-2013.csv', '2014-2017.csv')])
+    fx.drop(['Wdy', 'Jul.Day'], axis=1, inplace=True)
+    fx.rename(columns={c: c[:3] for c in fx.columns}, inplace=True)
+    fx = fx.loc['2007/01/01':'2008/01/01']
+    holdout = {'CAD': slice(49, 99), 'JPY': slice(99, 149), 'AUD': slice(149, 199)}
+    xss, yss = [], []
+    for col in fx.columns:
+        keep = np.ones(len(fx), dtype=bool)
+        keep[fx[col].isnull().values] = False
+        keep[holdout.get(col, slice(0, 0))] = False
+        idx = np.flatnonzero(keep)
+        xss.append(idx.astype(float))
+        yss.append(np.reciprocal(fx[col].values[idx]))
+    return xss, yss
+
+
+def load_weather():
+    import pandas as pd
+    d = os.path.join(REF, 'data', 'weather')
+    xss, yss = [], []
+    holds = [None, (10.2, 10.8), (13.5, 14.2), None]
+    for sensor, hold in zip(['bra', 'cam', 'chi', 'sot'], holds):
+        y = pd.read_csv(os.path.join(d, sensor + 'y.csv'), header=None,
+                        names=['WSPD', 'WD', 'GST', 'ATMP'], usecols=['ATMP'])
+        x = pd.read_csv(os.path.join(d, sensor + 'x.csv'), header=None,
+                        names=['time'])
+        y.loc[y['ATMP'] == -1, 'ATMP'] = np.nan
+        y = y.dropna()
+        xy = pd.concat([x, y], axis=1, join='inner')
+        if hold is not None:
+            xy = xy.loc[~xy['time'].between(hold[0], hold[1])]
+        xss.append(xy['time'].values.astype(float))
+        yss.append(xy['ATMP'].values.astype(float))
+    return xss, yss
+
+
+def _normalise(yss):
+    # runlmc/util/normalizer.py:19-34 via models/multigp.py:63-69
+    return [(y - y.mean()) / y.std() for y in yss]
+
+
+def _dataset_case(name, seed, Xs, Ys, m, lmc, lmc_ranks, slfm, indep,
+                  n_probes, dense):
+    from scipy.stats import truncnorm
+    rng = np.random.RandomState(seed)
+    D = len(Xs)
+    Xs = [np.asarray(x, dtype=float).reshape(-1, 1) for x in Xs]
+    lens = [len(x) for x in Xs]
+    n = sum(lens)
+    y = np.hstack(Ys)
+    draw = lambda r: truncnorm(-1, 1).rvs(size=(r, D), random_state=rng)
+    coreg_vecs = ([draw(r) for r in lmc_ranks] + [draw(1) for _ in slfm] +
+                  [np.zeros((1, D)) for _ in indep])
+    coreg_diags = ([np.ones(D) for _ in lmc] + [np.zeros(D) for _ in slfm] +
+                   [np.eye(D)[d] for d in range(len(indep))])
+    noise = 0.1 * np.ones(D)
+    kdescs = list(lmc) + list(slfm) + list(indep)
+
+    def kern(desc):
+        if desc[0] == 'scaled_rbf':
+            from oracle.kernels import ScaledSpec
+            return ScaledSpec(RBFSpec(desc[1]), desc[2])
+        return _kernel_from_desc(desc)
+
+    spec = KernelSpec(D, [kern(k) for k in kdescs], coreg_vecs, coreg_diags,
+                      noise, num_lmc=len(lmc), num_slfm=len(slfm))
+    spec.set_input_dim(1)
+    grid = autogrid(Xs, lo=None, hi=None,
+                    m=None if m is None else np.array([float(m)]))[0]
+    grid_dists = grid - grid[0]
+    W = multi_interpolant(Xs, grid)
+    WT = W.transpose().tocsr()
+    ad = (0,)
+    out = dict(D=D, Q=len(kdescs), num_lmc=len(lmc), num_slfm=len(slfm),
+               lens=np.array(lens), m=len(grid), grid=grid,
+               grid_dists=grid_dists, noise=noise, y=y,
+               kdesc=np.array([';'.join(str(v) for v in k) for k in kdescs]),
+               W_indptr=W.indptr, W_indices=W.indices, W_data=W.data,
+               WT_indptr=WT.indptr, WT_indices=WT.indices, WT_data=WT.data)
+    for q in range(len(kdescs)):
+        out[f'A{q}'] = coreg_vecs[q]
+        out[f'kappa{q}'] = coreg_diags[q]
+    for d in range(D):
+        out[f'X{d}'] = Xs[d].ravel()
+    out['tops'] = spec.eval_kernels_fixed_dim(grid_dists, ad)
+    dt = spec.eval_kernel_gradients({ad: grid_dists})
+    out['dtops_count'] = np.array([len(g) for g in dt])
+    for q, gl in enumerate(dt):
+        for p_, g in enumerate(gl):
+            out[f'dtop{q}_{p_}'] = g
+    K, gks = gen_grid_kernel(spec, {ad: grid_dists}, {ad: (W, WT)}, lens)
+    out['ref_ktype'] = np.array(
+        'sum' if spec.Q == 1 else type(gks[ad].grid_K).__name__)
+    gx = rng.randn(2, D * len(grid))
+    out['grid_x'] = gx
+    ref_grid = np.array([gks[ad].grid_K.matvec(v) for v in gx])
+    for kt in ('sum', 'bt', 'slfm'):
+        out[f'grid_mv_{kt}'] = ref_grid      # auto-selected representation
+    xx = rng.randn(2, n)
+    out['full_x'] = xx
+    out['full_mv'] = np.array([K.matvec(v) for v in xx])
+    rs = rng.randint(0, 2, (n_probes, n)) * 2 - 1
+    out['rs'] = rs
+    if dense:
+        Kd = K.as_numpy()
+        Kd = 0.5 * (Kd + Kd.T)
+        c = la.cho_factor(Kd)
+        alpha = la.cho_solve(c, y)
+        inv_rs = la.cho_solve(c, rs.T.astype(float)).T
+        out['alpha_dense'] = alpha
+        out['inv_rs_dense'] = inv_rs
+        out['logdet_dense'] = 2 * np.sum(np.log(np.diag(c[0])))
+
+        class _FixedDeriv:
+            def generate(self, K_, y_):
+                return StochasticDeriv(alpha, rs, inv_rs, n_probes)
+
+        Ysplit = np.split(y, np.cumsum(lens)[:-1])
+        lik = ApproxLMCLikelihood(spec, K, {ad: grid_dists}, {ad: (W, WT)},
+                                  Ysplit, _FixedDeriv())
+        gv, gd = lik.coreg_vec_gradients(), lik.coreg_diags_gradients()
+        gkk, gn = lik.kernel_gradients(), lik.noise_gradient()
+        for q in range(len(kdescs)):
+            out[f'grad_A{q}'] = gv[q]
+            out[f'grad_kappa{q}'] = gd[q]
+            out[f'grad_kern{q}'] = np.array(gkk[q])
+        out['grad_noise'] = gn
+    sols = [Iterative.solve(K, y, verbose=True, minres=True, tol=1e-4)]
+    out['ref_minres_x'] = np.array([s[0] for s in sols])
+    out['ref_minres_iters'] = np.array([s[1] for s in sols])
+    out['ref_minres_err'] = np.array([s[2] for s in sols])
+    out['ref_cg_x'] = np.zeros((0, n))
+    out['ref_cg_iters'] = np.zeros(0, dtype=int)
+    out['ref_cg_err'] = np.zeros(0)
+    _save(name + '.npz', **out)
+
+
+def gen_datasets():
+    xss, yss = load_fx2007()
+    assert len(xss) == 13 and sum(map(len, xss)) == 3054
+    # BASELINE config 3 as the reference runs it: D=13, Q=1 RBF, rank 2,
+    # default m = 3054 // 13 = 234 (+4) (standard_tester.py:48-53)
+    _dataset_case('fx2007', 21, xss, _normalise(yss), None,
+                  lmc=[('rbf', 1.0)], lmc_ranks=[2], slfm=[], indep=[],
+                  n_probes=4, dense=True)
+    xss, yss = load_weather()
+    assert [len(x) for x in xss] == [4220, 4147, 4104, 3318]
+    # BASELINE config 4: 2 SLFM RBF + 4 independent Scaled(RBF), m = 500 (+4)
+    _dataset_case('weather', 22, xss, _normalise(yss), 500, lmc=[], lmc_ranks=[],
+                  slfm=[('rbf', 1.0), ('rbf', 1.0)],
+                  indep=[('scaled_rbf', 1.0, 1.0)] * 4, n_probes=2, dense=False)
+
+
 if __name__ == '__main__':
-    gen_linalg()
-    gen_interp()
-    gen_lmc()
+    _main()

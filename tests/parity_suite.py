@@ -33,7 +33,7 @@ from runlmc_amd.linalg.block_matrix import SymmSquareBlockMatrix
 from runlmc_amd.linalg.matrix import Matrix
 from runlmc_amd.approx.ski import SKI
 from runlmc_amd.approx.iterative import Iterative
-from runlmc_amd.kern.stationary import RBF, Matern32, StdPeriodic
+from runlmc_amd.kern.stationary import RBF, Matern32, StdPeriodic, Scaled
 from runlmc_amd.lmc.functional_kernel import FunctionalKernel
 from runlmc_amd.lmc.grid_kernel import gen_grid_kernel, GridKernel
 from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
@@ -174,14 +174,19 @@ def check_small_algebra():
 def _kernel(desc):
     parts = str(desc).split(';')
     kind, vals = parts[0], [float(v) for v in parts[1:]]
+    if kind == 'scaled_rbf':
+        return Scaled(RBF(vals[0]), vals[1])
     return {'rbf': RBF, 'matern': Matern32, 'periodic': StdPeriodic}[kind](*vals)
 
 
 def functional_kernel_for(c):
-    """Build the package's FunctionalKernel from a stored case (all kernels
-    of the golden cases are LMC kernels)."""
-    fk = FunctionalKernel(D=c.D, lmc_kernels=[_kernel(k) for k in c.kdesc],
-                          lmc_ranks=[len(a) for a in c.coreg_vecs])
+    """Build the package's FunctionalKernel from a stored case: LMC kernels
+    first, then SLFM, then independent GPs (the reference's order)."""
+    ks = [_kernel(k) for k in c.kdesc]
+    a, b = c.num_lmc, c.num_lmc + c.num_slfm
+    fk = FunctionalKernel(D=c.D, lmc_kernels=ks[:a],
+                          lmc_ranks=[len(v) for v in c.coreg_vecs[:a]],
+                          slfm_kernels=ks[a:b], indep_gp=ks[b:])
     fk.coreg_vecs = c.coreg_vecs
     fk.coreg_diags = c.coreg_diags
     fk.noise = c.noise

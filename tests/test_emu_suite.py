@@ -37,7 +37,8 @@ def test_small_algebra():
     ps.check_small_algebra()
 
 
-@pytest.mark.parametrize('name', ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid'])
+@pytest.mark.parametrize('name', ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid',
+                                  'fx2007', 'weather'])
 def test_lmc_operator(name):
     ps.check_lmc_operator(name)
 
@@ -55,7 +56,7 @@ def test_solver_edge_cases():
     ps.check_solver_edge_cases()
 
 
-@pytest.mark.parametrize('name', DENSE_CASES)
+@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_gradients_fixed_solves(name):
     ps.check_gradients_fixed_solves(name)
 

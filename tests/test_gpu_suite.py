@@ -3,7 +3,7 @@ ABI.  pytest -m gpu."""
 import pytest
 
 import parity_suite as ps
-from cases import DENSE_CASES, ALL_CASES
+from cases import DENSE_CASES, ALL_CASES, DATASET_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -37,12 +37,12 @@ def test_small_algebra():
     ps.check_small_algebra()
 
 
-@pytest.mark.parametrize('name', ALL_CASES)
+@pytest.mark.parametrize('name', ALL_CASES + DATASET_CASES)
 def test_lmc_operator(name):
     ps.check_lmc_operator(name)
 
 
-@pytest.mark.parametrize('name', ALL_CASES)
+@pytest.mark.parametrize('name', ALL_CASES + DATASET_CASES)
 def test_solver_minres(name):
     ps.check_solver(name, minres=True)
 
@@ -56,11 +56,11 @@ def test_solver_edge_cases():
     ps.check_solver_edge_cases()
 
 
-@pytest.mark.parametrize('name', DENSE_CASES)
+@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_gradients_fixed_solves(name):
     ps.check_gradients_fixed_solves(name)
 
 
-@pytest.mark.parametrize('name', DENSE_CASES)
+@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_gradients_end_to_end(name):
     ps.check_gradients_end_to_end(name)

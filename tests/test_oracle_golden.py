@@ -7,7 +7,7 @@ from oracle import operators as ops
 from oracle import interp
 from oracle import likelihood as lik
 from oracle.solver import iterative_solve
-from cases import Case, ALL_CASES, DENSE_CASES, GOLDEN
+from cases import Case, ALL_CASES, DENSE_CASES, DATASET_CASES, GOLDEN
 
 import os
 
@@ -105,7 +105,7 @@ def test_interpolation():
                                g['mi_dense'], **TIGHT)
 
 
-@pytest.mark.parametrize('name', ALL_CASES)
+@pytest.mark.parametrize('name', ALL_CASES + DATASET_CASES)
 def test_lmc_operator(name):
     c = Case(name)
     spec = c.spec()
@@ -138,7 +138,7 @@ def test_dense_and_logdet():
                                float(c.g['logdet_dense']), rtol=1e-12)
 
 
-@pytest.mark.parametrize('name', DENSE_CASES)
+@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_gradients_fixed_probes(name):
     """Reference gradient loops fed dense solves + stored probes: fully
     deterministic, so the oracle must match to roundoff."""
