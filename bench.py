@@ -31,6 +31,14 @@ from runlmc_amd.util import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+# HBM-side bytes per step from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
+# separate runs; FETCH_SIZE of the 16-B/lane reads of the intermediates doubled
+# per the gfx950 correction of MI355X_MICROARCH.md; Infinity-Cache hits are
+# counted by these counters).  Keyed by (config, batch); source file alongside.
+MEASURED_TRAFFIC = {
+    ('c2', 17): (42.7e6, 'profiles/r01/v2_c2_k17_pmc_summary.txt'),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -42,8 +50,8 @@ def parse():
                     help='vectors per step (default: probes per GPU + 1)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
     ap.add_argument('--no-nll', action='store_true', help='skip the NLL+grad timing')
-    ap.add_argument('--sweep', action='store_true',
-                    help='also time saturating batches (extra keys)')
+    ap.add_argument('--no-sweep', action='store_true',
+                    help='skip the saturating-batch timings (extra keys)')
     ap.add_argument('--cpu-seconds', type=float, default=8.0)
     return ap.parse_args()
 
@@ -269,16 +277,20 @@ def main():
                    'D': D, 'Q': Q, 'm': p.m, 'L': g.L, 'batch': batch,
                    'fft_split': [g.N1, g.N2], 'parallelism': 'probe-shard x%d' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': MEASURED_TRAFFIC.get((args.config, batch), (None, None))[0],
+                     'traffic_source': MEASURED_TRAFFIC.get((args.config, batch), (None, None))[1],
                      'kernel': 'grid MVM = k_cols_fwd + k_rows_mix<%d> + k_cols_inv' % D,
                      'algorithmic_bytes_per_step': alg,
                      'device_ms_per_step': ev_ms},
     }
 
-    if args.sweep and rank == 0:
+    if not args.no_sweep and world == 1:
+        # the configured batch (N+1 vectors) is latency-bound on a chip this
+        # size; larger batches show what the same kernels sustain
         sweep = {}
-        for b in (2, 17, 64, 256, 1024):
-            if b * D * p.m * 8 * 2 > 8e9:
+        for b in (64, 256, 1024):
+            if b * D * p.m * 8 * 2 > 4e9:
                 continue
             Xb = torch.randn(b, D * p.m, dtype=torch.float64, device=dev)
             Yb = torch.empty_like(Xb)

@@ -316,9 +316,12 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     size_t chunk_mb = 96;
     if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
-    // XCD affinity: a pair's intermediates (D*L*16 B) must sit in one XCD's 4 MiB L2
+    // XCD affinity (experiment knob, OFF by default: measured slower on MI355X --
+    // 1.30 vs 1.65 M MVM/s at C2, batch 1024 -- because the small chunks it
+    // needs cost more than the L2 re-reads save): a pair's intermediates
+    // (D*L*16 B) would have to sit in one XCD's 4 MiB L2
     {
-        double l2_mb = 3.0;
+        double l2_mb = 0.0;
         if (const char* e = getenv("RUNLMC_XCD_L2_MB")) l2_mb = atof(e);
         const size_t per_pair = (size_t)D * L * sizeof(cplx);
         const size_t ppx = (size_t)(l2_mb * 1048576.0) / per_pair;

@@ -15,7 +15,7 @@ for p in "${passes[@]}"; do
   out=$root/gpurun_out/pmc_${tag}/pass$i
   mkdir -p "$out"
   rocprofv3 --pmc $p --kernel-trace --output-format csv -d "$out" -- \
-      python3 "$root/bench.py" --no-cpu --no-nll "$@" > "$out/bench.json" 2> "$out/stderr.txt"
+      python3 "$root/bench.py" --no-cpu --no-nll --no-sweep "$@" > "$out/bench.json" 2> "$out/stderr.txt"
   i=$((i+1))
 done
 python3 "$root/tools/pmc_summary.py" "$root/gpurun_out/pmc_${tag}"

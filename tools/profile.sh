@@ -9,6 +9,6 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- \
-    python3 "$root/bench.py" --no-cpu --no-nll "$@" > "$out/bench.json" 2> "$out/stderr.txt"
+    python3 "$root/bench.py" --no-cpu --no-nll --no-sweep "$@" > "$out/bench.json" 2> "$out/stderr.txt"
 find "$out" -name '*kernel_stats.csv' | head -1 | xargs -r head -12
 cat "$out/bench.json"
