@@ -122,6 +122,18 @@ int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method, 
                    int check_every, int maxiter, int* iters_out, double* resid_out,
                    int* istop_out, void* stream);
 
+/* Same solve, additionally returning the Lanczos tridiagonal MINRES builds for
+ * each system: lanczos_out host [nrhs][lanczos_cap][2] = (alfa_k, beta_{k+1})
+ * for k = 1..min(iterations, lanczos_cap) (untouched beyond).  With
+ * Rademacher right-hand sides these give a stochastic-Lanczos-quadrature
+ * estimate of log det K~ at no extra operator products -- the matrix-free
+ * log-determinant the reference lists as future work (README.md:88-89; its
+ * own log_det_K is a dense Cholesky, models/interpolated_llgp.py:262-276).
+ * RL_MINRES only; lanczos_out may be NULL (then identical to rl_solve_batch). */
+int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, double tol,
+                           int check_every, int maxiter, int* iters_out, double* resid_out,
+                           int* istop_out, double* lanczos_out, int lanczos_cap, void* stream);
+
 /* ---- partial sums of the Hutchinson gradient --------------------------------
  * Replace the P*(N+1) operator products of StochasticDeriv.d_normal_quadratic
  * / d_logdet_K (runlmc/lmc/stochastic_deriv.py:69-78) driven by

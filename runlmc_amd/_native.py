@@ -206,19 +206,53 @@ class SkiOp:
 MINRES, CG = 0, 1
 
 
-def solve_batch(ski, B, method=MINRES, tol=1e-4, check_every=100, maxiter=0):
+def solve_batch(ski, B, method=MINRES, tol=1e-4, check_every=100, maxiter=0,
+                lanczos_cap=0):
     """Device batched solve K~ X = B.  B: (k, n) tensor on ski.device.
-    Returns (X tensor, iterations int[k], residuals float[k], istop int[k])."""
+    Returns (X tensor, iterations int[k], residuals float[k], istop int[k]);
+    with lanczos_cap > 0 (MINRES only) a fifth item, the (k, cap, 2) array of
+    Lanczos coefficients (alfa_j, beta_{j+1}) of every system."""
     k = B.shape[0]
     X = torch.empty_like(B)
     iters = np.zeros(k, dtype=np.int32)
     istop = np.zeros(k, dtype=np.int32)
     resid = np.zeros(k, dtype=np.float64)
+    if lanczos_cap > 0:
+        if method != MINRES:
+            raise ValueError('Lanczos coefficients come from MINRES only')
+        lz = np.zeros((k, int(lanczos_cap), 2), dtype=np.float64)
+        ski.lib.call('rl_solve_batch_lanczos', ski.handle, dev_ptr(B), dev_ptr(X),
+                     k, float(tol), int(check_every), int(maxiter),
+                     host_ptr(iters), host_ptr(resid), host_ptr(istop),
+                     host_ptr(lz), int(lanczos_cap), ski.lib.stream_ptr(ski.device))
+        return X, iters, resid, istop, lz
     ski.lib.call('rl_solve_batch', ski.handle, dev_ptr(B), dev_ptr(X), k,
                  int(method), float(tol), int(check_every), int(maxiter),
                  host_ptr(iters), host_ptr(resid), host_ptr(istop),
                  ski.lib.stream_ptr(ski.device))
     return X, iters, resid, istop
+
+
+def slq_quadratic_forms(lanczos, iters, sqnorms):
+    """r^T log(K) r for each system from its Lanczos tridiagonal (Gauss
+    quadrature): ||r||^2 * sum_j tau_j^2 log(theta_j), (theta, first
+    eigenvector components tau) the eigenpairs of T_k.  Host, O(k^2) each."""
+    from scipy.linalg import eigh_tridiagonal
+    out = np.zeros(len(iters))
+    for i, k in enumerate(iters):
+        k = int(min(k, lanczos.shape[1]))
+        if k < 1:
+            continue
+        d = lanczos[i, :k, 0]
+        e = lanczos[i, :k - 1, 1]
+        if k == 1:
+            theta, tau2 = d[:1], np.ones(1)
+        else:
+            theta, vecs = eigh_tridiagonal(d, e)
+            tau2 = vecs[0] ** 2
+        keep = theta > 0
+        out[i] = sqnorms[i] * np.sum(tau2[keep] * np.log(theta[keep]))
+    return out
 
 
 def cross_dots(lib, U, V, D, m):

@@ -34,13 +34,14 @@ class Iterative:
     CHECK_EVERY = 100      # reference iterative.py:39
 
     @staticmethod
-    def solve_device(K, B, minres=True, tol=1e-4, maxiter=0):
+    def solve_device(K, B, minres=True, tol=1e-4, maxiter=0, lanczos_cap=0):
         """B: (k, n) float64 tensor on the operator's device.  Returns
-        (X tensor, iterations, residuals, istop) without leaving the GPU."""
+        (X tensor, iterations, residuals, istop[, lanczos]) without the
+        vectors leaving the GPU."""
         ski = _device_operator(K)
         return solve_batch(ski, B.contiguous(), MINRES if minres else CG,
                            tol=tol, check_every=Iterative.CHECK_EVERY,
-                           maxiter=maxiter)
+                           maxiter=maxiter, lanczos_cap=lanczos_cap)
 
     @staticmethod
     def solve(K, y, verbose=False, minres=True, tol=1e-4):

@@ -138,6 +138,8 @@ struct MinresBufs {
     double* S[2];
     int* I;
     int* giter;
+    double* lanczos;    // [nrhs][lanczos_cap][2] (alfa_k, beta_{k+1}) or NULL
+    int lanczos_cap;
 };
 
 // init: x = 0, r1 = r2 = b, w = 0, v = b / beta1; partial = b.b comes from
@@ -300,6 +302,14 @@ k_minres_c(MinresBufs mb, int n, const double* __restrict__ partialA,
 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int f = 0; f < S_NFIELDS; ++f) so[f] = si[f];
+        // Lanczos tridiagonal entries of this system (stochastic Lanczos
+        // quadrature of log det reuses them; nothing else reads them)
+        const int itn = mb.I[rhs * I_NFIELDS + I_ITN];      // completed so far
+        if (mb.lanczos != nullptr && itn < mb.lanczos_cap) {
+            double* lz = mb.lanczos + ((size_t)rhs * mb.lanczos_cap + itn) * 2;
+            lz[0] = alfa;
+            lz[1] = beta;
+        }
         so[S_OLDB] = oldb;
         so[S_BETA] = beta;
         so[S_TNORM2] = tnorm2;

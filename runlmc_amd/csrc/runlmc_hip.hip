@@ -840,6 +840,7 @@ struct SolverWork {
     double* part[3] = {nullptr, nullptr, nullptr};
     int* count = nullptr;   // [0] active systems, [1] global iteration counter
     double* resid = nullptr; // [nrhs] explicit residual norms
+    double* lanczos = nullptr;
 };
 // frees a SolverWork (and a captured graph) at scope exit; kept apart so the
 // plain struct can be copied into launch closures
@@ -857,6 +858,7 @@ struct SolverWorkGuard {
         if (w->I) (void)hipFree(w->I);
         if (w->count) (void)hipFree(w->count);
         if (w->resid) (void)hipFree(w->resid);
+        if (w->lanczos) (void)hipFree(w->lanczos);
     }
 };
 
@@ -930,9 +932,32 @@ static int cg_iteration(rl_ski* s, SolverWork& w, double* X, int nrhs, int n, in
     return RL_OK;
 }
 
+static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int method,
+                            double tol, int check_every, int maxiter, int* iters_out,
+                            double* resid_out, int* istop_out, double* lanczos_out,
+                            int lanczos_cap, void* stream);
+
 extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method,
                               double tol, int check_every, int maxiter, int* iters_out,
                               double* resid_out, int* istop_out, void* stream) {
+    return solve_batch_impl(s, B, X, nrhs, method, tol, check_every, maxiter, iters_out,
+                            resid_out, istop_out, nullptr, 0, stream);
+}
+
+extern "C" int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs,
+                                      double tol, int check_every, int maxiter, int* iters_out,
+                                      double* resid_out, int* istop_out, double* lanczos_out,
+                                      int lanczos_cap, void* stream) {
+    if (lanczos_out != nullptr && lanczos_cap < 1)
+        return fail(RL_EINVAL, "rl_solve_batch_lanczos: lanczos_cap < 1");
+    return solve_batch_impl(s, B, X, nrhs, RL_MINRES, tol, check_every, maxiter, iters_out,
+                            resid_out, istop_out, lanczos_out, lanczos_cap, stream);
+}
+
+static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int method,
+                            double tol, int check_every, int maxiter, int* iters_out,
+                            double* resid_out, int* istop_out, double* lanczos_out,
+                            int lanczos_cap, void* stream) {
     if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_batch: NULL argument");
     if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_batch: nrhs < 0");
     if (method != RL_MINRES && method != RL_CG)
@@ -984,6 +1009,15 @@ extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, i
         mb.S[0] = w.S[0]; mb.S[1] = w.S[1];
         mb.I = w.I;
         mb.giter = w.count + 1;
+        mb.lanczos = nullptr;
+        mb.lanczos_cap = 0;
+        if (lanczos_out != nullptr) {
+            const size_t bytes = (size_t)nrhs * lanczos_cap * 2 * sizeof(double);
+            RL_HIP(hipMalloc((void**)&w.lanczos, bytes));
+            RL_HIP(hipMemsetAsync(w.lanczos, 0, bytes, st));
+            mb.lanczos = w.lanczos;
+            mb.lanczos_cap = lanczos_cap;
+        }
         RL_LAUNCH(k_minres_init, grid, blk, 0, st, B, n, (const double*)w.part[0], mb);
         RL_TRY(active_count(w, nrhs, st, &active));
         if (use_graph && active > 0) {
@@ -1053,6 +1087,10 @@ extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, i
     std::vector<double> hR((size_t)nrhs);
     RL_HIP(hipMemcpy(hI.data(), w.I, hI.size() * sizeof(int), hipMemcpyDeviceToHost));
     RL_HIP(hipMemcpy(hR.data(), w.resid, hR.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (lanczos_out != nullptr && w.lanczos != nullptr)
+        RL_HIP(hipMemcpy(lanczos_out, w.lanczos,
+                         (size_t)nrhs * lanczos_cap * 2 * sizeof(double),
+                         hipMemcpyDeviceToHost));
     for (int r = 0; r < nrhs; ++r) {
         if (iters_out) iters_out[r] = hI[(size_t)r * I_NFIELDS + I_ITN];
         if (istop_out) istop_out[r] = hI[(size_t)r * I_NFIELDS + I_ISTOP];

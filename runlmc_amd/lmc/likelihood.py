@@ -84,6 +84,25 @@ class ApproxLMCLikelihood(LMCLikelihood):
     def alpha(self):
         return self.deriv.alpha
 
+    # -- the likelihood value itself (reference models/interpolated_llgp.py:
+    #    262-290 computes these on the model, with a DENSE Cholesky log-det of
+    #    the exact kernel; here the log-det is matrix-free) ----------------------
+    def normal_quadratic(self):
+        """y^T K^-1 y with the Krylov alpha (interpolated_llgp.py:278-285)."""
+        return float(self.y.dot(self.deriv.alpha))
+
+    def log_det_K(self):
+        """Stochastic Lanczos quadrature estimate of log det K~ from the probe
+        solves' own Lanczos coefficients (no extra MVMs)."""
+        return self.deriv.logdet_K()
+
+    def log_likelihood(self):
+        """-(log det K + y^T alpha + n log 2 pi) / 2
+        (interpolated_llgp.py:287-290)."""
+        n = len(self.y)
+        return -0.5 * (self.log_det_K() + self.normal_quadratic() +
+                       n * np.log(2 * np.pi))
+
     # -- the batched partial sums ------------------------------------------------
     def _partials(self):
         if self._parts is not None:

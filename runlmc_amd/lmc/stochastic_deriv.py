@@ -15,6 +15,9 @@ from ..util.dist import rank_world, shard_rows, all_reduce_sum_, broadcast_
 
 
 class StochasticDerivService:
+    # Lanczos steps kept per system for the log-determinant quadrature
+    LANCZOS_CAP = 256
+
     def __init__(self, metrics, pool, n_it, tol, group=None):
         self.metrics = metrics
         self._pool = pool          # interface compatibility only
@@ -42,8 +45,8 @@ class StochasticDerivService:
         rhs = np.vstack([np.asarray(y, dtype=np.float64)[None, :],
                          rs[mine].astype(np.float64)])
         B = torch.from_numpy(rhs).to(dev)
-        X, iters, resid, istop = Iterative.solve_device(
-            K, B, minres=True, tol=self._tol)
+        X, iters, resid, istop, lanczos = Iterative.solve_device(
+            K, B, minres=True, tol=self._tol, lanczos_cap=self.LANCZOS_CAP)
         rank, world = rank_world(self._group)
         if self.metrics is not None:
             # mean over the N+1 systems; alpha (solved everywhere) counted once
@@ -59,7 +62,8 @@ class StochasticDerivService:
         # use rank 0's alpha so gradients are bit-identical across ranks
         broadcast_(alpha, 0, self._group)
         return StochasticDeriv(alpha, B[1:], X[1:], self._n_it, group=self._group,
-                               iterations=iters, residuals=resid, istop=istop)
+                               iterations=iters, residuals=resid, istop=istop,
+                               lanczos=lanczos)
 
     def _concurrent_solve(self, ls):
         """Reference entry point (stochastic_deriv.py:51-52): a list of
@@ -80,7 +84,7 @@ class StochasticDeriv(Derivative):
     ``n_it`` is the GLOBAL probe count (the 1/N of the estimator)."""
 
     def __init__(self, alpha, rs, inv_rs, n_it, group=None, iterations=None,
-                 residuals=None, istop=None):
+                 residuals=None, istop=None, lanczos=None):
         to_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(a, dtype=np.float64))
         self.alpha_dev = to_t(alpha)
@@ -89,6 +93,7 @@ class StochasticDeriv(Derivative):
         self._n_it = int(n_it)
         self._group = group
         self.iterations, self.residuals, self.istop = iterations, residuals, istop
+        self.lanczos = lanczos
         self._alpha_host = None
 
     @property
@@ -104,6 +109,26 @@ class StochasticDeriv(Derivative):
     @property
     def _inv_rs(self):
         return self.inv_rs_dev.cpu().numpy()
+
+    def logdet_probe_estimates(self):
+        """Per-probe stochastic-Lanczos-quadrature values r_i^T log(K) r_i of
+        THIS rank's probes, from the Lanczos tridiagonals the probe solves
+        built (no extra operator products)."""
+        if self.lanczos is None:
+            raise ValueError('no Lanczos coefficients were recorded')
+        from .._native import slq_quadratic_forms
+        n = self.alpha_dev.shape[0]
+        its = np.asarray(self.iterations)[1:]
+        sq = np.full(len(its), float(n))         # ||r||^2 = n for +-1 probes
+        return slq_quadratic_forms(self.lanczos[1:], its, sq)
+
+    def logdet_K(self):
+        """Hutchinson + Lanczos-quadrature estimate of log det K (mean over
+        all ranks' probes)."""
+        local = self.logdet_probe_estimates()
+        tot = torch.tensor([float(local.sum())], dtype=torch.float64)
+        all_reduce_sum_(tot, self._group)
+        return float(tot[0]) / self._n_it
 
     # generic operator form, any Matrix dKdt (reference :69-78)
     def d_normal_quadratic(self, dKdt):

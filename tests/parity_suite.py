@@ -326,3 +326,29 @@ def check_gradients_end_to_end(name):
     d[0] = 1
     dK = Diag(np.repeat(d, c.lens))
     assert abs(lik.deriv.derivative(dK) - lik.noise_gradient()[0]) < 1e-9
+
+
+def check_logdet_slq(name):
+    """Matrix-free log det K~: (1) the Lanczos quadrature of each stored probe
+    against the exact r^T log(K) r from the dense K~ (deterministic, tight);
+    (2) the Hutchinson mean against the dense Cholesky log-det within its
+    sampling error."""
+    c = Case(name)
+    fk, K, gk = build_operator(c)
+    ad = (0,)
+    svc = StochasticDerivService(None, None, len(c.rs), 1e-4)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
+                              c.Ys, svc, probes=c.rs)
+    est = lik.deriv.logdet_probe_estimates()
+    exact_ld = float(c.g['logdet_dense'])
+    if 'K_dense' in c.g:
+        w, V = np.linalg.eigh(c.g['K_dense'])
+        logK = (V * np.log(w)) @ V.T
+        exact = np.array([r @ logK @ r for r in c.rs.astype(float)])
+        np.testing.assert_allclose(est, exact, rtol=2e-3)
+    mean = lik.log_det_K()
+    sem = est.std(ddof=1) / np.sqrt(len(est))
+    assert abs(mean - exact_ld) <= 5 * sem + 0.02 * abs(exact_ld), (mean, exact_ld, sem)
+    ll = lik.log_likelihood()
+    ref_ll = -0.5 * (exact_ld + c.y.dot(c.g['alpha_dense']) + c.n * np.log(2 * np.pi))
+    assert abs(ll - ref_ll) <= 0.5 * (5 * sem + 0.02 * abs(exact_ld)) + 1e-4 * abs(ref_ll)

@@ -63,3 +63,8 @@ def test_gradients_fixed_solves(name):
 
 def test_gradients_end_to_end():
     ps.check_gradients_end_to_end('lmc_small')
+
+
+@pytest.mark.parametrize('name', ['lmc_small', 'lmc_q1'])
+def test_logdet_slq(name):
+    ps.check_logdet_slq(name)

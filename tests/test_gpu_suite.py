@@ -64,3 +64,8 @@ def test_gradients_fixed_solves(name):
 @pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_gradients_end_to_end(name):
     ps.check_gradients_end_to_end(name)
+
+
+@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
+def test_logdet_slq(name):
+    ps.check_logdet_slq(name)
