@@ -124,14 +124,16 @@ class Scaled(StationaryKern):
                 [self.k.from_dist(dists)])
 
     def update_gradient(self, grad):
+        # the reference creates `scale` but never links it (scaled.py:20), so
+        # it is not optimised: the free parameters are the inner kernel's
         grad = np.asarray(grad, dtype=float)
-        self.gradient = grad
+        self.gradient = grad[:-1]
+        self.scale_gradient = float(grad[-1])
         self.k.update_gradient(grad[:-1])
 
     @property
     def param_array(self):
-        return np.concatenate([self.k.param_array, [self.scale]])
+        return self.k.param_array
 
     def set_params(self, p):
-        self.k.set_params(p[:-1])
-        self.scale = float(p[-1])
+        self.k.set_params(p)

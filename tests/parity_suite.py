@@ -352,3 +352,107 @@ def check_logdet_slq(name):
     ll = lik.log_likelihood()
     ref_ll = -0.5 * (exact_ld + c.y.dot(c.g['alpha_dense']) + c.n * np.log(2 * np.pi))
     assert abs(ll - ref_ll) <= 0.5 * (5 * sem + 0.02 * abs(exact_ld)) + 1e-4 * abs(ref_ll)
+
+
+# --- the caller: model shell, prediction, optimiser ----------
+def _model_for(c, prediction='on-the-fly', n_probes=None):
+    from runlmc_amd.models.interpolated_llgp import InterpolatedLLGP
+    fk = functional_kernel_for(c)
+    Xs = [x.reshape(-1, 1) for x in c.Xs]
+    model = InterpolatedLLGP(Xs, c.Ys, normalize=False, m=[c.m - 4],
+                             functional_kernel=fk, prediction=prediction,
+                             trace_iterations=n_probes or len(c.rs), tolerance=1e-4)
+    np.testing.assert_allclose(model.dists[(0,)], c.grid_dists, rtol=0, atol=1e-12)
+    return model
+
+
+def _dense_pieces(c):
+    """Dense K~, K_UU and exact cross-covariance helper from the oracle."""
+    spec = c.spec()
+    op = olik.LMCOperatorOracle(spec, c.grid_dists, c.W, c.WT, c.lens)
+    Kd = op.as_numpy()
+    Kd = 0.5 * (Kd + Kd.T)
+    Kuu = ops.dense_from_matvec(op.grid_matvec, c.D * c.m)
+    return spec, op, Kd, Kuu
+
+
+def _exact_cross(spec, Xtest, Xtrain, D):
+    rl, cl = [len(x) for x in Xtest], [len(x) for x in Xtrain]
+    a = np.concatenate([np.ravel(x) for x in Xtest])
+    b = np.concatenate([np.ravel(x) for x in Xtrain])
+    dist = np.abs(a[:, None] - b[None, :])
+    ro, co = np.repeat(np.arange(D), rl), np.repeat(np.arange(D), cl)
+    K = np.zeros((len(a), len(b)))
+    for B, k in zip(spec.coreg_mats(), spec._kernels):
+        K += B[np.ix_(ro, co)] * k.from_dist(dist)
+    return K
+
+
+def check_model_prediction(name='lmc_small'):
+    from runlmc_amd.approx.interpolation import multi_interpolant
+    c = Case(name)
+    np.random.seed(5)
+    spec, op, Kd, Kuu = _dense_pieces(c)
+    alpha_d = np.linalg.solve(Kd, c.y)
+    rng = np.random.RandomState(9)
+    Xt = [np.sort(rng.rand(4 + d)).reshape(-1, 1) * 0.9 + 0.05 for d in range(c.D)]
+    grid = c.g['grid']
+    Wt = multi_interpolant(Xt, grid).toarray()
+    mean_ref = Wt @ (Kuu @ (c.WT @ alpha_d))
+    coreg = np.column_stack([np.square(a).sum(axis=0) for a in c.coreg_vecs]) + \
+        np.column_stack(c.coreg_diags)
+    k0 = np.array([float(k.from_dist(0.0)) for k in spec._kernels])
+    native = np.repeat(coreg @ k0 + c.noise, [len(x) for x in Xt])
+    Kx = _exact_cross(spec, Xt, c.Xs, c.D)
+    var_fly_ref = np.clip(native - np.einsum('ij,ji->i', Kx, np.linalg.solve(Kd, Kx.T)), 0, None)
+    nu = np.diag(Kuu @ (c.WT @ np.linalg.solve(Kd, c.W @ Kuu)))
+    var_pre_ref = np.clip(native - Wt @ nu, 0, None)
+
+    for mode, var_ref in (('on-the-fly', var_fly_ref), ('precompute', var_pre_ref)):
+        model = _model_for(c, prediction=mode)
+        mu, var = model.predict(Xt)
+        _close(np.concatenate(mu), mean_ref, rel=1e-5)
+        np.testing.assert_allclose(np.concatenate(var), var_ref, rtol=0,
+                                   atol=1e-5 * max(native.max(), 1.0))
+        assert [len(v) for v in mu] == [len(x) for x in Xt]
+    # empty request for one output, quantiles, normalisation round trip
+    model = _model_for(c)
+    Xe = [Xt[0]] + [np.zeros((0, 1))] * (c.D - 1)
+    mu, var = model.predict(Xe)
+    assert len(mu[1]) == 0 and len(mu[0]) == len(Xt[0])
+    lo, hi = model.predict_quantiles(Xe)[0]
+    assert np.all(lo <= mu[0]) and np.all(mu[0] <= hi)
+
+
+def check_model_optimize(name='lmc_q1'):
+    """Five AdaDelta steps raise the (dense, SKI) log likelihood (reference
+    models/test_interpolated_llgp.py:248-255) and the parameter vector round
+    trips through the Logexp transform."""
+    c = Case(name)
+    np.random.seed(11)
+    model = _model_for(c, n_probes=10)
+    x0 = model.param_array.copy()
+    model.param_array = x0
+    np.testing.assert_allclose(model.param_array, x0, rtol=1e-12, atol=1e-12)
+
+    def dense_ll():
+        fk = model._functional_kernel
+        from oracle.kernels import KernelSpec
+        sp = KernelSpec(c.D, c.spec()._kernels, fk.coreg_vecs, fk.coreg_diags, fk.noise)
+        for ks, k in zip(sp._kernels, fk.kernels):
+            ks.inv_lengthscale = k.inv_lengthscale
+        sp.set_input_dim(1)
+        Kd = olik.LMCOperatorOracle(sp, c.grid_dists, c.W, c.WT, c.lens).as_numpy()
+        Kd = 0.5 * (Kd + Kd.T)
+        return -0.5 * (olik.logdet_dense(Kd) + c.y @ np.linalg.solve(Kd, c.y) +
+                       c.n * np.log(2 * np.pi))
+
+    before = dense_ll()
+    # the matrix-free likelihood agrees with the dense one within its sampling error
+    assert abs(model.log_likelihood() - before) < 0.15 * abs(before) + 5.0
+    g = model.gradient
+    assert g.shape == x0.shape and np.all(np.isfinite(g))
+    opt = model.optimize(max_it=5)
+    assert opt.n_iter == 5
+    after = dense_ll()
+    assert after > before, (before, after)

@@ -69,3 +69,11 @@ def test_gradients_end_to_end(name):
 @pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_logdet_slq(name):
     ps.check_logdet_slq(name)
+
+
+def test_model_prediction():
+    ps.check_model_prediction('lmc_small')
+
+
+def test_model_optimize():
+    ps.check_model_optimize('lmc_q1')
