@@ -83,6 +83,47 @@ struct SmallDft<8, INV> {
     }
 };
 
+// Odd radices: only ever the FIRST pass of a column transform whose length is
+// 3 * 2^a or 5 * 2^a (embedding lengths just above 2m instead of the next
+// power of two).
+#define RL_SIN_PI_3 0.86602540378443864676     // sin(2 pi / 3)
+#define RL_COS_2PI_5 0.30901699437494742410
+#define RL_COS_4PI_5 -0.80901699437494742410
+#define RL_SIN_2PI_5 0.95105651629515357212
+#define RL_SIN_4PI_5 0.58778525229247312917
+template <bool INV>
+struct SmallDft<3, INV> {
+    static __device__ __forceinline__ void run(cplx* v) {
+        const cplx t = c_add(v[1], v[2]);
+        const cplx u = c_scale(c_quarter<INV>(c_sub(v[1], v[2])), RL_SIN_PI_3);
+        const cplx mid = c_make(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
+        v[0] = c_add(v[0], t);
+        v[1] = c_add(mid, u);
+        v[2] = c_sub(mid, u);
+    }
+};
+template <bool INV>
+struct SmallDft<5, INV> {
+    static __device__ __forceinline__ void run(cplx* v) {
+        const cplx t1 = c_add(v[1], v[4]), t2 = c_add(v[2], v[3]);
+        const cplx d1 = c_sub(v[1], v[4]), d2 = c_sub(v[2], v[3]);
+        const cplx a1 = c_make(v[0].x + RL_COS_2PI_5 * t1.x + RL_COS_4PI_5 * t2.x,
+                               v[0].y + RL_COS_2PI_5 * t1.y + RL_COS_4PI_5 * t2.y);
+        const cplx a2 = c_make(v[0].x + RL_COS_4PI_5 * t1.x + RL_COS_2PI_5 * t2.x,
+                               v[0].y + RL_COS_4PI_5 * t1.y + RL_COS_2PI_5 * t2.y);
+        // -i b (forward) / +i b (inverse)
+        const cplx b1 = c_quarter<INV>(c_make(RL_SIN_2PI_5 * d1.x + RL_SIN_4PI_5 * d2.x,
+                                              RL_SIN_2PI_5 * d1.y + RL_SIN_4PI_5 * d2.y));
+        const cplx b2 = c_quarter<INV>(c_make(RL_SIN_4PI_5 * d1.x - RL_SIN_2PI_5 * d2.x,
+                                              RL_SIN_4PI_5 * d1.y - RL_SIN_2PI_5 * d2.y));
+        v[0] = c_add(v[0], c_add(t1, t2));
+        v[1] = c_add(a1, b1);
+        v[4] = c_sub(a1, b1);
+        v[2] = c_add(a2, b2);
+        v[3] = c_sub(a2, b2);
+    }
+};
+
 // 16 = 4 x 4: a radix-4 stage over elements 4 apart, the W16^{jk} twiddles, a
 // radix-4 stage over contiguous quads, outputs renamed to natural order.
 #define RL_COS_PI_8 0.92387953251128673848
@@ -168,6 +209,10 @@ __device__ __forceinline__ void fft_pass_any(int radix, cplx* tile, int n, int n
                                              unsigned cols_magic = 0) {
     if (radix == 16)
         fft_pass<16, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
+    else if (radix == 5)
+        fft_pass<5, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
+    else if (radix == 3)
+        fft_pass<3, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
     else if (radix == 8)
         fft_pass<8, INV>(tile, n, ns, cols, ld, tw, tid, nthr, cols_magic);
     else if (radix == 4)

@@ -53,30 +53,30 @@ static int ilog2(int x) {
     return l;
 }
 
-// Transform lengths with a fused (register first/last pass) instantiation and
-// their radix schedules; code = 1: (8,8)  2: (8,16)  3: (16,16), 0: none.
-static int fused_code(int n) {
-    switch (n) {
-        case 64: case 512: return 1;
-        case 128: case 1024: return 2;
-        case 256: return 3;
-        default: return 0;
-    }
-}
-
+// Radix schedules.  Lengths are 2^a, 3 * 2^a or 5 * 2^a; an odd factor is always
+// the FIRST pass (its butterfly distance is then a power of two, which the
+// pass code relies on).  Power-of-two parts 8 / 16 / 64 / 128 / 256 / 512 / 1024 use
+// the schedules the fused kernels are instantiated for.
 static FftPlan make_plan(int n) {
     FftPlan p;
     p.n = n;
     p.npass = 0;
     for (int i = 0; i < RL_MAX_PASSES; ++i) p.radix[i] = 1;
-    const int fixed[5][4] = {{64, 8, 8, 0}, {128, 8, 16, 0}, {256, 16, 16, 0},
-                             {512, 8, 8, 8}, {1024, 8, 8, 16}};
+    int rem = n;
+    for (int odd : {3, 5})
+        if (rem % odd == 0) {
+            p.radix[p.npass++] = odd;
+            rem /= odd;
+            break;
+        }
+    const int fixed[7][4] = {{8, 8, 0, 0},     {16, 16, 0, 0},   {64, 8, 8, 0},
+                             {128, 8, 16, 0},  {256, 16, 16, 0}, {512, 8, 8, 8},
+                             {1024, 8, 8, 16}};
     for (const auto& f : fixed)
-        if (f[0] == n) {
+        if (f[0] == rem) {
             for (int i = 1; i < 4 && f[i]; ++i) p.radix[p.npass++] = f[i];
             return p;
         }
-    int rem = n;
     while (rem > 1) {
         int r = 8;
         while (rem % r) r /= 2;
@@ -84,6 +84,57 @@ static FftPlan make_plan(int n) {
         rem /= r;
     }
     return p;
+}
+
+// code of the fused (register first/last pass) instantiation that runs a
+// plan: first radix * 100 + last radix; 0 if there is none
+static int fused_code(const FftPlan& p) {
+    if (p.npass < 2 || p.npass > 3) return 0;
+    const int ra = p.radix[0], rb = p.radix[p.npass - 1];
+    const int code = ra * 100 + rb;
+    switch (code) {
+        case 808: case 816: case 1616: return p.n >= 64 ? code : 0;
+        case 308: case 316: case 508: case 516: return code;
+        default: return 0;
+    }
+}
+
+// Embedding length: the smallest of 2^k, 3 * 2^k, 5 * 2^k that is >= 2m (any
+// length >= 2m - 1 embeds the Toeplitz matrix exactly; the reference uses the
+// next power of two, bttb.py:16-19).  Split L = N1 * N2 with N2 a power of two
+// (row transforms) and the odd factor in N1.  RUNLMC_POW2_ONLY=1 forces the
+// reference's length.
+static void choose_length(int m, int* L_out, int* N1_out, int* N2_out) {
+    const bool pow2_only = getenv("RUNLMC_POW2_ONLY") != nullptr;
+    long best = 0;
+    int best_odd = 1;
+    for (int odd : {1, 3, 5}) {
+        if (odd != 1 && pow2_only) continue;
+        long L = odd;
+        while (L < 2L * m || L < 16) L *= 2;
+        if (odd != 1 && L / odd < 64 * 8) continue;   // too short to be worth it
+        if (best == 0 || L < best) { best = L; best_odd = odd; }
+    }
+    const int L = (int)best;
+    const int P = L / best_odd;              // power-of-two part
+    const int l = ilog2(P);
+    int N2 = 1 << ((l + 1) / 2);
+    if (best_odd != 1) {
+        // prefer a split the fused kernels cover: N2 in 64..1024 and the
+        // power-of-two part of N1 in {8, 16, 64, 128, 256}
+        int bestN2 = 0;
+        double bestScore = 1e300;
+        for (int n2 = 64; n2 <= 1024 && n2 <= P / 8; n2 *= 2) {
+            const int p1 = P / n2;
+            if (p1 != 8 && p1 != 16 && p1 != 64 && p1 != 128 && p1 != 256) continue;
+            const double score = std::fabs(std::log2((double)best_odd * p1 / n2));
+            if (score < bestScore) { bestScore = score; bestN2 = n2; }
+        }
+        if (bestN2) N2 = bestN2;
+    }
+    *L_out = L;
+    *N2_out = N2;
+    *N1_out = L / N2;
 }
 
 // position -> frequency of the in-place DIF graph (tests/flow_model.py)
@@ -218,6 +269,8 @@ static void set_lds_attrs() {
     (void)hipFuncSetAttribute((const void*)k_rows_spec,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     set_lds_attr_cols2<8, 8>(); set_lds_attr_cols2<8, 16>(); set_lds_attr_cols2<16, 16>();
+    set_lds_attr_cols2<3, 8>(); set_lds_attr_cols2<3, 16>();
+    set_lds_attr_cols2<5, 8>(); set_lds_attr_cols2<5, 16>();
     set_lds_attr_rows<1>();  set_lds_attr_rows<2>();  set_lds_attr_rows<3>();
     set_lds_attr_rows<4>();  set_lds_attr_rows<5>();  set_lds_attr_rows<6>();
     set_lds_attr_rows<7>();  set_lds_attr_rows<8>();  set_lds_attr_rows<9>();
@@ -245,12 +298,10 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     g->D = D;
     g->m = m;
     g->max_tops = max_tops;
-    int L = 16;
-    while (L < 2 * m) L *= 2;
+    int L;
+    choose_length(m, &L, &g->N1, &g->N2);
     g->L = L;
     const int l = ilog2(L);
-    g->N2 = 1 << ((l + 1) / 2);
-    g->N1 = L / g->N2;
     // rows per k_rows_mix workgroup: as many as fit the soft LDS budget; if even
     // one row does not fit, shrink N2 (longer column transforms) before giving up
     for (;;) {
@@ -284,9 +335,10 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
 
     g->plan1 = make_plan(g->N1);
     g->plan2 = make_plan(g->N2);
-    g->code1 = fused_code(g->N1);
-    g->code2 = fused_code(g->N2);
-    g->v2 = g->code1 != 0 && g->code2 != 0 && getenv("RUNLMC_FORCE_V1") == nullptr;
+    g->code1 = fused_code(g->plan1);
+    g->code2 = fused_code(g->plan2);
+    const bool rows_ok = g->code2 == 808 || g->code2 == 816 || g->code2 == 1616;
+    g->v2 = g->code1 != 0 && rows_ok && getenv("RUNLMC_FORCE_V1") == nullptr;
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
 
@@ -295,7 +347,8 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     if ((rc = upload(&g->tw2, unity_table(g->N2, 1, g->N2))) != RL_OK) return rc;
     const int shift = l / 2;
     if ((rc = upload(&g->twlo, unity_table(1L << shift, 1, L))) != RL_OK) return rc;
-    if ((rc = upload(&g->twhi, unity_table((long)L >> shift, 1L << shift, L))) != RL_OK) return rc;
+    if ((rc = upload(&g->twhi, unity_table(((long)L + (1L << shift) - 1) >> shift, 1L << shift,
+                                           L))) != RL_OK) return rc;
     if ((rc = upload(&g->freq1, g->h_freq1)) != RL_OK) return rc;
     g->twl.lo = g->twlo;
     g->twl.hi = g->twhi;
@@ -519,8 +572,9 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
     const int sub = g->N2 / g->plan2.radix[0];
     auto lds = [&](int R) { return (size_t)g->N2 * ((R * g->D) | 1) * sizeof(cplx); };
     int R = 1;
-    while (R * 2 <= g->N1 && R * g->D * sub < RL_THREADS && lds(2 * R) <= kLdsSoft) R *= 2;
-    while (R * 2 <= g->N1 && lds(2 * R) <= 40 * 1024 &&
+    while (g->N1 % (R * 2) == 0 && R * g->D * sub < RL_THREADS && lds(2 * R) <= kLdsSoft)
+        R *= 2;
+    while (g->N1 % (R * 2) == 0 && lds(2 * R) <= 40 * 1024 &&
            (size_t)(g->N1 / (2 * R)) * pairs >= 2048)
         R *= 2;
     tp->R = R;
@@ -561,8 +615,8 @@ template <int D>
 static void launch2_rows_code(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                               const MixParams& mp) {
     switch (g->code2) {
-        case 1: launch2_rows<D, 8, 8>(g, tp, pairs, st, mp); break;
-        case 2: launch2_rows<D, 8, 16>(g, tp, pairs, st, mp); break;
+        case 808: launch2_rows<D, 8, 8>(g, tp, pairs, st, mp); break;
+        case 816: launch2_rows<D, 8, 16>(g, tp, pairs, st, mp); break;
         default: launch2_rows<D, 16, 16>(g, tp, pairs, st, mp); break;
     }
 }
@@ -572,8 +626,12 @@ static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, dou
     Tile2 tp;
     choose_tiles(g, pairs, &tp);
     switch (g->code1) {
-        case 1: launch2_cols_fwd<8, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        case 2: launch2_cols_fwd<8, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 808: launch2_cols_fwd<8, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 816: launch2_cols_fwd<8, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 308: launch2_cols_fwd<3, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 316: launch2_cols_fwd<3, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 508: launch2_cols_fwd<5, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 516: launch2_cols_fwd<5, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
         default: launch2_cols_fwd<16, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
     }
     switch (g->D) {
@@ -585,8 +643,12 @@ static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, dou
         default: return fail(RL_ELIMIT, "unsupported D");
     }
     switch (g->code1) {
-        case 1: launch2_cols_inv<8, 8>(g, tp, pairs, st, Yc, nv); break;
-        case 2: launch2_cols_inv<8, 16>(g, tp, pairs, st, Yc, nv); break;
+        case 808: launch2_cols_inv<8, 8>(g, tp, pairs, st, Yc, nv); break;
+        case 816: launch2_cols_inv<8, 16>(g, tp, pairs, st, Yc, nv); break;
+        case 308: launch2_cols_inv<3, 8>(g, tp, pairs, st, Yc, nv); break;
+        case 316: launch2_cols_inv<3, 16>(g, tp, pairs, st, Yc, nv); break;
+        case 508: launch2_cols_inv<5, 8>(g, tp, pairs, st, Yc, nv); break;
+        case 516: launch2_cols_inv<5, 16>(g, tp, pairs, st, Yc, nv); break;
         default: launch2_cols_inv<16, 16>(g, tp, pairs, st, Yc, nv); break;
     }
     return RL_OK;
