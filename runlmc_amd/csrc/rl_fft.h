@@ -182,7 +182,9 @@ __device__ __forceinline__ void fft_pass(cplx* tile, int n, int ns, int cols, in
     for (int w = tid; w < work; w += nthr) {
         const int bf = cols_magic ? (int)fast_div((unsigned)w, cols_magic) : w / cols;
         const int c = w - bf * cols;
-        const int j = bf & (sub - 1);
+        // sub is a power of two except in a leading odd-radix pass of a length
+        // with two odd factors
+        const int j = (sub & (sub - 1)) == 0 ? (bf & (sub - 1)) : bf % sub;
         const int g = (bf - j) * R;  // (bf / sub) * ns
         cplx* p = tile + (size_t)(g + j) * ld + c;
         const size_t leg = (size_t)sub * ld;

@@ -53,9 +53,10 @@ static int ilog2(int x) {
     return l;
 }
 
-// Radix schedules.  Lengths are 2^a, 3 * 2^a or 5 * 2^a; an odd factor is always
-// the FIRST pass (its butterfly distance is then a power of two, which the
-// pass code relies on).  Power-of-two parts 8 / 16 / 64 / 128 / 256 / 512 / 1024 use
+// Radix schedules.  Lengths are odd * 2^a with odd in {1, 3, 5, 9, 15, 25}; odd
+// factors always come FIRST (the register first pass has no power-of-two
+// assumption; an LDS pass needs a power-of-two butterfly distance, which holds
+// for a second odd pass because what remains after it is a power of two).  Power-of-two parts 8 / 16 / 64 / 128 / 256 / 512 / 1024 use
 // the schedules the fused kernels are instantiated for.
 static FftPlan make_plan(int n) {
     FftPlan p;
@@ -63,11 +64,13 @@ static FftPlan make_plan(int n) {
     p.npass = 0;
     for (int i = 0; i < RL_MAX_PASSES; ++i) p.radix[i] = 1;
     int rem = n;
+    // at most two odd passes (9 = 3*3, 15 = 3*5, 25 = 5*5); after the last odd
+    // pass the remaining length is a power of two, so every later butterfly
+    // distance is one too
     for (int odd : {3, 5})
-        if (rem % odd == 0) {
+        while (rem % odd == 0 && p.npass < 2) {
             p.radix[p.npass++] = odd;
             rem /= odd;
-            break;
         }
     const int fixed[7][4] = {{8, 8, 0, 0},     {16, 16, 0, 0},   {64, 8, 8, 0},
                              {128, 8, 16, 0},  {256, 16, 16, 0}, {512, 8, 8, 8},
@@ -89,7 +92,7 @@ static FftPlan make_plan(int n) {
 // code of the fused (register first/last pass) instantiation that runs a
 // plan: first radix * 100 + last radix; 0 if there is none
 static int fused_code(const FftPlan& p) {
-    if (p.npass < 2 || p.npass > 3) return 0;
+    if (p.npass < 2 || p.npass > 4) return 0;
     const int ra = p.radix[0], rb = p.radix[p.npass - 1];
     const int code = ra * 100 + rb;
     switch (code) {
@@ -99,7 +102,7 @@ static int fused_code(const FftPlan& p) {
     }
 }
 
-// Embedding length: the smallest of 2^k, 3 * 2^k, 5 * 2^k that is >= 2m (any
+// Embedding length: the smallest odd * 2^k, odd in {1,3,5,9,15,25}, >= 2m (any
 // length >= 2m - 1 embeds the Toeplitz matrix exactly; the reference uses the
 // next power of two, bttb.py:16-19).  Split L = N1 * N2 with N2 a power of two
 // (row transforms) and the odd factor in N1.  RUNLMC_POW2_ONLY=1 forces the
@@ -108,7 +111,7 @@ static void choose_length(int m, int* L_out, int* N1_out, int* N2_out) {
     const bool pow2_only = getenv("RUNLMC_POW2_ONLY") != nullptr;
     long best = 0;
     int best_odd = 1;
-    for (int odd : {1, 3, 5}) {
+    for (int odd : {1, 3, 5, 9, 15, 25}) {
         if (odd != 1 && pow2_only) continue;
         long L = odd;
         while (L < 2L * m || L < 16) L *= 2;
@@ -302,24 +305,28 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     choose_length(m, &L, &g->N1, &g->N2);
     g->L = L;
     const int l = ilog2(L);
-    // rows per k_rows_mix workgroup: as many as fit the soft LDS budget; if even
-    // one row does not fit, shrink N2 (longer column transforms) before giving up
+    // rows per (first-generation) row workgroup: the largest divisor of N1 that
+    // fits the soft LDS budget and still leaves >= 16 workgroups per pair; if
+    // even one row does not fit, shrink N2 (longer column transforms)
+    auto pick_rows = [&](int cols_per_row) {
+        int best = 0;
+        for (int r = 1; r <= g->N1; ++r) {
+            if (g->N1 % r) continue;
+            if (lds_rows(g->N2, r * cols_per_row) > kLdsSoft) break;
+            if (r > 1 && g->N1 / r < 16) break;
+            best = r;
+        }
+        return best;
+    };
     for (;;) {
-        int R = 0;
-        for (int r = g->N1; r >= 1; r /= 2)
-            if (lds_rows(g->N2, r * D) <= kLdsSoft) { R = r; break; }
+        int R = pick_rows(D);
         if (R == 0 && lds_rows(g->N2, D) <= kLdsHard) R = 1;
         if (R > 0) { g->rowsB = R; break; }
         if (g->N2 <= 4) { delete g; return fail(RL_ELIMIT, "rl_gridop_create: D*L exceeds LDS"); }
         g->N2 /= 2;
         g->N1 *= 2;
     }
-    // cap rows so that a launch still has a few hundred workgroups to spread
-    while (g->rowsB > 1 && g->N1 / g->rowsB < 16) g->rowsB /= 2;
-    g->rowsS = 1;
-    for (int r = g->N1; r >= 1; r /= 2)
-        if (lds_rows(g->N2, r) <= kLdsSoft) { g->rowsS = r; break; }
-    while (g->rowsS > 1 && g->N1 / g->rowsS < 16) g->rowsS /= 2;
+    g->rowsS = std::max(1, pick_rows(1));
     // columns per k_cols_* workgroup
     int C = std::min(32, g->N2);
     while (C > 1 && ((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsSoft) C /= 2;

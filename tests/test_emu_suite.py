@@ -76,3 +76,33 @@ def test_model_prediction():
 
 def test_model_optimize():
     ps.check_model_optimize('lmc_q1')
+
+
+@pytest.mark.parametrize('D,Q,m,nvec', [
+    (2, 2, 1100, 3),      # 4096 = 64 x 64 (fused power-of-two kernels)
+    (3, 2, 700, 3),       # 1536 = 3 * 512
+    (2, 2, 2400, 3),      # 5120 = 5 * 1024
+    (2, 1, 4500, 2),      # 9216 = 9 * 1024
+    (2, 1, 7500, 2),      # 15360 = 15 * 1024
+    (2, 2, 6300, 3),      # 12800 = 25 * 512
+    (4, 3, 5004, 3)])     # C2: 10240 = 5 * 2048
+def test_embedding_lengths(D, Q, m, nvec):
+    """Every family of embedding length against the oracle (which always uses
+    the reference's next power of two: the Toeplitz product does not depend
+    on the embedding length)."""
+    import numpy as np
+    from oracle import operators as ops
+    from runlmc_amd._native import GridOp
+    rng = np.random.RandomState(m)
+    g = GridOp(D, m, Q)
+    tops = np.array([np.exp(-(0.002 + 0.01 * q) * np.arange(m)) for q in range(Q)])
+    A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+    kap = [np.abs(rng.randn(D)) for _ in range(Q)]
+    g.set_lmc(tops, A, kap)
+    X = rng.randn(nvec, D * m)
+    Y = g.matmat_host(X)
+    Bs = ops.coreg_mats(A, kap)
+    toeps = [ops.BTTBOracle(t) for t in tops]
+    for v in range(nvec):
+        ref = ops.grid_sum_matvec(Bs, toeps, X[v])
+        assert np.abs(Y[v] - ref).max() < 1e-11 * np.abs(ref).max()

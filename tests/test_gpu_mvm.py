@@ -42,7 +42,10 @@ def _random_lmc(rng, D, Q, m, maxrank=2):
 @pytest.mark.parametrize('D,Q,m,nvec', [
     (1, 1, 1, 1), (1, 1, 2, 3), (2, 1, 7, 2), (3, 2, 50, 3), (2, 2, 104, 16),
     (13, 1, 238, 16), (4, 6, 504, 9), (4, 6, 1004, 8), (16, 2, 33, 5),
-    (4, 3, 5004, 17), (7, 3, 2049, 4), (10, 5, 20001, 3)])
+    (4, 3, 5004, 17), (7, 3, 2049, 4), (10, 5, 20001, 3),
+    # embedding lengths 3*2^k, 5*2^k, 9*2^k, 15*2^k, 25*2^k
+    (3, 2, 700, 3), (2, 2, 2400, 4), (2, 1, 4500, 2), (2, 1, 7500, 3),
+    (2, 2, 6300, 5), (2, 1, 100004, 2), (1, 1, 160000, 1)])
 def test_grid_mvm_vs_oracle(native, D, Q, m, nvec):
     from runlmc_amd._native import GridOp
     rng = np.random.RandomState(D * 1000 + Q * 100 + m)
@@ -60,11 +63,16 @@ def test_grid_mvm_vs_oracle(native, D, Q, m, nvec):
     g.set_dense(tops, np.array(Bs))
     assert _rel(g.matmat_host(X), Y) < REL
     # spectra: natural-order real spectrum of the circulant embedding
-    if g.L == ops.next_pow2(2 * m):
-        for q in range(Q):
+    for q in range(Q):
+        if g.L == ops.next_pow2(2 * m):
             ref = ops.bttb_spectrum(tops[q], (m,)).real
-            got = g.spectrum(q)[:g.L // 2 + 1]
-            assert np.abs(got - ref).max() < REL * np.abs(ref).max()
+        else:       # mixed-radix length: same embedding rule at length L
+            col = np.zeros(g.L)
+            col[:m] = tops[q]
+            col[g.L - m + 1:] = tops[q][1:][::-1]
+            ref = np.fft.rfft(col).real
+        got = g.spectrum(q)[:g.L // 2 + 1]
+        assert np.abs(got - ref).max() < REL * np.abs(ref).max()
     # single top
     k = min(2, nvec)
     Y1 = g.matmat_host(X[:k], top=Q - 1)
