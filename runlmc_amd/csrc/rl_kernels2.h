@@ -14,6 +14,10 @@
 #pragma once
 #include "rl_kernels.h"
 
+// upper bound of the workgroup size of the k2_* kernels; the launcher picks 256
+// or 512 threads by how many butterflies the first pass of a tile has
+#define RL_THREADS2 512
+
 struct Tile2 {
     int N1, N2;
     int C, logC;        // columns per k2_cols_* workgroup (power of two)
@@ -27,6 +31,7 @@ struct Tile2 {
     int pairs;          // pairs in this launch (xcd mode)
     int tilesC;         // column tiles per (pair, output)
     int tilesR;         // row tiles per pair
+    int thrC, thrR;     // workgroup sizes of the column / row kernels
 };
 
 // (pair, tile-within-pair) of this workgroup; false if it is launch padding
@@ -67,7 +72,7 @@ __device__ __forceinline__ void middle_adjoint(cplx* tile, const FftPlan& plan, 
 // LDS: tile [N1][C]
 // ---------------------------------------------------------------------------
 template <int RA, int RB>
-__global__ void __launch_bounds__(RL_THREADS)
+__global__ void __launch_bounds__(RL_THREADS2)
 k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
             cplx* __restrict__ T, Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1,
             const int* __restrict__ freq1, TwiddleL twl) {
@@ -137,7 +142,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
 // k2_cols_inv<RA, RB>: as k_cols_inv.  grid (tiles, D, npairs)
 // ---------------------------------------------------------------------------
 template <int RA, int RB>
-__global__ void __launch_bounds__(RL_THREADS)
+__global__ void __launch_bounds__(RL_THREADS2)
 k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, int m,
             Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1) {
     RL_SMEM(smem);
@@ -239,7 +244,7 @@ __device__ __forceinline__ void mix_point(cplx* z, const MixParams& mp, size_t L
 // (coalesced 16-byte elements); LDS passes with the column fastest.
 // ---------------------------------------------------------------------------
 template <int D, int RA, int RB>
-__global__ void __launch_bounds__(RL_THREADS)
+__global__ void __launch_bounds__(RL_THREADS2)
 k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restrict__ tw2,
             const int* __restrict__ freq1, TwiddleL twl, MixParams mp) {
     RL_SMEM(smem);

@@ -586,6 +586,15 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
         R *= 2;
     tp->R = R;
     tp->colsMagic = div_magic((unsigned)(R * g->D));
+    // 512 threads when LDS leaves room for only one or two workgroups per CU
+    // (big tiles: otherwise a CU would hold 4-8 waves) and the first pass has
+    // that many butterflies to hand out; measured on C5: 4.31 -> 3.89 ms
+    int thr_max = RL_THREADS2;
+    if (const char* e = getenv("RUNLMC_MAX_THREADS")) thr_max = std::max(256, atoi(e));
+    const size_t big = 48 * 1024;
+    tp->thrR = (lds(R) > big && R * g->D * sub >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
+    tp->thrC = ((size_t)g->N1 * C * sizeof(cplx) > big &&
+                (g->N1 / g->plan1.radix[0]) * C >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
     tp->pairs = (int)pairs;
     tp->tilesC = g->N2 / C;
     tp->tilesR = g->N1 / R;
@@ -597,7 +606,7 @@ static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
                              const double* X, int nv, int D, int mode) {
     dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * D));
-    RL_LAUNCH((k2_cols_fwd<RA, RB>), grid, dim3(RL_THREADS), (size_t)g->N1 * tp.C * sizeof(cplx),
+    RL_LAUNCH((k2_cols_fwd<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
               st, X, nv, D, g->m, mode, g->T, tp, g->plan1, g->tw1, g->freq1, g->twl);
 }
 template <int RA, int RB>
@@ -606,7 +615,7 @@ static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
     const int colsNeeded = std::min(g->m, g->N2);
     dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * g->D));
-    RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(RL_THREADS), (size_t)g->N1 * tp.C * sizeof(cplx),
+    RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
               st, g->T, Y, nv, g->D, g->m, tp, g->plan1, g->tw1);
 }
 template <int D, int RA, int RB>
@@ -615,7 +624,7 @@ static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
     const size_t lds = (size_t)g->N2 * ((tp.R * D) | 1) * sizeof(cplx);
-    RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(RL_THREADS), lds, st, g->T, tp, g->plan2,
+    RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->T, tp, g->plan2,
               g->tw2, g->freq1, g->twl, mp);
 }
 template <int D>
