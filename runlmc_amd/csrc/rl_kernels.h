@@ -301,3 +301,24 @@ k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
             Y[(size_t)(v0 + j) * nrows + row] = r;
         }
 }
+
+// ---------------------------------------------------------------------------
+// Row permutation of a batch of data-space vectors.
+//   gather : Y[v][i]       = X[v][perm[i]]
+//   scatter: Y[v][perm[i]] = X[v][i]
+// The SKI handle keeps its data points sorted by grid position internally
+// (interpolation rows of unsorted inputs gather from random grid positions:
+// one cache line per 8 useful bytes); callers keep their own order.
+//   grid (ceil(n / RL_THREADS), nvec)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(RL_THREADS)
+k_permute_rows(const double* __restrict__ X, double* __restrict__ Y,
+               const int* __restrict__ perm, int n, int scatter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t off = (size_t)blockIdx.y * n;
+    if (scatter)
+        Y[off + perm[i]] = X[off + i];
+    else
+        Y[off + i] = X[off + perm[i]];
+}

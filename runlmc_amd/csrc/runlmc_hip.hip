@@ -758,6 +758,14 @@ struct rl_ski {
     bool has_noise = false;
     double *G1 = nullptr, *G2 = nullptr;   // dev [cap][D*m] grid-side temporaries
     int cap = 0;
+    // Internal row order: data points sorted by grid position (W, WT and
+    // noise_diag above are stored in THAT order); perm[i] = caller's row of
+    // internal row i.  P1/P2: dev [pcap][n] staging for caller-order entry points.
+    bool permuted = false;
+    int* perm = nullptr;
+    std::vector<int> h_perm;
+    double *P1 = nullptr, *P2 = nullptr;
+    int pcap = 0;
     hipStream_t solver_stream = nullptr;   // capturable stream of rl_solve_batch
 };
 
@@ -768,7 +776,9 @@ static void launch_spmv(const int* indptr, const int* indices, const double* val
                         int ncols, int nvec, const double* X, double* Y, const double* diag,
                         const double* X2, hipStream_t st) {
     const unsigned gx = (nrows + RL_THREADS - 1) / RL_THREADS;
-    if ((size_t)nrows * nvec >= ((size_t)1 << 22)) {
+    static const int force_vb = getenv("RUNLMC_SPMV_VB") ? atoi(getenv("RUNLMC_SPMV_VB")) : 0;
+    const bool blocked = force_vb ? force_vb > 1 : (size_t)nrows * nvec >= ((size_t)1 << 22);
+    if (blocked) {
         RL_LAUNCH(k_spmv<8>, dim3(gx, (nvec + 7) / 8), dim3(RL_THREADS), 0, st, indptr, indices,
                   vals, nrows, ncols, nvec, X, Y, diag, X2);
     } else {
@@ -816,6 +826,52 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     s->ngrid = ngrid;
     const size_t nnz = W_indptr[n];
     int rc = RL_OK;
+    // sort the data points by the first grid point they touch
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    auto key = [&](int i) {
+        return W_indptr[i + 1] > W_indptr[i] ? W_indices[W_indptr[i]] : 0x7fffffff;
+    };
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key(a) < key(b); });
+    bool identity = true;
+    for (int i = 0; i < n && identity; ++i) identity = perm[i] == i;
+    if (getenv("RUNLMC_NO_SORT")) identity = true;
+    std::vector<int> wp_ptr, wp_idx, wtp_ptr, wtp_idx;
+    std::vector<double> wp_val, wtp_val;
+    if (!identity) {
+        s->permuted = true;
+        s->h_perm = perm;
+        std::vector<int> inv(n);
+        for (int i = 0; i < n; ++i) inv[perm[i]] = i;
+        wp_ptr.assign(n + 1, 0);
+        wp_idx.reserve(nnz);
+        wp_val.reserve(nnz);
+        for (int i = 0; i < n; ++i) {
+            const int r = perm[i];
+            for (int k = W_indptr[r]; k < W_indptr[r + 1]; ++k) {
+                wp_idx.push_back(W_indices[k]);
+                wp_val.push_back(W_data[k]);
+            }
+            wp_ptr[i + 1] = (int)wp_idx.size();
+        }
+        wtp_ptr.assign(WT_indptr, WT_indptr + ngrid + 1);
+        wtp_idx.resize(nnz);
+        wtp_val.resize(nnz);
+        std::vector<std::pair<int, double>> row;
+        for (int r = 0; r < ngrid; ++r) {
+            row.clear();
+            for (int k = WT_indptr[r]; k < WT_indptr[r + 1]; ++k)
+                row.emplace_back(inv[WT_indices[k]], WT_data[k]);
+            std::sort(row.begin(), row.end());
+            for (size_t j = 0; j < row.size(); ++j) {
+                wtp_idx[WT_indptr[r] + j] = row[j].first;
+                wtp_val[WT_indptr[r] + j] = row[j].second;
+            }
+        }
+        W_indptr = wp_ptr.data(); W_indices = wp_idx.data(); W_data = wp_val.data();
+        WT_indptr = wtp_ptr.data(); WT_indices = wtp_idx.data(); WT_data = wtp_val.data();
+        if ((rc = upload_raw((void**)&s->perm, perm.data(), (size_t)n * sizeof(int)))) return rc;
+    }
     if ((rc = upload_raw((void**)&s->W_indptr, W_indptr, (size_t)(n + 1) * sizeof(int)))) return rc;
     if ((rc = upload_raw((void**)&s->W_indices, W_indices, nnz * sizeof(int)))) return rc;
     if ((rc = upload_raw((void**)&s->W_data, W_data, nnz * sizeof(double)))) return rc;
@@ -833,7 +889,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     (void)hipSetDevice(s->g->device);
     if (s->solver_stream) (void)hipStreamDestroy(s->solver_stream);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
-                    s->WT_data, s->noise_diag, s->G1, s->G2};
+                    s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -850,6 +906,11 @@ extern "C" int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens)
     }
     if ((int)diag.size() != s->n)
         return fail(RL_EINVAL, "rl_ski_set_noise: sum(lens) != n");
+    if (s->permuted) {
+        std::vector<double> sorted(diag.size());
+        for (int i = 0; i < s->n; ++i) sorted[i] = diag[s->h_perm[i]];
+        diag.swap(sorted);
+    }
     RL_HIP(hipSetDevice(s->g->device));
     RL_HIP(hipMemcpy(s->noise_diag, diag.data(), diag.size() * sizeof(double),
                      hipMemcpyHostToDevice));
@@ -869,29 +930,71 @@ static int ski_reserve(rl_ski* s, int nvec) {
     return RL_OK;
 }
 
+static int ski_reserve_perm(rl_ski* s, int nvec) {
+    if (!s->permuted || nvec <= s->pcap) return RL_OK;
+    if (s->P1) RL_HIP(hipFree(s->P1));
+    if (s->P2) RL_HIP(hipFree(s->P2));
+    s->P1 = s->P2 = nullptr;
+    s->pcap = 0;
+    RL_HIP(hipMalloc((void**)&s->P1, (size_t)nvec * s->n * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&s->P2, (size_t)nvec * s->n * sizeof(double)));
+    s->pcap = nvec;
+    return RL_OK;
+}
+
+// caller order <-> internal (sorted) order
+static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int scatter,
+                         hipStream_t st) {
+    dim3 grid((s->n + RL_THREADS - 1) / RL_THREADS, nvec);
+    RL_LAUNCH(k_permute_rows, grid, dim3(RL_THREADS), 0, st, X, Y, (const int*)s->perm, s->n,
+              scatter);
+}
+
+// the three stages in INTERNAL row order
+static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st) {
+    launch_spmv(s->WT_indptr, s->WT_indices, s->WT_data, s->ngrid, s->n, nvec, Xp, G, nullptr,
+                nullptr, st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const double* diag,
+                     const double* X2p, hipStream_t st) {
+    launch_spmv(s->W_indptr, s->W_indices, s->W_data, s->n, s->ngrid, nvec, G, Yp, diag, X2p,
+                st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+// Yp = K~ Xp, both in internal row order (what the solver iterates on)
+static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st) {
+    RL_TRY(ski_reserve(s, nvec));
+    RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st));
+    RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st));
+    return ski_w_int(s, s->G2, Yp, nvec, s->has_noise ? s->noise_diag : nullptr, Xp, st);
+}
+
 extern "C" int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream) {
     if (!s || !X || !G) return fail(RL_EINVAL, "rl_ski_apply_wt: NULL argument");
     if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
     RL_HIP(hipSetDevice(s->g->device));
-    launch_spmv(s->WT_indptr, s->WT_indices, s->WT_data, s->ngrid, s->n, nvec, X, G, nullptr,
-                nullptr, (hipStream_t)stream);
-    RL_HIP(hipGetLastError());
-    return RL_OK;
-}
-
-static int ski_apply_w_impl(rl_ski* s, const double* G, double* Y, int nvec, const double* diag,
-                            const double* X2, hipStream_t stream) {
-    launch_spmv(s->W_indptr, s->W_indices, s->W_data, s->n, s->ngrid, nvec, G, Y, diag, X2,
-                stream);
-    RL_HIP(hipGetLastError());
-    return RL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->permuted) {
+        RL_TRY(ski_reserve_perm(s, nvec));
+        permute_rows(s, X, s->P1, nvec, 0, st);
+        X = s->P1;
+    }
+    return ski_wt_int(s, X, G, nvec, st);
 }
 
 extern "C" int rl_ski_apply_w(rl_ski* s, const double* G, double* Y, int nvec, void* stream) {
     if (!s || !G || !Y) return fail(RL_EINVAL, "rl_ski_apply_w: NULL argument");
     if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
     RL_HIP(hipSetDevice(s->g->device));
-    return ski_apply_w_impl(s, G, Y, nvec, nullptr, nullptr, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!s->permuted) return ski_w_int(s, G, Y, nvec, nullptr, nullptr, st);
+    RL_TRY(ski_reserve_perm(s, nvec));
+    RL_TRY(ski_w_int(s, G, s->P2, nvec, nullptr, nullptr, st));
+    permute_rows(s, s->P2, Y, nvec, 1, st);
+    return RL_OK;
 }
 
 extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void* stream) {
@@ -899,11 +1002,13 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
     if (X == Y) return fail(RL_EINVAL, "rl_ski_mvm: X and Y may not alias");
     if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
     RL_HIP(hipSetDevice(s->g->device));
-    RL_TRY(ski_reserve(s, nvec));
-    RL_TRY(rl_ski_apply_wt(s, X, s->G1, nvec, stream));
-    RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, stream));
-    return ski_apply_w_impl(s, s->G2, Y, nvec, s->has_noise ? s->noise_diag : nullptr, X,
-                            (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!s->permuted) return ski_mvm_int(s, X, Y, nvec, st);
+    RL_TRY(ski_reserve_perm(s, nvec));
+    permute_rows(s, X, s->P1, nvec, 0, st);
+    RL_TRY(ski_mvm_int(s, s->P1, s->P2, nvec, st));
+    permute_rows(s, s->P2, Y, nvec, 1, st);
+    return RL_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -912,7 +1017,8 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
 #include "rl_solver.h"
 
 struct SolverWork {
-    double* vec[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* vec[10] = {nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr};
     double* S[2] = {nullptr, nullptr};
     int* I = nullptr;
     double* part[3] = {nullptr, nullptr, nullptr};
@@ -966,7 +1072,7 @@ static int active_count(SolverWork& w, int nrhs, hipStream_t st, int* out) {
 static int residual_check(rl_ski* s, SolverWork& w, const double* B, const double* X,
                           double* scratch, int nrhs, int n, int nblk, double tol, int freeze,
                           hipStream_t st) {
-    RL_TRY(rl_ski_mvm(s, X, scratch, nrhs, st));
+    RL_TRY(ski_mvm_int(s, X, scratch, nrhs, st));
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
     RL_LAUNCH(k_resid_partial, grid, blk, red, st, B, (const double*)scratch, n, w.part[2]);
@@ -981,7 +1087,7 @@ static int minres_iteration(rl_ski* s, const MinresBufs& mb, SolverWork& w, int 
                             int nblk, double rtol, int maxiter, hipStream_t st) {
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
-    RL_TRY(rl_ski_mvm(s, mb.v, mb.q, nrhs, st));
+    RL_TRY(ski_mvm_int(s, mb.v, mb.q, nrhs, st));
     RL_LAUNCH(k_minres_a, grid, blk, red, st, mb, n, w.part[0]);
     RL_LAUNCH(k_minres_b, grid, blk, red, st, mb, n, (const double*)w.part[0], w.part[1]);
     RL_LAUNCH(k_minres_c, grid, blk, red, st, mb, n, (const double*)w.part[0],
@@ -1001,7 +1107,7 @@ static int cg_iteration(rl_ski* s, SolverWork& w, double* X, int nrhs, int n, in
               first, maxiter);
     RL_LAUNCH(k_cg_p, grid, blk, 0, st, p, (const double*)r, n, (const double*)w.S[0],
               (const int*)w.I);
-    RL_TRY(rl_ski_mvm(s, p, q, nrhs, st));
+    RL_TRY(ski_mvm_int(s, p, q, nrhs, st));
     RL_LAUNCH(k_dot_partial, grid, blk, red, st, (const double*)p, (const double*)q, n,
               w.part[0]);
     RL_LAUNCH(k_cg_update, grid, blk, red, st, X, r, (const double*)p, (const double*)q, n,
@@ -1076,14 +1182,24 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     int active = nrhs;
     int done = 0;          // iterations issued so far
 
-    RL_LAUNCH(k_dot_partial, grid, blk, red, st, B, B, n, w.part[0]);
+    // iterate in the handle's internal row order (data sorted by grid position)
+    const double* Bi = B;
+    double* Xi = X;
+    if (s->permuted) {
+        RL_HIP(hipMalloc((void**)&w.vec[8], (size_t)nrhs * n * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&w.vec[9], (size_t)nrhs * n * sizeof(double)));
+        permute_rows(s, B, w.vec[8], nrhs, 0, st);
+        Bi = w.vec[8];
+        Xi = w.vec[9];
+    }
+    RL_LAUNCH(k_dot_partial, grid, blk, red, st, Bi, Bi, n, w.part[0]);
     if (method == RL_MINRES) {
         MinresBufs mb;
         mb.tri[0] = w.vec[0]; mb.tri[1] = w.vec[1]; mb.tri[2] = w.vec[2];
         mb.w[0] = w.vec[3]; mb.w[1] = w.vec[4];
         mb.v = w.vec[5];
         mb.q = w.vec[6];
-        mb.x = X;
+        mb.x = Xi;
         mb.S[0] = w.S[0]; mb.S[1] = w.S[1];
         mb.I = w.I;
         mb.giter = w.count + 1;
@@ -1096,7 +1212,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             mb.lanczos = w.lanczos;
             mb.lanczos_cap = lanczos_cap;
         }
-        RL_LAUNCH(k_minres_init, grid, blk, 0, st, B, n, (const double*)w.part[0], mb);
+        RL_LAUNCH(k_minres_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], mb);
         RL_TRY(active_count(w, nrhs, st, &active));
         if (use_graph && active > 0) {
             RL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -1119,27 +1235,27 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             const bool check = check_every > 0 && done % check_every == 0;
             // the free slot of the rotating triple is scratch for the check
             if (check)
-                RL_TRY(residual_check(s, w, B, X, mb.q, nrhs, n, nblk, tol, 1, st));
+                RL_TRY(residual_check(s, w, Bi, Xi, mb.q, nrhs, n, nblk, tol, 1, st));
             if (check || guard.exec || done % 10 == 0)
                 RL_TRY(active_count(w, nrhs, st, &active));
         }
-        RL_TRY(residual_check(s, w, B, X, mb.q, nrhs, n, nblk, tol, 0, st));
+        RL_TRY(residual_check(s, w, Bi, Xi, mb.q, nrhs, n, nblk, tol, 0, st));
     } else {
         double *r = w.vec[0], *p = w.vec[1], *scratch = w.vec[3];
-        RL_LAUNCH(k_cg_init, grid, blk, 0, st, B, n, (const double*)w.part[0], X, r, p, w.S[0],
+        RL_LAUNCH(k_cg_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], Xi, r, p, w.S[0],
                   w.I, rtol);
         RL_TRY(active_count(w, nrhs, st, &active));
         // first iteration eagerly (its head skips the rho update), the rest from a graph
         if (active > 0) {
-            RL_TRY(cg_iteration(s, w, X, nrhs, n, nblk, 1, maxiter, st));
+            RL_TRY(cg_iteration(s, w, Xi, nrhs, n, nblk, 1, maxiter, st));
             done = 1;
             if (check_every == 1)
-                RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 1, st));
+                RL_TRY(residual_check(s, w, Bi, Xi, scratch, nrhs, n, nblk, tol, 1, st));
             RL_TRY(active_count(w, nrhs, st, &active));
         }
         if (use_graph && active > 0 && per_graph > 1) {
             RL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rc = cg_iteration(s, w, X, nrhs, n, nblk, 0, maxiter, st);
+            int rc = cg_iteration(s, w, Xi, nrhs, n, nblk, 0, maxiter, st);
             hipError_t e = hipStreamEndCapture(st, &guard.graph);
             if (rc != RL_OK) return rc;
             RL_HIP(e);
@@ -1149,16 +1265,17 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             if (guard.exec)
                 RL_HIP(hipGraphLaunch(guard.exec, st));
             else
-                RL_TRY(cg_iteration(s, w, X, nrhs, n, nblk, 0, maxiter, st));
+                RL_TRY(cg_iteration(s, w, Xi, nrhs, n, nblk, 0, maxiter, st));
             done += 1;
             const bool check = check_every > 0 && done % check_every == 0;
             if (check)
-                RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 1, st));
+                RL_TRY(residual_check(s, w, Bi, Xi, scratch, nrhs, n, nblk, tol, 1, st));
             if (check || done % 10 == 0 || done > maxiter)
                 RL_TRY(active_count(w, nrhs, st, &active));
         }
-        RL_TRY(residual_check(s, w, B, X, scratch, nrhs, n, nblk, tol, 0, st));
+        RL_TRY(residual_check(s, w, Bi, Xi, scratch, nrhs, n, nblk, tol, 0, st));
     }
+    if (s->permuted) permute_rows(s, Xi, X, nrhs, 1, st);
     RL_HIP(hipGetLastError());
     RL_HIP(hipStreamSynchronize(st));
     std::vector<int> hI((size_t)nrhs * I_NFIELDS);

@@ -456,3 +456,38 @@ def check_model_optimize(name='lmc_q1'):
     assert opt.n_iter == 5
     after = dense_ll()
     assert after > before, (before, after)
+
+
+def check_unsorted_inputs():
+    """Data points in arbitrary order (the reference benchmark's U(0,1) inputs):
+    the handle sorts them internally by grid position; every caller-order entry
+    point must be unaffected."""
+    from runlmc_amd.util import synth
+    from oracle.kernels import KernelSpec, RBFSpec
+    p = synth.make_problem(3, 2, 1, 60, seed=7)
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    skiop = K.device_operator()
+    spec = KernelSpec(p.D, [RBFSpec(g) for g in p.inv_lengthscales],
+                      list(p.coreg_vecs), list(p.coreg_diags), p.noise)
+    spec.set_input_dim(1)
+    op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    rng = np.random.RandomState(1)
+    X = rng.randn(3, p.n)
+    _close(K.matmat(X.T).T, np.array([op.matvec(v) for v in X]))
+    _close(gks[ad].matvec(X[0]), op.matvec(X[0]) - op.noise_diag * X[0])
+    dev = skiop.device
+    Xt = torch.from_numpy(X).to(dev)
+    _close(skiop.apply_wt(Xt).cpu().numpy(), np.array([p.WT.dot(v) for v in X]))
+    G = rng.randn(2, p.D * p.m)
+    _close(skiop.apply_w(torch.from_numpy(G).to(dev)).cpu().numpy(),
+           np.array([p.W.dot(v) for v in G]))
+    B = np.vstack([p.y, rng.randn(2, p.n)])
+    Xs, iters, resid = Iterative.solve(K, B, verbose=True, tol=1e-4)
+    for i in range(len(B)):
+        true_res = np.linalg.norm(B[i] - op.matvec(Xs[i]))
+        assert abs(true_res - resid[i]) <= 1e-9 + 1e-6 * true_res
+        xo, ito, erro, _ = iterative_solve(op.matvec, B[i], tol=1e-4)
+        assert abs(int(iters[i]) - ito) <= max(3, ito // 10)
+        _close(Xs[i], xo, rel=1e-4)

@@ -106,3 +106,7 @@ def test_embedding_lengths(D, Q, m, nvec):
     for v in range(nvec):
         ref = ops.grid_sum_matvec(Bs, toeps, X[v])
         assert np.abs(Y[v] - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_unsorted_inputs():
+    ps.check_unsorted_inputs()

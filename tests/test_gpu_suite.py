@@ -77,3 +77,7 @@ def test_model_prediction():
 
 def test_model_optimize():
     ps.check_model_optimize('lmc_q1')
+
+
+def test_unsorted_inputs():
+    ps.check_unsorted_inputs()
