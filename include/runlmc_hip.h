@@ -49,6 +49,12 @@ int rl_device_count(int* count);
  *   D outputs, m grid points (1-D grid), embedding length L = pow2 >= 2m
  *   (>= 16).  max_tops bounds Q in later rl_gridop_set_* calls.            */
 int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out);
+/* Same for a two-dimensional m1 x m2 grid: T_q is then a block-Toeplitz matrix
+ * of Toeplitz blocks, BTTB(top, (m1, m2)) (bttb.py:91-148 with two sizes; grid
+ * index i1*m2 + i2, top rows are k_q of the distances to grid point (0, 0)).
+ * The embedding is an N1 x N2 two-dimensional circulant, N_k = pow2 >= 2 m_k.
+ * Every other entry point is unchanged (m = m1*m2 points per output).        */
+int rl_gridop_create_2d(int device, int D, int m1, int m2, int max_tops, rl_gridop** out);
 int rl_gridop_destroy(rl_gridop* g);
 /* L = N1*N2 and tile parameters actually chosen (any pointer may be NULL). */
 int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int* rowsB);

@@ -57,3 +57,13 @@ def auto_grid_1d(Xs, m=None):
         m = sum(len(X) for X in Xs) // len(Xs)
     delta = (hi - lo) / m
     return np.linspace(lo - 2 * delta, hi + 2 * delta, int(m) + 4)
+
+
+def bicubic_rows(gridx, gridy, samples):
+    """Dense n x (mx*my) bicubic interpolation matrix: the tensor product of
+    the two 1-D cubic rows of each sample (reference interpolation.py:218-328:
+    interpolate along x at four grid rows, then along y); index ix*my + iy."""
+    samples = np.asarray(samples, dtype=np.float64)
+    Rx = cubic_rows(gridx, samples[:, 0])
+    Ry = cubic_rows(gridy, samples[:, 1])
+    return np.einsum('ni,nj->nij', Rx, Ry).reshape(len(samples), -1)

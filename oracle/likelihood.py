@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
 
-Scope: one active-dimension set, 1-D grid (the reference's C1-C5 workloads).
+Scope: one active-dimension set; 1-D grids (the reference's C1-C5 workloads)
+and N-D grids (BTTB kernels).
 """
 import numpy as np
 import scipy.linalg as la
@@ -32,10 +33,11 @@ class LMCOperatorOracle:
         self.W, self.WT = W, WT
         self.lens = list(lens)
         self.n = W.shape[0]
-        self.m = len(grid_dists)
-        self.sizes = (self.m,)
+        self.sizes = tuple(np.shape(grid_dists))
+        self.m = int(np.prod(self.sizes))
         self.ktype = ktype or choose_ktype(spec, active_dim)
-        self.tops = spec.eval_kernels_fixed_dim(grid_dists, active_dim)
+        self.tops = np.asarray(spec.eval_kernels_fixed_dim(grid_dists, active_dim)
+                               ).reshape(-1, self.m)
         self.Bs = spec.coreg_mats(active_dim)
         self.noise_diag = np.repeat(spec.noise, self.lens)
         if self.ktype == 'sum':
@@ -99,9 +101,9 @@ def stochastic_gradients(spec, grid_dists, W, WT, lens, alpha, rs, inv_rs,
     Returns dict(coreg_vec=[(R_q x D)]*Q, coreg_diag=[(D,)]*Q,
                  kernel=[[p_q floats]]*Q, noise=(D,))."""
     D, Q = spec.D, spec.Q
-    sizes = (len(grid_dists),)
+    sizes = tuple(np.shape(grid_dists))
     dists = {active_dim: grid_dists}
-    mats = [ops.BTTBOracle(k, sizes) for k in spec.eval_kernels(dists)]
+    mats = [ops.BTTBOracle(np.ravel(k), sizes) for k in spec.eval_kernels(dists)]
     dmats = spec.eval_kernel_gradients(dists)
 
     def ski_kron(B, toep):
@@ -132,7 +134,7 @@ def stochastic_gradients(spec, grid_dists, W, WT, lens, alpha, rs, inv_rs,
 
     g_kern = []
     for q, B in enumerate(spec.coreg_mats()):
-        g_kern.append([deriv(ski_kron(B, ops.BTTBOracle(dk, sizes)))
+        g_kern.append([deriv(ski_kron(B, ops.BTTBOracle(np.ravel(dk), sizes)))
                        for dk in dmats[q]])
 
     g_noise = np.zeros(D)

@@ -29,6 +29,7 @@ _d = ctypes.c_double
 _SIGNATURES = {
     'rl_device_count': [_c_int_p],
     'rl_gridop_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
+    'rl_gridop_create_2d': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
     'rl_gridop_destroy': [_vp],
     'rl_gridop_info': [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p],
     'rl_gridop_set_lmc': [_vp, _i, _vp, _vp, _vp, _vp],

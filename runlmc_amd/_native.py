@@ -34,14 +34,27 @@ def _vec_batch(lib, X, width, device):
 class GridOp:
     """Device handle of K_UU = sum_q B_q (x) T_q  (include/runlmc_hip.h)."""
 
-    def __init__(self, D, m, max_tops, device_index=0, lib=None):
+    def __init__(self, D, m, max_tops, device_index=0, lib=None, sizes=None):
+        """`m` grid points per output; `sizes=(m1, m2)` (m1*m2 == m) makes the
+        kernel matrices BTTB on a two-dimensional grid."""
         self.lib = lib or _lib.get_library()
         self.D, self.m, self.max_tops = int(D), int(m), int(max_tops)
         self.device = self.lib.torch_device(device_index)
         self.device_index = device_index
         self._h = ctypes.c_void_p()
-        self.lib.call('rl_gridop_create', device_index, self.D, self.m,
-                      self.max_tops, ctypes.byref(self._h))
+        self.sizes = None if sizes is None else tuple(int(v) for v in sizes)
+        if self.sizes is None or len(self.sizes) == 1:
+            self.lib.call('rl_gridop_create', device_index, self.D, self.m,
+                          self.max_tops, ctypes.byref(self._h))
+        elif len(self.sizes) == 2:
+            if self.sizes[0] * self.sizes[1] != self.m:
+                raise ValueError('sizes %s do not multiply to m = %d' % (self.sizes, self.m))
+            self.lib.call('rl_gridop_create_2d', device_index, self.D,
+                          self.sizes[0], self.sizes[1], self.max_tops,
+                          ctypes.byref(self._h))
+        else:
+            raise NotImplementedError(
+                'grids of more than two dimensions have no device path')
         info = [ctypes.c_int() for _ in range(5)]
         self.lib.call('rl_gridop_info', self._h, *[ctypes.byref(i) for i in info])
         self.L, self.N1, self.N2, self.colsA, self.rowsB = [i.value for i in info]

@@ -55,15 +55,56 @@ def interp_cubic(grid, samples):
     return M.tocsr()       # duplicates (clamped taps) are summed
 
 
+def interp_bicubic(gridx, gridy, samples):
+    """n x (mx*my) CSR matrix with 16 taps per row: cubic interpolation along
+    x at the four grid rows around each sample, then along y (reference
+    interpolation.py:218-328).  Grid index = ix * my + iy."""
+    gridx, gridy = np.asarray(gridx), np.asarray(gridy)
+    samples = np.asarray(samples)
+    mx, my = gridx.size, gridy.size
+    n = samples.shape[0]
+    if n == 0:
+        return scipy.sparse.csr_matrix((0, mx * my), dtype=float)
+    for name, grid in (('gridx', gridx), ('gridy', gridy)):
+        if grid.ndim != 1:
+            raise ValueError('{} dim {} should be 1'.format(name, grid.ndim))
+        if grid.size < 4:
+            raise ValueError('grid size {} must be >=4'.format(grid.size))
+    if samples.ndim != 2 or samples.shape[1] != 2:
+        raise ValueError('expecting 2d samples, got shape {}'.format(samples.shape))
+    for axis, grid in ((0, gridx), (1, gridy)):
+        col = samples[:, axis]
+        if col.min() <= grid[0] or col.max() >= grid[-1]:
+            _LOG.warning('%s range of samples [%f, %f] outside grid range [%f, %f]',
+                         'xy'[axis], col.min(), col.max(), grid[0], grid[-1])
+    shifts = np.array([-2, -1, 0, 1])
+
+    def taps(grid, coords):
+        pos = (coords - grid[0]) / (grid[1] - grid[0])
+        left = np.floor(pos)
+        idx = np.clip(left[:, None] - shifts[None, :], 0, len(grid) - 1).astype(np.int64)
+        return idx, cubic_kernel((pos - left)[:, None] + shifts[None, :])
+
+    ix, wx = taps(gridx, samples[:, 0])          # (n, 4) each
+    iy, wy = taps(gridy, samples[:, 1])
+    cols = (ix[:, :, None] * my + iy[:, None, :]).reshape(n, 16)
+    vals = (wx[:, :, None] * wy[:, None, :]).reshape(n, 16)
+    rows = np.repeat(np.arange(n), 16)
+    return scipy.sparse.coo_matrix((vals.ravel(), (rows, cols.ravel())),
+                                   shape=(n, mx * my)).tocsr()
+
+
 def multi_interpolant(Xs, *inducing_grids):
     """Block-diagonal interpolant over all outputs: (sum_d n_d) x (D m) CSR
     with int32 indices (reference interpolation.py:119-176)."""
     if Xs[0].ndim == 1 or Xs[0].shape[1] == 1:
         blocks = [interp_cubic(inducing_grids[0], np.asarray(X).ravel())
                   for X in Xs]
+    elif Xs[0].shape[1] == 2:
+        blocks = [interp_bicubic(inducing_grids[0], inducing_grids[1], np.asarray(X))
+                  for X in Xs]
     else:
-        raise NotImplementedError(
-            'bicubic (2-D input) interpolation is not part of this release')
+        raise NotImplementedError('inputs of more than two dimensions')
     W = scipy.sparse.block_diag(blocks, format='csr')
     W.sort_indices()
     W.indices = W.indices.astype(np.int32)

@@ -36,6 +36,33 @@ __device__ __forceinline__ cplx twiddle_L(const TwiddleL& t, int e) {
     return c_mul(t.lo[e & t.mask], t.hi[e >> t.shift]);
 }
 
+// Grid geometry.  1-D (m1 == 0): m points embedded in one length-L transform
+// that the kernels split N1 x N2 with an inter-step twiddle.  2-D (a BTTB of
+// Toeplitz blocks on an m1 x m2 grid, reference bttb.py:110-148 with two sizes):
+// the embedding is a genuine N1 x N2 two-dimensional transform -- same kernels,
+// zero padding / mirroring / cropping per axis, and NO inter-step twiddle
+// (TwiddleL.lo == NULL).
+struct Geom {
+    int m;        // points per output block (m1 * m2 in 2-D)
+    int m1, m2;   // 2-D grid sizes; m1 == 0 means 1-D
+};
+
+// index into the m-point block of padded position (n1, n2), or -1 for padding.
+// mode 1: symmetric circulant column of a top row (mirror per axis).
+__device__ __forceinline__ int padded_source(const Geom& g, int n1, int n2, int N1, int N2,
+                                             int mode) {
+    if (g.m1 == 0) {
+        const int n = n1 * N2 + n2;
+        if (n < g.m) return n;
+        if (mode == 1 && n > N1 * N2 - g.m) return N1 * N2 - n;
+        return -1;
+    }
+    int i1 = -1, i2 = -1;
+    if (n1 < g.m1) i1 = n1; else if (mode == 1 && n1 > N1 - g.m1) i1 = N1 - n1;
+    if (n2 < g.m2) i2 = n2; else if (mode == 1 && n2 > N2 - g.m2) i2 = N2 - n2;
+    return (i1 < 0 || i2 < 0) ? -1 : i1 * g.m2 + i2;
+}
+
 __device__ __forceinline__ void load_table(cplx* dst, const cplx* src, int n, int tid, int nthr) {
     for (int i = tid; i < n; i += nthr) dst[i] = src[i];
 }
@@ -50,7 +77,7 @@ __device__ __forceinline__ void load_table(cplx* dst, const cplx* src, int n, in
 // LDS: tile [N1][C] + twiddle table [N1]
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(RL_THREADS)
-k_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode, cplx* __restrict__ T,
+k_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode, cplx* __restrict__ T,
            int N1, int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1,
            const int* __restrict__ freq1, TwiddleL twl) {
     RL_SMEM(smem);
@@ -59,6 +86,7 @@ k_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode, cplx*
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int c0 = blockIdx.x * C, b = blockIdx.y, pair = blockIdx.z;
     const int L = N1 * N2;
+    const int m = geo.m;
     const int v0 = 2 * pair, v1 = 2 * pair + 1;
     const double* x0 = X + ((size_t)v0 * D + b) * m;
     const double* x1 = X + ((size_t)v1 * D + b) * m;
@@ -67,13 +95,8 @@ k_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode, cplx*
     load_table(tw, tw1, N1, tid, nthr);
     for (int idx = tid; idx < N1 * C; idx += nthr) {
         const int c = idx % C, n1 = idx / C;
-        const int n = n1 * N2 + c0 + c;
         double re = 0.0, im = 0.0;
-        int src = -1;
-        if (n < m)
-            src = n;
-        else if (mode == 1 && n > L - m)
-            src = L - n;
+        const int src = padded_source(geo, n1, c0 + c, N1, N2, mode);
         if (src >= 0) {
             re = x0[src];
             if (has1) im = x1[src];
@@ -87,8 +110,9 @@ k_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode, cplx*
     for (int idx = tid; idx < N1 * C; idx += nthr) {
         const int c = idx % C, r = idx / C;
         const int n2 = c0 + c;
-        const cplx w = twiddle_L(twl, freq1[r] * n2);
-        out[(size_t)r * N2 + n2] = c_mul(tile[idx], w);
+        cplx z = tile[idx];
+        if (twl.lo != nullptr) z = c_mul(z, twiddle_L(twl, freq1[r] * n2));
+        out[(size_t)r * N2 + n2] = z;
     }
 }
 
@@ -217,9 +241,9 @@ k_rows_mix(cplx* __restrict__ T, int N1, int N2, int R, FftPlan plan2,
     for (int idx = tid; idx < cols * N2; idx += nthr) {
         const int n2 = idx % N2, rb = idx / N2;
         const int rr = rb / D, b = rb % D;
-        const cplx w = twiddle_L(twl, freq1[r0 + rr] * n2);
-        base[(size_t)b * L + (size_t)(r0 + rr) * N2 + n2] =
-            c_mulc(tile[(size_t)n2 * CB + rb], w);
+        cplx z = tile[(size_t)n2 * CB + rb];
+        if (twl.lo != nullptr) z = c_mulc(z, twiddle_L(twl, freq1[r0 + rr] * n2));
+        base[(size_t)b * L + (size_t)(r0 + rr) * N2 + n2] = z;
     }
 }
 
@@ -229,7 +253,7 @@ k_rows_mix(cplx* __restrict__ T, int N1, int N2, int R, FftPlan plan2,
 //   Y [nvec][D][m];  beta == 0: Y = result, else Y += result
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(RL_THREADS)
-k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, int m, int N1,
+k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, Geom geo, int N1,
            int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1) {
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
@@ -247,17 +271,18 @@ k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, 
     __syncthreads();
     fft_tile_adjoint(tile, plan1, C, C, tw, tid, nthr);
 
+    const int m = geo.m;
     const int v0 = 2 * pair, v1 = 2 * pair + 1;
     double* y0 = Y + ((size_t)v0 * D + b) * m;
     double* y1 = Y + ((size_t)v1 * D + b) * m;
     const bool has1 = v1 < nvec;
     for (int idx = tid; idx < N1 * C; idx += nthr) {
         const int c = idx % C, n1 = idx / C;
-        const int n = n1 * N2 + c0 + c;
-        if (n < m) {
+        const int dst = padded_source(geo, n1, c0 + c, N1, N2, 0);
+        if (dst >= 0) {
             const cplx z = tile[idx];
-            y0[n] = z.x;
-            if (has1) y1[n] = z.y;
+            y0[dst] = z.x;
+            if (has1) y1[dst] = z.y;
         }
     }
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void middle_adjoint(cplx* tile, const FftPlan& plan, 
 // ---------------------------------------------------------------------------
 template <int RA, int RB>
 __global__ void __launch_bounds__(RL_THREADS2)
-k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
+k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
             cplx* __restrict__ T, Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1,
             const int* __restrict__ freq1, TwiddleL twl) {
     RL_SMEM(smem);
@@ -89,6 +89,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
     }
     const int c0 = ct * C;
     const int L = N1 * N2;
+    const int m = geo.m;
     const int v0 = 2 * pair, v1 = 2 * pair + 1;
     const double* x0 = X + ((size_t)v0 * D + b) * m;
     const double* x1 = X + ((size_t)v1 * D + b) * m;
@@ -100,12 +101,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
         cplx v[RA];
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int n = (j + sub * i) * N2 + c0 + c;
-            int src = -1;
-            if (n < m)
-                src = n;
-            else if (mode == 1 && n > L - m)
-                src = L - n;
+            const int src = padded_source(geo, j + sub * i, c0 + c, N1, N2, mode);
             double re = 0.0, im = 0.0;
             if (src >= 0) {
                 re = x0[src];
@@ -133,7 +129,9 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int r = g + k;
-            out[(size_t)r * N2 + n2] = c_mul(v[k], twiddle_L(twl, freq1[r] * n2));
+            cplx z = v[k];
+            if (twl.lo != nullptr) z = c_mul(z, twiddle_L(twl, freq1[r] * n2));
+            out[(size_t)r * N2 + n2] = z;
         }
     }
 }
@@ -143,7 +141,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, int m, int mode,
 // ---------------------------------------------------------------------------
 template <int RA, int RB>
 __global__ void __launch_bounds__(RL_THREADS2)
-k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, int m,
+k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, Geom geo,
             Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1) {
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
@@ -175,6 +173,7 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
 
     // adjoint of the first forward pass, straight into the cropped output
     const int sub = N1 / RA;
+    const int m = geo.m;
     const int v0 = 2 * pair, v1 = 2 * pair + 1;
     double* y0 = Y + ((size_t)v0 * D + b) * m;
     double* y1 = Y + ((size_t)v1 * D + b) * m;
@@ -182,7 +181,8 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
     // rows n1 >= ceil((m - c0) / N2) of this tile are cropped away entirely
     for (int w = tid; w < sub * C; w += nthr) {
         const int c = w & (C - 1), j = w >> tp.logC;
-        if (j * N2 + c0 + c >= m) continue;          // even the first leg is outside
+        // even the first leg (the smallest row index) is cropped away
+        if (padded_source(geo, j, c0 + c, N1, N2, 0) < 0) continue;
         cplx v[RA];
 #pragma unroll
         for (int k = 0; k < RA; ++k) v[k] = tile[(size_t)(j + sub * k) * C + c];
@@ -191,10 +191,10 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
         SmallDft<RA, true>::run(v);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int n = (j + sub * i) * N2 + c0 + c;
-            if (n < m) {
-                y0[n] = v[i].x;
-                if (has1) y1[n] = v[i].y;
+            const int dst = padded_source(geo, j + sub * i, c0 + c, N1, N2, 0);
+            if (dst >= 0) {
+                y0[dst] = v[i].x;
+                if (has1) y1[dst] = v[i].y;
             }
         }
     }
@@ -308,7 +308,9 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int n2 = j + sub * i;
-            dst[n2] = c_mulc(v[i], twiddle_L(twl, k1 * n2));
+            cplx z = v[i];
+            if (twl.lo != nullptr) z = c_mulc(z, twiddle_L(twl, k1 * n2));
+            dst[n2] = z;
         }
     }
 }

@@ -192,6 +192,7 @@ static const size_t kLdsHard = 156 * 1024;   // one workgroup per CU (160 KiB LD
 struct rl_gridop {
     int device = 0;
     int D = 0, m = 0, L = 0, N1 = 0, N2 = 0;
+    Geom geo{0, 0, 0};   // m1 == 0: 1-D grid; else an m1 x m2 grid (2-D BTTB)
     int colsA = 0;   // columns per k_cols_* workgroup
     int rowsB = 0;   // rows per k_rows_mix workgroup
     int rowsS = 0;   // rows per k_rows_spec workgroup
@@ -285,7 +286,25 @@ static void set_lds_attrs() {
 
 #define RL_MAX_D 16
 
+static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_tops,
+                              rl_gridop** out);
+
 extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out) {
+    return gridop_create_impl(device, D, m, 0, 0, max_tops, out);
+}
+
+extern "C" int rl_gridop_create_2d(int device, int D, int m1, int m2, int max_tops,
+                                   rl_gridop** out) {
+    if (m1 < 1 || m2 < 1) {
+        if (out) *out = nullptr;
+        return fail(RL_EINVAL, "rl_gridop_create_2d: m1, m2 must be >= 1");
+    }
+    if ((long)m1 * m2 > (1L << 27)) return fail(RL_ELIMIT, "rl_gridop_create_2d: grid too large");
+    return gridop_create_impl(device, D, m1 * m2, m1, m2, max_tops, out);
+}
+
+static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_tops,
+                              rl_gridop** out) {
     if (!out) return fail(RL_EINVAL, "out is NULL");
     *out = nullptr;
     if (D < 1 || m < 1 || max_tops < 1)
@@ -302,7 +321,18 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     g->m = m;
     g->max_tops = max_tops;
     int L;
-    choose_length(m, &L, &g->N1, &g->N2);
+    g->geo = Geom{m, m1, m2};
+    if (m1 == 0) {
+        choose_length(m, &L, &g->N1, &g->N2);
+    } else {
+        // 2-D: one circulant embedding per axis (reference bttb.py:112: next
+        // power of two of twice each size), floored at 4
+        g->N1 = 4;
+        while (g->N1 < 2 * m1) g->N1 *= 2;
+        g->N2 = 4;
+        while (g->N2 < 2 * m2) g->N2 *= 2;
+        L = g->N1 * g->N2;
+    }
     g->L = L;
     const int l = ilog2(L);
     // rows per (first-generation) row workgroup: the largest divisor of N1 that
@@ -322,7 +352,10 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
         int R = pick_rows(D);
         if (R == 0 && lds_rows(g->N2, D) <= kLdsHard) R = 1;
         if (R > 0) { g->rowsB = R; break; }
-        if (g->N2 <= 4) { delete g; return fail(RL_ELIMIT, "rl_gridop_create: D*L exceeds LDS"); }
+        if (g->N2 <= 4 || m1 != 0) {
+            delete g;
+            return fail(RL_ELIMIT, "rl_gridop_create: D * row length exceeds LDS");
+        }
         g->N2 /= 2;
         g->N1 *= 2;
     }
@@ -357,7 +390,7 @@ extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_grido
     if ((rc = upload(&g->twhi, unity_table(((long)L + (1L << shift) - 1) >> shift, 1L << shift,
                                            L))) != RL_OK) return rc;
     if ((rc = upload(&g->freq1, g->h_freq1)) != RL_OK) return rc;
-    g->twl.lo = g->twlo;
+    g->twl.lo = m1 == 0 ? g->twlo : nullptr;   // 2-D: no inter-step twiddle
     g->twl.hi = g->twhi;
     g->twl.shift = shift;
     g->twl.mask = (1 << shift) - 1;
@@ -420,7 +453,7 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     const size_t need = ((size_t)npairs + g->D - 1) / g->D;
     RL_TRY(ensure_workspace(g, std::max<size_t>(need, 1)));
     dim3 gridA(g->N2 / g->colsA, 1, npairs);
-    RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, g->tops, ntop, 1, g->m,
+    RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, g->tops, ntop, 1, g->geo,
               1, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);
     dim3 gridS(g->N1 / g->rowsS, npairs);
     RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
@@ -607,16 +640,16 @@ static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
     dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * D));
     RL_LAUNCH((k2_cols_fwd<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
-              st, X, nv, D, g->m, mode, g->T, tp, g->plan1, g->tw1, g->freq1, g->twl);
+              st, X, nv, D, g->geo, mode, g->T, tp, g->plan1, g->tw1, g->freq1, g->twl);
 }
 template <int RA, int RB>
 static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                              double* Y, int nv) {
-    const int colsNeeded = std::min(g->m, g->N2);
+    const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
     dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * g->D));
     RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
-              st, g->T, Y, nv, g->D, g->m, tp, g->plan1, g->tw1);
+              st, g->T, Y, nv, g->D, g->geo, tp, g->plan1, g->tw1);
 }
 template <int D, int RA, int RB>
 static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
@@ -684,7 +717,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (g->v2 && g->xcd_pairs > 0 && total_pairs >= 16) chunk = std::min(chunk, g->xcd_pairs);
     RL_TRY(ensure_workspace(g, chunk));
     const size_t vec_len = (size_t)g->D * g->m;
-    const int colsNeeded = std::min(g->m, g->N2);
+    const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
     const unsigned tilesInv = (colsNeeded + g->colsA - 1) / g->colsA;
     for (size_t p0 = 0; p0 < total_pairs; p0 += chunk) {
         const size_t pairs = std::min(chunk, total_pairs - p0);
@@ -697,7 +730,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
             continue;
         }
         dim3 gridA(g->N2 / g->colsA, g->D, (unsigned)pairs);
-        RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, Xc, nv, g->D, g->m,
+        RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, Xc, nv, g->D, g->geo,
                   0, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);
         switch (g->D) {
 #define RL_CASE(d) case d: launch_rows_mix<d>(g, pairs, stream, mp); break;
@@ -709,7 +742,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         }
         dim3 gridI(tilesInv, g->D, (unsigned)pairs);
         RL_LAUNCH(k_cols_inv, gridI, dim3(RL_THREADS), lds_cols(g), stream, g->T, Yc, nv, g->D,
-                  g->m, g->N1, g->N2, g->colsA, g->plan1, g->tw1);
+                  g->geo, g->N1, g->N2, g->colsA, g->plan1, g->tw1);
     }
     RL_HIP(hipGetLastError());
     return RL_OK;
@@ -738,9 +771,13 @@ extern "C" int rl_gridop_spectrum_host(rl_gridop* g, int q, double* out) {
     RL_HIP(hipMemcpy(scr.data(), g->spec + (size_t)q * g->L, (size_t)g->L * sizeof(double),
                      hipMemcpyDeviceToHost));
     for (int r = 0; r < g->N1; ++r)
-        for (int c = 0; c < g->N2; ++c)
-            out[g->h_freq1[r] + (size_t)g->N1 * g->h_freq2[c]] =
-                scr[(size_t)r * g->N2 + c] * (double)g->L;
+        for (int c = 0; c < g->N2; ++c) {
+            // 1-D: frequency k1 + N1 k2 of the length-L transform;
+            // 2-D: entry (k1, k2) of the N1 x N2 transform, row-major
+            const size_t k = g->geo.m1 ? (size_t)g->h_freq1[r] * g->N2 + g->h_freq2[c]
+                                       : g->h_freq1[r] + (size_t)g->N1 * g->h_freq2[c];
+            out[k] = scr[(size_t)r * g->N2 + c] * (double)g->L;
+        }
     return RL_OK;
 }
 

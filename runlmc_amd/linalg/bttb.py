@@ -5,8 +5,10 @@ its spectrum and pad->FFT->multiply->IFFT->crop all happen in the HIP library
 (rl_gridop_* with D = 1, B = [[1]]).  The embedding length is the reference's
 ``next pow2 >= 2m`` (bttb.py:16-19), floored at 16.
 
-Only 1-D grids (``len(sizes) == 1``) have a device path in this round;
-higher-dimensional BTTB raises NotImplementedError.
+One- and two-dimensional grids have a device path (a 2-D BTTB is embedded in a
+two-dimensional circulant, one power-of-two length per axis, exactly as the
+reference's rfftn over ``sizes``); three or more dimensions raise
+NotImplementedError.
 """
 import numpy as np
 
@@ -38,15 +40,15 @@ class BTTB(Matrix):
         # unsafe casts (e.g. complex) raise TypeError, as in the reference
         self.top = top.astype('float64', casting='safe')
         self._sizes = tuple(int(s) for s in sizes)
-        if len(self._sizes) != 1:
+        if len(self._sizes) > 2:
             raise NotImplementedError(
-                'device BTTB supports 1-D grids only in this release; got '
-                'sizes {}'.format(self._sizes))
+                'device BTTB supports 1-D and 2-D grids; got sizes {}'
+                .format(self._sizes))
         self._dev = None
 
     def _device_op(self):
         if self._dev is None:
-            op = GridOp(1, self.top.size, 1)
+            op = GridOp(1, self.top.size, 1, sizes=self._sizes)
             op.set_dense(self.top.reshape(1, -1), np.ones((1, 1, 1)))
             self._dev = op
         return self._dev

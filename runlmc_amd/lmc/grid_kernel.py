@@ -94,13 +94,15 @@ class GridKernel(Matrix):
         self.active_dim = active_dim
         fk = functional_kernel
         grid_dists = np.asarray(grid_dists)
-        if grid_dists.ndim != 1:
+        if grid_dists.ndim > 2:
             raise NotImplementedError(
-                'device GridKernel supports 1-D grids only in this release')
-        tops = as_f64(fk.eval_kernels_fixed_dim(grid_dists, active_dim))
+                'device GridKernel supports 1-D and 2-D grids')
         kidx = fk.active_dims[active_dim]
+        tops = as_f64(fk.eval_kernels_fixed_dim(grid_dists, active_dim)
+                      ).reshape(len(kidx), -1)
         self._m = tops.shape[1]
-        self._op = GridOp(fk.D, self._m, len(kidx), device_index=device_index)
+        self._op = GridOp(fk.D, self._m, len(kidx), device_index=device_index,
+                          sizes=grid_dists.shape)
         self._op.set_lmc(tops, [fk.coreg_vecs[q] for q in kidx],
                          [fk.coreg_diags[q] for q in kidx])
         self._skiop = SkiOp(self._op, interpolant, interpolantT)
@@ -113,7 +115,7 @@ class GridKernel(Matrix):
         fk = functional_kernel
         kidx = fk.active_dims[self.active_dim]
         tops = as_f64(fk.eval_kernels_fixed_dim(np.asarray(grid_dists),
-                                                self.active_dim))
+                                                self.active_dim)).reshape(len(kidx), -1)
         self._op.set_lmc(tops, [fk.coreg_vecs[q] for q in kidx],
                          [fk.coreg_diags[q] for q in kidx])
 

@@ -55,13 +55,13 @@ class LMCLikelihood:
 _GRAD_OPS = {}
 
 
-def _grad_operator(D, m, ntops, device_index):
+def _grad_operator(D, m, ntops, device_index, sizes=None):
     """Top-row-only operators are parameter free apart from their spectra, so
-    one handle per shape is reused across optimiser steps."""
-    key = (D, m, device_index)
+    one handle per grid shape is reused across optimiser steps."""
+    key = (D, m, device_index, sizes)
     op = _GRAD_OPS.get(key)
     if op is None or op.max_tops < ntops:
-        op = GridOp(D, m, ntops, device_index=device_index)
+        op = GridOp(D, m, ntops, device_index=device_index, sizes=sizes)
         _GRAD_OPS[key] = op
     return op
 
@@ -117,7 +117,8 @@ class ApproxLMCLikelihood(LMCLikelihood):
         flat_tops = tops + [g for gl in dtops for g in gl]
         ntops = len(flat_tops)
         m = flat_tops[0].shape[0]
-        gop = _grad_operator(D, m, ntops, skiop.grid.device_index)
+        gop = _grad_operator(D, m, ntops, skiop.grid.device_index,
+                             sizes=skiop.grid.sizes)
         gop.set_lmc(np.stack(flat_tops), [None] * ntops,
                     [np.zeros(D)] * ntops)
 

@@ -10,6 +10,7 @@ Every product, solve and gradient inside runs on the device
 * ``log_det_K()`` is the matrix-free stochastic-Lanczos estimate of
   log det K~ (the reference's is a dense Cholesky of the exact kernel and is
   never on its optimiser path, interpolated_llgp.py:262-276).
+* inputs of one or two dimensions (bicubic interpolation, BTTB kernels);
 * prediction modes: 'on-the-fly' and 'precompute' (both batched solves on the
   device); 'exact' (dense Cholesky) is not provided.
 * parameters live in one flat array in the optimiser's space; positive
@@ -76,9 +77,10 @@ class InterpolatedLLGP:
         self.prediction = prediction
         self._functional_kernel = functional_kernel
         self._functional_kernel.set_input_dim(self.input_dim)
-        if self.input_dim != 1 or len(functional_kernel.active_dims) != 1:
+        if self.input_dim > 2 or len(functional_kernel.active_dims) != 1:
             raise NotImplementedError(
-                'this release handles 1-D inputs with one active-dimension set')
+                'this release handles 1-D and 2-D inputs with one '
+                'active-dimension set')
         self.y = np.hstack(self.Ys)
         self.kernel = None
         self.dists, self.interpolants, self.grid_axes = {}, {}, {}
@@ -114,8 +116,11 @@ class InterpolatedLLGP:
         for ad in self._functional_kernel.active_dims:
             Xs = [X[:, list(ad)] for X in self.Xs]
             self.grid_axes[ad] = autogrid(Xs, wrap(lo), wrap(hi), wrap(m))
-            grid = self.grid_axes[ad][0]
-            self.dists[ad] = np.abs(grid - grid[0])
+            axes = self.grid_axes[ad]
+            # distance of every grid point to grid point 0, shaped like the
+            # grid (interpolated_llgp.py:425-432)
+            mesh = np.meshgrid(*[a - a[0] for a in axes], indexing='ij')
+            self.dists[ad] = np.sqrt(sum(np.square(g) for g in mesh))
             W = multi_interpolant(Xs, *self.grid_axes[ad])
             WT = W.transpose().tocsr()
             WT.sort_indices()

@@ -38,6 +38,8 @@ class Case:
         self.D, self.Q, self.m = int(g['D']), int(g['Q']), int(g['m'])
         self.num_lmc = int(g['num_lmc']) if 'num_lmc' in g else self.Q
         self.num_slfm = int(g['num_slfm']) if 'num_slfm' in g else 0
+        self.P = int(g['P']) if 'P' in g else 1          # input dimension
+        self.ad = tuple(range(self.P))                   # active-dimension key
         self.lens = [int(v) for v in g['lens']]
         self.n = sum(self.lens)
         self.grid_dists = g['grid_dists']
@@ -53,6 +55,8 @@ class Case:
             (g['WT_data'], g['WT_indices'], g['WT_indptr']),
             shape=(self.D * self.m, self.n))
         self.Xs = [g[f'X{d}'] for d in range(self.D)]
+        self.grid_axes = ([g['axis_x'], g['axis_y']] if self.P == 2 else
+                          ([g['grid']] if 'grid' in g else None))
         self.Ys = np.split(self.y, np.cumsum(self.lens)[:-1])
         self.rs = g['rs']
         self.tops = g['tops']
@@ -61,7 +65,7 @@ class Case:
         sp = KernelSpec(self.D, [kernel_from_desc(k) for k in self.kdesc],
                         self.coreg_vecs, self.coreg_diags, self.noise,
                         num_lmc=self.num_lmc, num_slfm=self.num_slfm)
-        sp.set_input_dim(1)
+        sp.set_input_dim(self.P)
         return sp
 
     def dtops(self):
@@ -70,7 +74,7 @@ class Case:
                 for q in range(self.Q)]
 
 
-ALL_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid']
-DENSE_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1']
+ALL_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid', 'lmc_2d']
+DENSE_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_2d']
 # the reference's real-data workloads (BASELINE configs 3 and 4)
 DATASET_CASES = ['fx2007', 'weather']

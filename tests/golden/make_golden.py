@@ -339,10 +339,13 @@ def gen_lmc():
 
 
 def _main():
+    if '--2d-only' in sys.argv:
+        return gen_2d()
     if '--datasets-only' not in sys.argv:
         gen_linalg()
         gen_interp()
         gen_lmc()
+        gen_2d()
     gen_datasets()
 
 
@@ -509,6 +512,99 @@ def gen_datasets():
     _dataset_case('weather', 22, xss, _normalise(yss), 500, lmc=[], lmc_ranks=[],
                   slfm=[('rbf', 1.0), ('rbf', 1.0)],
                   indep=[('scaled_rbf', 1.0, 1.0)] * 4, n_probes=2, dense=False)
+
+
+
+
+# ---------------------------------------------------------------------------
+# 5. Two-dimensional inputs: BTTB kernel matrices on an m1 x m2 grid, bicubic
+#    interpolation (reference bttb.py:110-148, interpolation.py:218-328,
+#    models/interpolated_llgp.py:415-443 for the grid / distance construction)
+# ---------------------------------------------------------------------------
+def gen_2d():
+    from runlmc.approx.interpolation import interp_bicubic
+    from runlmc.util.numpy_convenience import cartesian_product
+    rng = np.random.RandomState(31)
+    D, lens, mreq = 2, [60, 45], [6.0, 7.0]
+    kdescs = [('rbf', 3.0), ('matern', 2.0)]
+    ranks = [1, 2]
+    Q = len(kdescs)
+    coreg_vecs = [rng.uniform(-1, 1, size=(r, D)) for r in ranks]
+    coreg_diags = [1.0 / rng.gamma(2.0, 1.0, size=D) for _ in range(Q)]
+    noise = 0.1 * (0.5 + rng.rand(D))
+    Xs = [rng.rand(n, 2) for n in lens]
+    Ys = [np.sin(4 * X[:, 0] + d) * np.cos(3 * X[:, 1]) + 0.1 * rng.randn(len(X))
+          for d, X in enumerate(Xs)]
+    y = np.hstack(Ys)
+    n = sum(lens)
+    axes = autogrid(Xs, lo=None, hi=None, m=np.array(mreq))
+    grid = cartesian_product(*axes)
+    shape = [len(a) for a in axes]
+    dists = la.norm(grid.reshape(shape + [2]) - grid[0], axis=-1)     # (m1, m2)
+    W = multi_interpolant(Xs, *axes)
+    WT = W.transpose().tocsr()
+    ad = (0, 1)
+    spec = KernelSpec(D, [_kernel_from_desc(k) for k in kdescs], coreg_vecs,
+                      coreg_diags, noise)
+    spec.set_input_dim(2)
+    out = dict(D=D, Q=Q, P=2, ranks=np.array(ranks), lens=np.array(lens),
+               m=int(np.prod(shape)), sizes=np.array(shape), axis_x=axes[0],
+               axis_y=axes[1], grid_dists=dists, noise=noise, y=y,
+               kdesc=np.array([';'.join(str(v) for v in k) for k in kdescs]),
+               W_indptr=W.indptr, W_indices=W.indices, W_data=W.data,
+               WT_indptr=WT.indptr, WT_indices=WT.indices, WT_data=WT.data)
+    for q in range(Q):
+        out[f'A{q}'] = coreg_vecs[q]
+        out[f'kappa{q}'] = coreg_diags[q]
+    for d in range(D):
+        out[f'X{d}'] = Xs[d]
+    tops = spec.eval_kernels_fixed_dim(dists, ad)
+    out['tops'] = tops.reshape(Q, -1)
+    dt = spec.eval_kernel_gradients({ad: dists})
+    out['dtops_count'] = np.array([len(g) for g in dt])
+    for q, gl in enumerate(dt):
+        for p_, g in enumerate(gl):
+            out[f'dtop{q}_{p_}'] = np.ravel(g)
+    gx = rng.randn(3, D * out['m'])
+    out['grid_x'] = gx
+    for kt in ('sum', 'bt', 'slfm'):
+        gk = GridKernel(spec, dists, W, WT, kt, ad)
+        out[f'grid_mv_{kt}'] = np.array([gk.grid_K.matvec(v) for v in gx])
+    K, _ = gen_grid_kernel(spec, {ad: dists}, {ad: (W, WT)}, lens)
+    xx = rng.randn(3, n)
+    out['full_x'] = xx
+    out['full_mv'] = np.array([K.matvec(v) for v in xx])
+    rs = rng.randint(0, 2, (6, n)) * 2 - 1
+    out['rs'] = rs
+    Kd = K.as_numpy()
+    Kd = 0.5 * (Kd + Kd.T)
+    out['K_dense'] = Kd
+    c = la.cho_factor(Kd)
+    alpha = la.cho_solve(c, y)
+    inv_rs = la.cho_solve(c, rs.T.astype(float)).T
+    out['alpha_dense'], out['inv_rs_dense'] = alpha, inv_rs
+    out['logdet_dense'] = 2 * np.sum(np.log(np.diag(c[0])))
+
+    class _FixedDeriv:
+        def generate(self, K_, y_):
+            return StochasticDeriv(alpha, rs, inv_rs, len(rs))
+
+    lik = ApproxLMCLikelihood(spec, K, {ad: dists}, {ad: (W, WT)}, Ys, _FixedDeriv())
+    gv, gd = lik.coreg_vec_gradients(), lik.coreg_diags_gradients()
+    gkk, gn = lik.kernel_gradients(), lik.noise_gradient()
+    for q in range(Q):
+        out[f'grad_A{q}'], out[f'grad_kappa{q}'] = gv[q], gd[q]
+        out[f'grad_kern{q}'] = np.array(gkk[q])
+    out['grad_noise'] = gn
+    sols = [Iterative.solve(K, rhs, verbose=True, minres=True, tol=1e-4)
+            for rhs in [y] + [r.astype(float) for r in rs[:2]]]
+    out['ref_minres_x'] = np.array([s[0] for s in sols])
+    out['ref_minres_iters'] = np.array([s[1] for s in sols])
+    out['ref_minres_err'] = np.array([s[2] for s in sols])
+    s0 = Iterative.solve(K, y, verbose=True, minres=False, tol=1e-4)
+    out['ref_cg_x'], out['ref_cg_iters'], out['ref_cg_err'] = (
+        np.array([s0[0]]), np.array([s0[1]]), np.array([s0[2]]))
+    _save('lmc_2d.npz', **out)
 
 
 if __name__ == '__main__':

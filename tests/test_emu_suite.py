@@ -38,12 +38,12 @@ def test_small_algebra():
 
 
 @pytest.mark.parametrize('name', ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid',
-                                  'fx2007', 'weather'])
+                                  'lmc_2d', 'fx2007', 'weather'])
 def test_lmc_operator(name):
     ps.check_lmc_operator(name)
 
 
-@pytest.mark.parametrize('name', ['lmc_small', 'lmc_q1'])
+@pytest.mark.parametrize('name', ['lmc_small', 'lmc_q1', 'lmc_2d'])
 def test_solver_minres(name):
     ps.check_solver(name, minres=True)
 
@@ -70,8 +70,9 @@ def test_logdet_slq(name):
     ps.check_logdet_slq(name)
 
 
-def test_model_prediction():
-    ps.check_model_prediction('lmc_small')
+@pytest.mark.parametrize('name', ['lmc_small', 'lmc_2d'])
+def test_model_prediction(name):
+    ps.check_model_prediction(name)
 
 
 def test_model_optimize():

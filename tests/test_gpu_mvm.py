@@ -87,7 +87,7 @@ def test_golden_operator(native, name):
     representations agree) and the full SKI operator."""
     from runlmc_amd._native import GridOp, SkiOp
     c = Case(name)
-    g = GridOp(c.D, c.m, c.Q)
+    g = GridOp(c.D, c.m, c.Q, sizes=np.shape(c.grid_dists))
     g.set_lmc(c.tops, c.coreg_vecs, c.coreg_diags)
     Y = g.matmat_host(c.g['grid_x'])
     for kt in ('sum', 'bt', 'slfm'):

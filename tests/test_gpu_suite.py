@@ -71,8 +71,9 @@ def test_logdet_slq(name):
     ps.check_logdet_slq(name)
 
 
-def test_model_prediction():
-    ps.check_model_prediction('lmc_small')
+@pytest.mark.parametrize('name', ['lmc_small', 'lmc_2d'])
+def test_model_prediction(name):
+    ps.check_model_prediction(name)
 
 
 def test_model_optimize():

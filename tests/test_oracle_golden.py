@@ -110,18 +110,19 @@ def test_lmc_operator(name):
     c = Case(name)
     spec = c.spec()
     np.testing.assert_allclose(
-        spec.eval_kernels_fixed_dim(c.grid_dists, (0,)), c.g['tops'], **TIGHT)
-    for q, gl in enumerate(spec.eval_kernel_gradients({(0,): c.grid_dists})):
+        np.reshape(spec.eval_kernels_fixed_dim(c.grid_dists, c.ad), (c.Q, -1)),
+        c.g['tops'], **TIGHT)
+    for q, gl in enumerate(spec.eval_kernel_gradients({c.ad: c.grid_dists})):
         for p, gq in enumerate(gl):
-            np.testing.assert_allclose(gq, c.g[f'dtop{q}_{p}'], **TIGHT)
+            np.testing.assert_allclose(np.ravel(gq), c.g[f'dtop{q}_{p}'], **TIGHT)
     for kt in ('sum', 'bt', 'slfm'):
         op = lik.LMCOperatorOracle(spec, c.grid_dists, c.W, c.WT, c.lens,
-                                   ktype=kt)
+                                   ktype=kt, active_dim=c.ad)
         got = np.array([op.grid_matvec(v) for v in c.g['grid_x']])
         ref = c.g[f'grid_mv_{kt}']
         scale = np.abs(ref).max()
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * scale)
-    op = lik.LMCOperatorOracle(spec, c.grid_dists, c.W, c.WT, c.lens)
+    op = lik.LMCOperatorOracle(spec, c.grid_dists, c.W, c.WT, c.lens, active_dim=c.ad)
     got = np.array([op.matvec(v) for v in c.g['full_x']])
     ref = c.g['full_mv']
     np.testing.assert_allclose(got, ref, rtol=0,
@@ -145,7 +146,7 @@ def test_gradients_fixed_probes(name):
     c = Case(name)
     g = lik.stochastic_gradients(c.spec(), c.grid_dists, c.W, c.WT, c.lens,
                                  c.g['alpha_dense'], c.rs,
-                                 c.g['inv_rs_dense'])
+                                 c.g['inv_rs_dense'], active_dim=c.ad)
     for q in range(c.Q):
         for mine, key in ((g['coreg_vec'][q], f'grad_A{q}'),
                           (g['coreg_diag'][q], f'grad_kappa{q}'),
@@ -162,7 +163,8 @@ def test_reference_solver_wrapper(name):
     """The reference's Iterative.solve iterates, iteration counts and
     residuals (SciPy under it) vs the oracle's restated MINRES/CG."""
     c = Case(name)
-    op = lik.LMCOperatorOracle(c.spec(), c.grid_dists, c.W, c.WT, c.lens)
+    op = lik.LMCOperatorOracle(c.spec(), c.grid_dists, c.W, c.WT, c.lens,
+                               active_dim=c.ad)
     rhs = [c.y] + [r.astype(float) for r in c.rs[:2]]
     for i, b in enumerate(rhs):
         x, it, err, _ = iterative_solve(op.matvec, b, tol=1e-4, minres=True)
