@@ -303,11 +303,15 @@ def main():
     if not args.no_nll:
         import torch.distributed as dist
         np.random.seed(4321)
-        total = n_probes * world if world > 1 else n_probes
+        # the config's N probes in total, dealt round-robin to the ranks
+        # (strong scaling of one optimiser step; alpha is solved on every rank)
+        total = n_probes
         probes = np.random.randint(0, 2, (total, p.n)) * 2 - 1
         info = gpu_nll_grad(p, probes, total)
         info['seconds'] = max_over_ranks(info['seconds'], world, dev)
         info['n_probes_global'] = total
+        info['scaling'] = 'strong'
+        info['probes_per_rank'] = -(-total // world)
         out['nll_grad'] = info
 
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -289,6 +289,15 @@ static void set_lds_attrs() {
 static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_tops,
                               rl_gridop** out);
 
+// destroys a half-built handle on every early return of a create function
+template <class H, int (*Destroy)(H*)>
+struct HandleGuard {
+    H* h;
+    explicit HandleGuard(H* h_) : h(h_) {}
+    ~HandleGuard() { if (h) (void)Destroy(h); }
+    H* release() { H* r = h; h = nullptr; return r; }
+};
+
 extern "C" int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out) {
     return gridop_create_impl(device, D, m, 0, 0, max_tops, out);
 }
@@ -316,6 +325,7 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     set_lds_attrs();
 
     rl_gridop* g = new rl_gridop;
+    HandleGuard<rl_gridop, rl_gridop_destroy> guard(g);
     g->device = device;
     g->D = D;
     g->m = m;
@@ -352,10 +362,8 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
         int R = pick_rows(D);
         if (R == 0 && lds_rows(g->N2, D) <= kLdsHard) R = 1;
         if (R > 0) { g->rowsB = R; break; }
-        if (g->N2 <= 4 || m1 != 0) {
-            delete g;
+        if (g->N2 <= 4 || m1 != 0)
             return fail(RL_ELIMIT, "rl_gridop_create: D * row length exceeds LDS");
-        }
         g->N2 /= 2;
         g->N1 *= 2;
     }
@@ -367,10 +375,8 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
         C = 8;
         while (C > 1 && ((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsHard) C /= 2;
     }
-    if (((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsHard) {
-        delete g;
+    if (((size_t)g->N1 * C + g->N1) * sizeof(cplx) > kLdsHard)
         return fail(RL_ELIMIT, "rl_gridop_create: grid too long for one LDS column tile");
-    }
     g->colsA = C;
 
     g->plan1 = make_plan(g->N1);
@@ -420,7 +426,7 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
         const size_t ppx = (size_t)(l2_mb * 1048576.0) / per_pair;
         g->xcd_pairs = ppx >= 1 ? 8 * ppx : 0;
     }
-    *out = g;
+    *out = guard.release();
     return RL_OK;
 }
 
@@ -858,6 +864,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
         return fail(RL_EINVAL, "rl_ski_create: W and WT have different nnz");
     RL_HIP(hipSetDevice(g->device));
     rl_ski* s = new rl_ski;
+    HandleGuard<rl_ski, rl_ski_destroy> guard(s);
     s->g = g;
     s->n = n;
     s->ngrid = ngrid;
@@ -917,7 +924,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     if ((rc = upload_raw((void**)&s->WT_data, WT_data, nnz * sizeof(double)))) return rc;
     RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
     RL_HIP(hipMemset(s->noise_diag, 0, (size_t)n * sizeof(double)));
-    *out = s;
+    *out = guard.release();
     return RL_OK;
 }
 
