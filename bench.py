@@ -53,19 +53,26 @@ def parse():
     ap.add_argument('--no-sweep', action='store_true',
                     help='skip the saturating-batch timings (extra keys)')
     ap.add_argument('--cpu-seconds', type=float, default=8.0)
+    # debugging aids for the multi-rank path on a one-GPU box
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
+    ap.add_argument('--same-gpu', action='store_true',
+                    help='every rank uses cuda:0 (only meaningful with gloo)')
     return ap.parse_args()
 
 
-def dist_setup(ngpus):
+def dist_setup(args):
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if args.same_gpu else int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     return rank, world, local
@@ -81,7 +88,8 @@ def max_over_ranks(x, world, dev):
     if world == 1:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    on = dev if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([x], dtype=torch.float64, device=on)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
 
@@ -245,7 +253,7 @@ def main():
     args = parse()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: runlmc_amd has no CPU path')
-    rank, world, local = dist_setup(args.gpus)
+    rank, world, local = dist_setup(args)
     dev = torch.device('cuda', torch.cuda.current_device())
     D, Q, R, m_data, n_probes = synth.CONFIGS[args.config]
     p = synth.make_problem(D, Q, R, m_data)
