@@ -92,6 +92,14 @@ int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int* W_indices
                   const double* W_data, const int* WT_indptr, const int* WT_indices,
                   const double* WT_data, rl_ski** out);
 int rl_ski_destroy(rl_ski* s);
+/* Kernels split over several active-dimension sets live on several grids:
+ * K~ = sum_t W_t K_t W_t^T + diag(eps) (the SumMatrix of one GridKernel per
+ * active-dimension set that gen_grid_kernel builds, grid_kernel.py:51-74).
+ * Adds term t >= 1: its grid operator (same D, same device, not owned) and its
+ * interpolant pair, n x (D*m_t).  Terms are numbered in the order added.     */
+int rl_ski_add_term(rl_ski* s, rl_gridop* g, const int* W_indptr, const int* W_indices,
+                    const double* W_data, const int* WT_indptr, const int* WT_indices,
+                    const double* WT_data);
 /* noise host [D], lens host [D] (sum lens == n): eps repeated per output
  * (np.repeat(noise, lens), grid_kernel.py:70).                               */
 int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens);
@@ -100,6 +108,9 @@ int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void* stream);
 /* G[v] = W^T X[v] (dev [nvec][D*m])  /  Y[v] = W G[v] (dev [nvec][n]).      */
 int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream);
 int rl_ski_apply_w(rl_ski* s, const double* G, double* Y, int nvec, void* stream);
+/* The same with the interpolants of term `term` (0 = the first).             */
+int rl_ski_apply_wt_term(rl_ski* s, int term, const double* X, double* G, int nvec, void* stream);
+int rl_ski_apply_w_term(rl_ski* s, int term, const double* G, double* Y, int nvec, void* stream);
 
 /* ---- batched Krylov solves  K~ X = B  --------------------------------------
  * Replaces Iterative.solve (runlmc/approx/iterative.py:23-62) and the N+1

@@ -39,6 +39,9 @@ _SIGNATURES = {
     'rl_gridop_spectrum_host': [_vp, _i, _vp],
     'rl_ski_create': [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp)],
     'rl_ski_destroy': [_vp],
+    'rl_ski_add_term': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'rl_ski_apply_wt_term': [_vp, _i, _vp, _vp, _i, _vp],
+    'rl_ski_apply_w_term': [_vp, _i, _vp, _vp, _i, _vp],
     'rl_ski_set_noise': [_vp, _vp, _vp],
     'rl_ski_mvm': [_vp, _vp, _vp, _i, _vp],
     'rl_ski_apply_wt': [_vp, _vp, _vp, _i, _vp],

@@ -171,6 +171,28 @@ class SkiOp:
         self._h = ctypes.c_void_p()
         self.lib.call('rl_ski_create', gridop.handle, self.n,
                       *[host_ptr(a) for a in arrs], ctypes.byref(self._h))
+        self.grids = [gridop]          # grid operator of every term (kept alive)
+
+    @staticmethod
+    def _csr_arrays(W, WT):
+        W, WT = W.tocsr(), WT.tocsr()
+        return [np.ascontiguousarray(W.indptr, dtype=np.int32),
+                np.ascontiguousarray(W.indices, dtype=np.int32),
+                as_f64(W.data),
+                np.ascontiguousarray(WT.indptr, dtype=np.int32),
+                np.ascontiguousarray(WT.indices, dtype=np.int32),
+                as_f64(WT.data)]
+
+    def add_term(self, gridop, W, WT):
+        """Add W_t K_t W_t^T for kernels on another active-dimension set;
+        returns the term index."""
+        if W.shape != (self.n, gridop.width) or WT.shape != (gridop.width, self.n):
+            raise ValueError('interpolant shapes do not match the operator')
+        arrs = self._csr_arrays(W, WT)
+        self.lib.call('rl_ski_add_term', self._h, gridop.handle,
+                      *[host_ptr(a) for a in arrs])
+        self.grids.append(gridop)
+        return len(self.grids) - 1
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -196,18 +218,18 @@ class SkiOp:
                       X.shape[0], self.lib.stream_ptr(self.device))
         return out
 
-    def apply_wt(self, X):
-        out = torch.empty((X.shape[0], self.grid.width), dtype=torch.float64,
+    def apply_wt(self, X, term=0):
+        out = torch.empty((X.shape[0], self.grids[term].width), dtype=torch.float64,
                           device=self.device)
-        self.lib.call('rl_ski_apply_wt', self._h, dev_ptr(X), dev_ptr(out),
-                      X.shape[0], self.lib.stream_ptr(self.device))
+        self.lib.call('rl_ski_apply_wt_term', self._h, int(term), dev_ptr(X),
+                      dev_ptr(out), X.shape[0], self.lib.stream_ptr(self.device))
         return out
 
-    def apply_w(self, G):
+    def apply_w(self, G, term=0):
         out = torch.empty((G.shape[0], self.n), dtype=torch.float64,
                           device=self.device)
-        self.lib.call('rl_ski_apply_w', self._h, dev_ptr(G), dev_ptr(out),
-                      G.shape[0], self.lib.stream_ptr(self.device))
+        self.lib.call('rl_ski_apply_w_term', self._h, int(term), dev_ptr(G),
+                      dev_ptr(out), G.shape[0], self.lib.stream_ptr(self.device))
         return out
 
     def matmat_host(self, X):

@@ -293,14 +293,15 @@ k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, 
 // Each thread owns one row and VB vectors: the row's CSR entries (12 bytes per
 // non-zero) are fetched once and reused for every vector, so the matrix
 // structure is streamed nvec / VB times instead of nvec times.
-// Used for W^T x (rows = D*m grid points) and for W g + eps * x (rows = n).
+// Used for W^T x (rows = D*m grid points) and for W g + eps * x (rows = n);
+// `accumulate` adds into Y (further terms of a split-kernel operator).
 // ---------------------------------------------------------------------------
 template <int RL_SPMV_VB>
 __global__ void __launch_bounds__(RL_THREADS)
 k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
        const double* __restrict__ vals, int nrows, int ncols, int nvec,
        const double* __restrict__ X, double* __restrict__ Y, const double* __restrict__ diag,
-       const double* __restrict__ X2) {
+       const double* __restrict__ X2, int accumulate) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     const int v0 = blockIdx.y * RL_SPMV_VB;
     if (row >= nrows) return;
@@ -323,6 +324,7 @@ k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
         if (j < nv) {
             double r = acc[j];
             if (diag != nullptr) r = fma(dg, X2[(size_t)(v0 + j) * nrows + row], r);
+            if (accumulate) r += Y[(size_t)(v0 + j) * nrows + row];
             Y[(size_t)(v0 + j) * nrows + row] = r;
         }
 }

@@ -790,7 +790,20 @@ extern "C" int rl_gridop_spectrum_host(rl_gridop* g, int q, double* out) {
 // ---------------------------------------------------------------------------
 // SKI operator
 // ---------------------------------------------------------------------------
+// one W K_UU W^T term of the operator (kernels that share an
+// active-dimension set share a grid, hence a term)
+struct SkiTerm {
+    rl_gridop* g = nullptr;
+    int ngrid = 0;
+    int *W_indptr = nullptr, *W_indices = nullptr;
+    double* W_data = nullptr;
+    int *WT_indptr = nullptr, *WT_indices = nullptr;
+    double* WT_data = nullptr;
+};
+
 struct rl_ski {
+    std::vector<SkiTerm> extra;   // terms beyond the first (rl_ski_add_term)
+    int max_ngrid = 0;
     rl_gridop* g = nullptr;
     int n = 0, ngrid = 0;
     int *W_indptr = nullptr, *W_indices = nullptr;
@@ -817,16 +830,16 @@ struct rl_ski {
 // (bandwidth-bound: the structure is 12 bytes per non-zero per pass).
 static void launch_spmv(const int* indptr, const int* indices, const double* vals, int nrows,
                         int ncols, int nvec, const double* X, double* Y, const double* diag,
-                        const double* X2, hipStream_t st) {
+                        const double* X2, hipStream_t st, int accumulate = 0) {
     const unsigned gx = (nrows + RL_THREADS - 1) / RL_THREADS;
     static const int force_vb = getenv("RUNLMC_SPMV_VB") ? atoi(getenv("RUNLMC_SPMV_VB")) : 0;
     const bool blocked = force_vb ? force_vb > 1 : (size_t)nrows * nvec >= ((size_t)1 << 22);
     if (blocked) {
         RL_LAUNCH(k_spmv<8>, dim3(gx, (nvec + 7) / 8), dim3(RL_THREADS), 0, st, indptr, indices,
-                  vals, nrows, ncols, nvec, X, Y, diag, X2);
+                  vals, nrows, ncols, nvec, X, Y, diag, X2, accumulate);
     } else {
         RL_LAUNCH(k_spmv<1>, dim3(gx, nvec), dim3(RL_THREADS), 0, st, indptr, indices, vals,
-                  nrows, ncols, nvec, X, Y, diag, X2);
+                  nrows, ncols, nvec, X, Y, diag, X2, accumulate);
     }
 }
 
@@ -850,6 +863,54 @@ static int upload_raw(void** dev, const void* host, size_t bytes) {
     return RL_OK;
 }
 
+// Upload one term's CSR pair, rows of W (and column indices of WT) renumbered
+// by `perm` (perm[i] = caller's row of internal row i) when given.
+static int upload_term(SkiTerm* t, int n, int ngrid, const int* W_indptr, const int* W_indices,
+                       const double* W_data, const int* WT_indptr, const int* WT_indices,
+                       const double* WT_data, const std::vector<int>* perm) {
+    const size_t nnz = W_indptr[n];
+    std::vector<int> wp_ptr, wp_idx, wtp_idx;
+    std::vector<double> wp_val, wtp_val;
+    if (perm) {
+        std::vector<int> inv(n);
+        for (int i = 0; i < n; ++i) inv[(*perm)[i]] = i;
+        wp_ptr.assign(n + 1, 0);
+        wp_idx.reserve(nnz);
+        wp_val.reserve(nnz);
+        for (int i = 0; i < n; ++i) {
+            const int r = (*perm)[i];
+            for (int k = W_indptr[r]; k < W_indptr[r + 1]; ++k) {
+                wp_idx.push_back(W_indices[k]);
+                wp_val.push_back(W_data[k]);
+            }
+            wp_ptr[i + 1] = (int)wp_idx.size();
+        }
+        wtp_idx.resize(nnz);
+        wtp_val.resize(nnz);
+        std::vector<std::pair<int, double>> row;
+        for (int r = 0; r < ngrid; ++r) {
+            row.clear();
+            for (int k = WT_indptr[r]; k < WT_indptr[r + 1]; ++k)
+                row.emplace_back(inv[WT_indices[k]], WT_data[k]);
+            std::sort(row.begin(), row.end());
+            for (size_t j = 0; j < row.size(); ++j) {
+                wtp_idx[WT_indptr[r] + j] = row[j].first;
+                wtp_val[WT_indptr[r] + j] = row[j].second;
+            }
+        }
+        W_indptr = wp_ptr.data(); W_indices = wp_idx.data(); W_data = wp_val.data();
+        WT_indices = wtp_idx.data(); WT_data = wtp_val.data();
+    }
+    t->ngrid = ngrid;
+    RL_TRY(upload_raw((void**)&t->W_indptr, W_indptr, (size_t)(n + 1) * sizeof(int)));
+    RL_TRY(upload_raw((void**)&t->W_indices, W_indices, nnz * sizeof(int)));
+    RL_TRY(upload_raw((void**)&t->W_data, W_data, nnz * sizeof(double)));
+    RL_TRY(upload_raw((void**)&t->WT_indptr, WT_indptr, (size_t)(ngrid + 1) * sizeof(int)));
+    RL_TRY(upload_raw((void**)&t->WT_indices, WT_indices, nnz * sizeof(int)));
+    RL_TRY(upload_raw((void**)&t->WT_data, WT_data, nnz * sizeof(double)));
+    return RL_OK;
+}
+
 extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int* W_indices,
                              const double* W_data, const int* WT_indptr, const int* WT_indices,
                              const double* WT_data, rl_ski** out) {
@@ -868,8 +929,6 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     s->g = g;
     s->n = n;
     s->ngrid = ngrid;
-    const size_t nnz = W_indptr[n];
-    int rc = RL_OK;
     // sort the data points by the first grid point they touch
     std::vector<int> perm(n);
     for (int i = 0; i < n; ++i) perm[i] = i;
@@ -880,57 +939,58 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     bool identity = true;
     for (int i = 0; i < n && identity; ++i) identity = perm[i] == i;
     if (getenv("RUNLMC_NO_SORT")) identity = true;
-    std::vector<int> wp_ptr, wp_idx, wtp_ptr, wtp_idx;
-    std::vector<double> wp_val, wtp_val;
     if (!identity) {
         s->permuted = true;
         s->h_perm = perm;
-        std::vector<int> inv(n);
-        for (int i = 0; i < n; ++i) inv[perm[i]] = i;
-        wp_ptr.assign(n + 1, 0);
-        wp_idx.reserve(nnz);
-        wp_val.reserve(nnz);
-        for (int i = 0; i < n; ++i) {
-            const int r = perm[i];
-            for (int k = W_indptr[r]; k < W_indptr[r + 1]; ++k) {
-                wp_idx.push_back(W_indices[k]);
-                wp_val.push_back(W_data[k]);
-            }
-            wp_ptr[i + 1] = (int)wp_idx.size();
-        }
-        wtp_ptr.assign(WT_indptr, WT_indptr + ngrid + 1);
-        wtp_idx.resize(nnz);
-        wtp_val.resize(nnz);
-        std::vector<std::pair<int, double>> row;
-        for (int r = 0; r < ngrid; ++r) {
-            row.clear();
-            for (int k = WT_indptr[r]; k < WT_indptr[r + 1]; ++k)
-                row.emplace_back(inv[WT_indices[k]], WT_data[k]);
-            std::sort(row.begin(), row.end());
-            for (size_t j = 0; j < row.size(); ++j) {
-                wtp_idx[WT_indptr[r] + j] = row[j].first;
-                wtp_val[WT_indptr[r] + j] = row[j].second;
-            }
-        }
-        W_indptr = wp_ptr.data(); W_indices = wp_idx.data(); W_data = wp_val.data();
-        WT_indptr = wtp_ptr.data(); WT_indices = wtp_idx.data(); WT_data = wtp_val.data();
-        if ((rc = upload_raw((void**)&s->perm, perm.data(), (size_t)n * sizeof(int)))) return rc;
+        RL_TRY(upload_raw((void**)&s->perm, perm.data(), (size_t)n * sizeof(int)));
     }
-    if ((rc = upload_raw((void**)&s->W_indptr, W_indptr, (size_t)(n + 1) * sizeof(int)))) return rc;
-    if ((rc = upload_raw((void**)&s->W_indices, W_indices, nnz * sizeof(int)))) return rc;
-    if ((rc = upload_raw((void**)&s->W_data, W_data, nnz * sizeof(double)))) return rc;
-    if ((rc = upload_raw((void**)&s->WT_indptr, WT_indptr, (size_t)(ngrid + 1) * sizeof(int)))) return rc;
-    if ((rc = upload_raw((void**)&s->WT_indices, WT_indices, nnz * sizeof(int)))) return rc;
-    if ((rc = upload_raw((void**)&s->WT_data, WT_data, nnz * sizeof(double)))) return rc;
+    SkiTerm t0;
+    RL_TRY(upload_term(&t0, n, ngrid, W_indptr, W_indices, W_data, WT_indptr, WT_indices,
+                       WT_data, s->permuted ? &s->h_perm : nullptr));
+    s->W_indptr = t0.W_indptr; s->W_indices = t0.W_indices; s->W_data = t0.W_data;
+    s->WT_indptr = t0.WT_indptr; s->WT_indices = t0.WT_indices; s->WT_data = t0.WT_data;
+    s->max_ngrid = ngrid;
     RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
     RL_HIP(hipMemset(s->noise_diag, 0, (size_t)n * sizeof(double)));
     *out = guard.release();
     return RL_OK;
 }
 
+extern "C" int rl_ski_add_term(rl_ski* s, rl_gridop* g, const int* W_indptr,
+                               const int* W_indices, const double* W_data,
+                               const int* WT_indptr, const int* WT_indices,
+                               const double* WT_data) {
+    if (!s || !g) return fail(RL_EINVAL, "rl_ski_add_term: NULL handle");
+    if (g->D != s->g->D || g->device != s->g->device)
+        return fail(RL_EINVAL, "rl_ski_add_term: grid operator has another D or device");
+    const int ngrid = g->D * g->m;
+    RL_TRY(check_csr(W_indptr, W_indices, s->n, ngrid, "W"));
+    RL_TRY(check_csr(WT_indptr, WT_indices, ngrid, s->n, "WT"));
+    if (W_indptr[s->n] != WT_indptr[ngrid])
+        return fail(RL_EINVAL, "rl_ski_add_term: W and WT have different nnz");
+    RL_HIP(hipSetDevice(g->device));
+    SkiTerm t;
+    t.g = g;
+    // the handle's row order was fixed by its first term
+    int rc = upload_term(&t, s->n, ngrid, W_indptr, W_indices, W_data, WT_indptr, WT_indices,
+                         WT_data, s->permuted ? &s->h_perm : nullptr);
+    s->extra.push_back(t);     // pushed even on failure so destroy frees what was uploaded
+    if (rc != RL_OK) return rc;
+    if (ngrid > s->max_ngrid) {
+        s->max_ngrid = ngrid;
+        s->cap = 0;            // grid-side temporaries must grow
+    }
+    return RL_OK;
+}
+
 extern "C" int rl_ski_destroy(rl_ski* s) {
     if (!s) return RL_OK;
     (void)hipSetDevice(s->g->device);
+    for (SkiTerm& t : s->extra) {
+        void* tp[] = {t.W_indptr, t.W_indices, t.W_data, t.WT_indptr, t.WT_indices, t.WT_data};
+        for (void* p : tp)
+            if (p) (void)hipFree(p);
+    }
     if (s->solver_stream) (void)hipStreamDestroy(s->solver_stream);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2};
@@ -963,13 +1023,13 @@ extern "C" int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens)
 }
 
 static int ski_reserve(rl_ski* s, int nvec) {
-    if (nvec <= s->cap) return RL_OK;
+    if (nvec <= s->cap && s->G1) return RL_OK;
     if (s->G1) RL_HIP(hipFree(s->G1));
     if (s->G2) RL_HIP(hipFree(s->G2));
     s->G1 = s->G2 = nullptr;
     s->cap = 0;
-    RL_HIP(hipMalloc((void**)&s->G1, (size_t)nvec * s->ngrid * sizeof(double)));
-    RL_HIP(hipMalloc((void**)&s->G2, (size_t)nvec * s->ngrid * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&s->G1, (size_t)nvec * s->max_ngrid * sizeof(double)));
+    RL_HIP(hipMalloc((void**)&s->G2, (size_t)nvec * s->max_ngrid * sizeof(double)));
     s->cap = nvec;
     return RL_OK;
 }
@@ -1013,12 +1073,40 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
     RL_TRY(ski_reserve(s, nvec));
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st));
     RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st));
-    return ski_w_int(s, s->G2, Yp, nvec, s->has_noise ? s->noise_diag : nullptr, Xp, st);
+    RL_TRY(ski_w_int(s, s->G2, Yp, nvec, s->has_noise ? s->noise_diag : nullptr, Xp, st));
+    for (const SkiTerm& t : s->extra) {       // Yp += W_t K_t W_t^T Xp
+        launch_spmv(t.WT_indptr, t.WT_indices, t.WT_data, t.ngrid, s->n, nvec, Xp, s->G1,
+                    nullptr, nullptr, st);
+        RL_TRY(rl_gridop_mvm(t.g, s->G1, s->G2, nvec, st));
+        launch_spmv(t.W_indptr, t.W_indices, t.W_data, s->n, t.ngrid, nvec, s->G2, Yp, nullptr,
+                    nullptr, st, 1);
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
-extern "C" int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream) {
+// CSR pair of term `term` (0 = the handle's first term)
+static int term_view(rl_ski* s, int term, SkiTerm* out) {
+    if (term < 0 || term > (int)s->extra.size())
+        return fail(RL_EINVAL, "SKI term index out of range");
+    if (term == 0) {
+        out->g = s->g;
+        out->ngrid = s->ngrid;
+        out->W_indptr = s->W_indptr; out->W_indices = s->W_indices; out->W_data = s->W_data;
+        out->WT_indptr = s->WT_indptr; out->WT_indices = s->WT_indices;
+        out->WT_data = s->WT_data;
+    } else {
+        *out = s->extra[term - 1];
+    }
+    return RL_OK;
+}
+
+extern "C" int rl_ski_apply_wt_term(rl_ski* s, int term, const double* X, double* G, int nvec,
+                                    void* stream) {
     if (!s || !X || !G) return fail(RL_EINVAL, "rl_ski_apply_wt: NULL argument");
     if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
+    SkiTerm t;
+    RL_TRY(term_view(s, term, &t));
     RL_HIP(hipSetDevice(s->g->device));
     hipStream_t st = (hipStream_t)stream;
     if (s->permuted) {
@@ -1026,19 +1114,38 @@ extern "C" int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, 
         permute_rows(s, X, s->P1, nvec, 0, st);
         X = s->P1;
     }
-    return ski_wt_int(s, X, G, nvec, st);
+    launch_spmv(t.WT_indptr, t.WT_indices, t.WT_data, t.ngrid, s->n, nvec, X, G, nullptr,
+                nullptr, st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_ski_apply_w_term(rl_ski* s, int term, const double* G, double* Y, int nvec,
+                                   void* stream) {
+    if (!s || !G || !Y) return fail(RL_EINVAL, "rl_ski_apply_w: NULL argument");
+    if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
+    SkiTerm t;
+    RL_TRY(term_view(s, term, &t));
+    RL_HIP(hipSetDevice(s->g->device));
+    hipStream_t st = (hipStream_t)stream;
+    double* dst = Y;
+    if (s->permuted) {
+        RL_TRY(ski_reserve_perm(s, nvec));
+        dst = s->P2;
+    }
+    launch_spmv(t.W_indptr, t.W_indices, t.W_data, s->n, t.ngrid, nvec, G, dst, nullptr, nullptr,
+                st);
+    if (s->permuted) permute_rows(s, s->P2, Y, nvec, 1, st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_ski_apply_wt(rl_ski* s, const double* X, double* G, int nvec, void* stream) {
+    return rl_ski_apply_wt_term(s, 0, X, G, nvec, stream);
 }
 
 extern "C" int rl_ski_apply_w(rl_ski* s, const double* G, double* Y, int nvec, void* stream) {
-    if (!s || !G || !Y) return fail(RL_EINVAL, "rl_ski_apply_w: NULL argument");
-    if (nvec <= 0) return nvec == 0 ? RL_OK : fail(RL_EINVAL, "nvec < 0");
-    RL_HIP(hipSetDevice(s->g->device));
-    hipStream_t st = (hipStream_t)stream;
-    if (!s->permuted) return ski_w_int(s, G, Y, nvec, nullptr, nullptr, st);
-    RL_TRY(ski_reserve_perm(s, nvec));
-    RL_TRY(ski_w_int(s, G, s->P2, nvec, nullptr, nullptr, st));
-    permute_rows(s, s->P2, Y, nvec, 1, st);
-    return RL_OK;
+    return rl_ski_apply_w_term(s, 0, G, Y, nvec, stream);
 }
 
 extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void* stream) {
@@ -1223,6 +1330,8 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     // everything the operator product allocates lazily must exist before capture
     RL_TRY(ski_reserve(s, nrhs));
     RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
+    for (const SkiTerm& t : s->extra)
+        RL_TRY(ensure_workspace(t.g, std::min(((size_t)nrhs + 1) / 2, t.g->chunk_pairs)));
     int active = nrhs;
     int done = 0;          // iterations issued so far
 

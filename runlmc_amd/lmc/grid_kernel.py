@@ -137,47 +137,56 @@ class GridKernel(Matrix):
 
 
 class LMCOperator(SumMatrix):
-    """K~ = GridKernel + Diag(noise): the SumMatrix gen_grid_kernel returns
-    (reference grid_kernel.py:70-74), with a fused device product and a
-    handle the batched solver can use."""
+    """K~ = sum over active-dimension sets of GridKernel + Diag(noise): the
+    SumMatrix gen_grid_kernel returns (reference grid_kernel.py:66-74), with
+    ONE device handle (all terms and the noise) that serves the fused product
+    and the batched solver."""
 
-    def __init__(self, grid_kernel, noise_diag_matrix, noise, lens):
-        super().__init__([grid_kernel, noise_diag_matrix])
-        self._gk = grid_kernel
-        self._gk._skiop.set_noise(noise, lens)
+    def __init__(self, grid_kernels, noise_diag_matrix, noise, lens):
+        grid_kernels = list(grid_kernels)
+        super().__init__(grid_kernels + [noise_diag_matrix])
+        self._gks = grid_kernels
+        first = grid_kernels[0]
+        self._skiop = first._skiop
+        self.term_of = {first.active_dim: 0}
+        for gk in grid_kernels[1:]:
+            W, WT = gk.ski.W, gk.ski.WT
+            self.term_of[gk.active_dim] = self._skiop.add_term(gk._op, W, WT)
+        self._skiop.set_noise(noise, lens)
         self.lens = list(lens)
 
     def device_operator(self):
-        return self._gk._skiop
+        return self._skiop
 
     @property
     def device(self):
-        return self._gk.device
+        return self._skiop.device
 
     def _try_fuse(self):
         return None
 
     def matmat_device(self, X):
-        return self._gk._skiop.mvm(X)
+        return self._skiop.mvm(X)
 
     def matvec(self, x):
         x = check_vector(x, self.shape[1])
-        return self._gk._skiop.matmat_host(x.astype(np.float64))
+        return self._skiop.matmat_host(x.astype(np.float64))
 
     def matmat(self, X):
         X = check_block(X, self.shape[1])
-        return self._gk._skiop.matmat_host(
+        return self._skiop.matmat_host(
             np.ascontiguousarray(X.T, dtype=np.float64)).T
+
+    def update_noise(self, noise, lens):
+        self._skiop.set_noise(noise, lens)
+        self.Ks[-1].v = np.repeat(noise, lens)
 
 
 def gen_grid_kernel(fk, grid_dists, interpolants, lens_per_output,
                     device_index=0):
     """(K~, {active_dim: GridKernel}) exactly as the reference returns them
-    (grid_kernel.py:49-74)."""
-    if len(fk.active_dims) != 1:
-        raise NotImplementedError(
-            'kernels split over several active-dimension sets are not part '
-            'of this release (SURVEY.md section 8f-4)')
+    (grid_kernel.py:49-74): one GridKernel per active-dimension set, summed
+    with the noise."""
     grid_kerns = {}
     for active_dim in fk.active_dims:
         W, WT = interpolants[active_dim]
@@ -185,5 +194,5 @@ def gen_grid_kernel(fk, grid_dists, interpolants, lens_per_output,
             fk, grid_dists[active_dim], W, WT, choose_ktype(fk, active_dim),
             active_dim, device_index=device_index)
     noise = Diag(np.repeat(fk.noise, lens_per_output))
-    (gk,) = grid_kerns.values()
-    return LMCOperator(gk, noise, fk.noise, lens_per_output), grid_kerns
+    K = LMCOperator(list(grid_kerns.values()), noise, fk.noise, lens_per_output)
+    return K, grid_kerns

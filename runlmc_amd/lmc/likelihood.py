@@ -112,26 +112,41 @@ class ApproxLMCLikelihood(LMCLikelihood):
         dv = self.deriv
         skiop = self.K.device_operator()
         lib, dev = skiop.lib, skiop.device
-        tops = [as_f64(np.ravel(k)) for k in self.materialized_kernels]
-        dtops = [[as_f64(np.ravel(g)) for g in gl] for gl in self.materialized_grads]
-        flat_tops = tops + [g for gl in dtops for g in gl]
-        ntops = len(flat_tops)
-        m = flat_tops[0].shape[0]
-        gop = _grad_operator(D, m, ntops, skiop.grid.device_index,
-                             sizes=skiop.grid.sizes)
-        gop.set_lmc(np.stack(flat_tops), [None] * ntops,
-                    [np.zeros(D)] * ntops)
-
+        term_of = getattr(self.K, 'term_of', None) or {ad: 0 for ad in fk.active_dims}
         nloc = dv.rs_dev.shape[0]
         U = torch.cat([dv.alpha_dev[None, :], dv.inv_rs_dev], dim=0).contiguous()
         V = torch.cat([dv.alpha_dev[None, :], dv.rs_dev], dim=0).contiguous()
-        Ut = skiop.apply_wt(U)
-        Vt = skiop.apply_wt(V)
-        P = torch.empty((ntops, nloc + 1, D, D), dtype=torch.float64, device=dev)
-        TV = torch.empty_like(Vt)
-        for t in range(ntops):
-            gop.mvm(Vt, out=TV, top=t)
-            P[t] = cross_dots(lib, Ut, TV, D, m)
+
+        # per active-dimension set (= per grid = per term of the operator): the
+        # top rows k_q and dk_q/dtheta of its kernels, one batched Toeplitz
+        # product and one D x D Gram per top row
+        owner = []            # (q, None) for k_q, (q, p) for dk_q/dtheta_p
+        blocks = []           # P tensors (ntops_t, nloc + 1, D, D)
+        for ad, qs in fk.active_dims.items():
+            term = term_of[ad]
+            grid = skiop.grids[term]
+            tops_t, own_t = [], []
+            for q in qs:
+                tops_t.append(as_f64(np.ravel(self.materialized_kernels[q])))
+                own_t.append((q, None))
+            for q in qs:
+                for p_, g in enumerate(self.materialized_grads[q]):
+                    tops_t.append(as_f64(np.ravel(g)))
+                    own_t.append((q, p_))
+            nt = len(tops_t)
+            gop = _grad_operator(D, grid.m, nt, grid.device_index, sizes=grid.sizes)
+            gop.set_lmc(np.stack(tops_t), [None] * nt, [np.zeros(D)] * nt)
+            Ut = skiop.apply_wt(U, term)
+            Vt = skiop.apply_wt(V, term)
+            P = torch.empty((nt, nloc + 1, D, D), dtype=torch.float64, device=dev)
+            TV = torch.empty_like(Vt)
+            for t in range(nt):
+                gop.mvm(Vt, out=TV, top=t)
+                P[t] = cross_dots(lib, Ut, TV, D, grid.m)
+            owner += own_t
+            blocks.append(P)
+        P = torch.cat(blocks, dim=0)
+        ntops = P.shape[0]
         offsets = torch.from_numpy(
             np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int32)).to(dev)
         seg = segment_dots(lib, U, V, offsets, D)          # (nloc + 1, D)
@@ -143,9 +158,16 @@ class ApproxLMCLikelihood(LMCLikelihood):
         N = dv._n_it
         Psum = probe[:ntops * D * D].reshape(ntops, D, D)
         ssum = probe[ntops * D * D:]
-        G = (0.5 * (P[:, 0] - Psum / N)).cpu().numpy()
+        Gall = (0.5 * (P[:, 0] - Psum / N)).cpu().numpy()
         noise = (0.5 * (seg[0] - ssum / N)).cpu().numpy()
-        self._parts = dict(G=G[:Q], Gd=G[Q:], noise=noise)
+        G = [None] * Q
+        Gd = [[None] * len(self.materialized_grads[q]) for q in range(Q)]
+        for t, (q, p_) in enumerate(owner):
+            if p_ is None:
+                G[q] = Gall[t]
+            else:
+                Gd[q][p_] = Gall[t]
+        self._parts = dict(G=G, Gd=Gd, noise=noise)
         return self._parts
 
     def coreg_vec_gradients(self):
@@ -159,14 +181,8 @@ class ApproxLMCLikelihood(LMCLikelihood):
 
     def kernel_gradients(self):
         Gd = self._partials()['Gd']
-        out, t = [], 0
-        for q, B in enumerate(self.functional_kernel.coreg_mats()):
-            row = []
-            for _ in self.materialized_grads[q]:
-                row.append(float(np.sum(B * Gd[t])))
-                t += 1
-            out.append(row)
-        return out
+        return [[float(np.sum(B * Gqp)) for Gqp in Gd[q]]
+                for q, B in enumerate(self.functional_kernel.coreg_mats())]
 
     def noise_gradient(self):
         return self._partials()['noise'].copy()

@@ -10,7 +10,9 @@ Every product, solve and gradient inside runs on the device
 * ``log_det_K()`` is the matrix-free stochastic-Lanczos estimate of
   log det K~ (the reference's is a dense Cholesky of the exact kernel and is
   never on its optimiser path, interpolated_llgp.py:262-276).
-* inputs of one or two dimensions (bicubic interpolation, BTTB kernels);
+* inputs of any dimension, each kernel acting on one or two of them (bicubic
+  interpolation, BTTB kernels; kernels on different active-dimension sets get
+  their own grids);
 * prediction modes: 'on-the-fly' and 'precompute' (both batched solves on the
   device); 'exact' (dense Cholesky) is not provided.
 * parameters live in one flat array in the optimiser's space; positive
@@ -77,10 +79,9 @@ class InterpolatedLLGP:
         self.prediction = prediction
         self._functional_kernel = functional_kernel
         self._functional_kernel.set_input_dim(self.input_dim)
-        if self.input_dim > 2 or len(functional_kernel.active_dims) != 1:
+        if any(len(ad) > 2 for ad in functional_kernel.active_dims):
             raise NotImplementedError(
-                'this release handles 1-D and 2-D inputs with one '
-                'active-dimension set')
+                'kernels may act on one or two input dimensions each')
         self.y = np.hstack(self.Ys)
         self.kernel = None
         self.dists, self.interpolants, self.grid_axes = {}, {}, {}
@@ -197,8 +198,7 @@ class InterpolatedLLGP:
             # same grid and interpolants: only spectra, factors and noise change
             for ad, gk in self._grid_kernels.items():
                 gk.update(fk, self.dists[ad])
-            self._K.device_operator().set_noise(fk.noise, lens)
-            self._K.Ks[1].v = np.repeat(fk.noise, lens)
+            self._K.update_noise(fk.noise, lens)
         self.kernel = ApproxLMCLikelihood(
             fk, self._K, self.dists, self.interpolants, self.Ys,
             self._deriv_service)
@@ -272,12 +272,12 @@ class InterpolatedLLGP:
         rl, cl = [len(X) for X in Xs], [len(X) for X in self.Xs]
         A = np.vstack([X.reshape(len(X), self.input_dim) for X in Xs])
         B = np.vstack(self.Xs)
-        (ad,) = fk.active_dims
-        dist = sdist.cdist(A[:, list(ad)], B[:, list(ad)])
+        dist = {ad: sdist.cdist(A[:, list(ad)], B[:, list(ad)])
+                for ad in fk.active_dims}
         ro, co = np.repeat(np.arange(fk.D), rl), np.repeat(np.arange(fk.D), cl)
         K = np.zeros((sum(rl), sum(cl)))
         for Bq, k in zip(fk.coreg_mats(), fk.kernels):
-            K += Bq[np.ix_(ro, co)] * k.from_dist(dist)
+            K += Bq[np.ix_(ro, co)] * k.from_dist(dist[k.active_dims])
         return K
 
     def _var_on_the_fly(self, _W, Xs):
@@ -289,6 +289,9 @@ class InterpolatedLLGP:
 
     def _precomputed_nu(self):
         if 'nu' not in self._caches:
+            if len(self.interpolants) != 1:
+                raise ValueError(
+                    'precompute prediction mode unavailable for split kernels')
             (ad,) = self.interpolants
             W, WT = self.interpolants[ad]
             gk = self._grid_kernels[ad]
@@ -300,19 +303,23 @@ class InterpolatedLLGP:
             self._caches['nu'] = np.diag(back).copy()
         return self._caches['nu']
 
-    def _var_precompute(self, W, _Xs):
-        return W.dot(self._precomputed_nu())
+    def _var_precompute(self, Ws, _Xs):
+        nu = self._precomputed_nu()
+        (W,) = Ws.values()
+        return W.dot(nu)
 
     def _raw_predict(self, Xs):
         self._ensure()
         Xs = [np.asarray(X, dtype=float).reshape(len(X), self.input_dim) for X in Xs]
         lens = [len(X) for X in Xs]
-        (ad,) = self._functional_kernel.active_dims
-        W = multi_interpolant([X[:, list(ad)] for X in Xs], *self.grid_axes[ad])
-        mean = W.dot(self._grid_alpha()[ad])
+        mean = np.zeros(sum(lens))
+        Ws = {}
+        for ad, grid_alpha in self._grid_alpha().items():
+            Ws[ad] = multi_interpolant([X[:, list(ad)] for X in Xs], *self.grid_axes[ad])
+            mean += Ws[ad].dot(grid_alpha)
         native = np.repeat(self._native_variance(), lens)
         explained = (self._var_on_the_fly if self.prediction == 'on-the-fly'
-                     else self._var_precompute)(W, Xs)
+                     else self._var_precompute)(Ws, Xs)
         var = native - explained
         var[var < 0] = 0
         cuts = np.cumsum(lens)[:-1]

@@ -341,11 +341,14 @@ def gen_lmc():
 def _main():
     if '--2d-only' in sys.argv:
         return gen_2d()
+    if '--split-only' in sys.argv:
+        return gen_split()
     if '--datasets-only' not in sys.argv:
         gen_linalg()
         gen_interp()
         gen_lmc()
         gen_2d()
+        gen_split()
     gen_datasets()
 
 
@@ -605,6 +608,85 @@ def gen_2d():
     out['ref_cg_x'], out['ref_cg_iters'], out['ref_cg_err'] = (
         np.array([s0[0]]), np.array([s0[1]]), np.array([s0[2]]))
     _save('lmc_2d.npz', **out)
+
+
+# ---------------------------------------------------------------------------
+# 6. Kernels split over two active-dimension sets: one GridKernel (own grid,
+#    own interpolant) per set, summed (reference grid_kernel.py:49-74,
+#    models/interpolated_llgp.py:415-443, likelihood.py:112-123)
+# ---------------------------------------------------------------------------
+def gen_split():
+    rng = np.random.RandomState(41)
+    D, lens = 2, [50, 40]
+    kinfo = [('rbf', 2.0, (0,)), ('matern', 1.5, (1,)), ('rbf', 6.0, (0,))]
+    ranks = [1, 2, 1]
+    Q = len(kinfo)
+    coreg_vecs = [rng.uniform(-1, 1, size=(r, D)) for r in ranks]
+    coreg_diags = [1.0 / rng.gamma(2.0, 1.0, size=D) for _ in range(Q)]
+    noise = 0.1 * (0.5 + rng.rand(D))
+    Xs = [rng.rand(n, 2) for n in lens]
+    Ys = [np.sin(4 * X[:, 0] + d) + np.cos(3 * X[:, 1]) + 0.1 * rng.randn(len(X))
+          for d, X in enumerate(Xs)]
+    y = np.hstack(Ys)
+    n = sum(lens)
+    kernels = []
+    for kind, par, ad in kinfo:
+        k = _kernel_from_desc((kind, par))
+        k.active_dims = list(ad)
+        kernels.append(k)
+    spec = KernelSpec(D, kernels, coreg_vecs, coreg_diags, noise)
+    spec.set_input_dim(2)
+    mreq = {(0,): 16.0, (1,): 12.0}
+    dists, interp, axes = {}, {}, {}
+    for ad in spec.active_dims:
+        Xa = [X[:, list(ad)] for X in Xs]
+        axes[ad] = autogrid(Xa, lo=None, hi=None, m=np.array([mreq[ad]]))[0]
+        dists[ad] = axes[ad] - axes[ad][0]
+        W = multi_interpolant(Xa, axes[ad])
+        interp[ad] = (W, W.transpose().tocsr())
+    out = dict(D=D, Q=Q, ranks=np.array(ranks), lens=np.array(lens), noise=noise, y=y,
+               kdesc=np.array(['%s;%s' % (k, p) for k, p, _ in kinfo]),
+               kad=np.array([ad[0] for _, _, ad in kinfo]))
+    for q in range(Q):
+        out[f'A{q}'], out[f'kappa{q}'] = coreg_vecs[q], coreg_diags[q]
+    for d in range(D):
+        out[f'X{d}'] = Xs[d]
+    for ad in spec.active_dims:
+        tag = str(ad[0])
+        W, WT = interp[ad]
+        out['grid' + tag] = axes[ad]
+        out['W%s_indptr' % tag], out['W%s_indices' % tag], out['W%s_data' % tag] = (
+            W.indptr, W.indices, W.data)
+    K, _ = gen_grid_kernel(spec, dists, interp, lens)
+    xx = rng.randn(3, n)
+    out['full_x'] = xx
+    out['full_mv'] = np.array([K.matvec(v) for v in xx])
+    rs = rng.randint(0, 2, (6, n)) * 2 - 1
+    out['rs'] = rs
+    Kd = K.as_numpy()
+    Kd = 0.5 * (Kd + Kd.T)
+    out['K_dense'] = Kd
+    c = la.cho_factor(Kd)
+    alpha = la.cho_solve(c, y)
+    inv_rs = la.cho_solve(c, rs.T.astype(float)).T
+    out['alpha_dense'], out['inv_rs_dense'] = alpha, inv_rs
+    out['logdet_dense'] = 2 * np.sum(np.log(np.diag(c[0])))
+
+    class _FixedDeriv:
+        def generate(self, K_, y_):
+            return StochasticDeriv(alpha, rs, inv_rs, len(rs))
+
+    lik = ApproxLMCLikelihood(spec, K, dists, interp, Ys, _FixedDeriv())
+    gv, gd = lik.coreg_vec_gradients(), lik.coreg_diags_gradients()
+    gkk, gn = lik.kernel_gradients(), lik.noise_gradient()
+    for q in range(Q):
+        out[f'grad_A{q}'], out[f'grad_kappa{q}'] = gv[q], gd[q]
+        out[f'grad_kern{q}'] = np.array(gkk[q])
+    out['grad_noise'] = gn
+    s0 = Iterative.solve(K, y, verbose=True, minres=True, tol=1e-4)
+    out['ref_minres_x'], out['ref_minres_iters'], out['ref_minres_err'] = (
+        s0[0], np.array(s0[1]), np.array(s0[2]))
+    _save('lmc_split.npz', **out)
 
 
 if __name__ == '__main__':

@@ -494,3 +494,55 @@ def check_unsorted_inputs():
         xo, ito, erro, _ = iterative_solve(op.matvec, B[i], tol=1e-4)
         assert abs(int(iters[i]) - ito) <= max(3, ito // 10)
         _close(Xs[i], xo, rel=1e-4)
+
+
+def check_split_kernels():
+    """Kernels on two different active-dimension sets (two grids, two
+    interpolants, ONE device handle): product, solve and gradients against the
+    reference's outputs for the same model."""
+    import scipy.sparse
+    g = np.load(os.path.join(GOLDEN, 'lmc_split.npz'))
+    D, Q = int(g['D']), int(g['Q'])
+    lens = [int(v) for v in g['lens']]
+    n = sum(lens)
+    kerns = []
+    for desc, ad in zip(g['kdesc'], g['kad']):
+        k = _kernel(desc)
+        k.active_dims = [int(ad)]
+        kerns.append(k)
+    fk = FunctionalKernel(D=D, lmc_kernels=kerns, lmc_ranks=[int(r) for r in g['ranks']])
+    fk.coreg_vecs = [g[f'A{q}'] for q in range(Q)]
+    fk.coreg_diags = [g[f'kappa{q}'] for q in range(Q)]
+    fk.noise = g['noise']
+    fk.set_input_dim(2)
+    assert sorted(fk.active_dims) == [(0,), (1,)]
+    dists, interp = {}, {}
+    for ad in fk.active_dims:
+        tag = str(ad[0])
+        grid = g['grid' + tag]
+        dists[ad] = grid - grid[0]
+        W = scipy.sparse.csr_matrix(
+            (g['W%s_data' % tag], g['W%s_indices' % tag], g['W%s_indptr' % tag]),
+            shape=(n, D * len(grid)))
+        interp[ad] = (W, W.transpose().tocsr())
+    K, gks = gen_grid_kernel(fk, dists, interp, lens)
+    assert len(K.Ks) == 3 and isinstance(K.Ks[-1], Diag)
+    _close(K.matmat(g['full_x'].T).T, g['full_mv'])
+    # noise-free terms + noise = the whole operator
+    x = g['full_x'][0]
+    parts = sum(gk.matvec(x) for gk in gks.values()) + K.Ks[-1].matvec(x)
+    _close(parts, g['full_mv'][0])
+    Kd = K.as_numpy()
+    _close(0.5 * (Kd + Kd.T), g['K_dense'])
+    Ys = np.split(g['y'], np.cumsum(lens)[:-1])
+    X1, it1, err1 = Iterative.solve(K, g['y'], verbose=True, tol=1e-4)
+    _close(X1, g['alpha_dense'], rel=1e-5)
+    assert abs(it1 - int(g['ref_minres_iters'])) <= 3
+    fixed = _FixedDeriv(g['alpha_dense'], g['rs'], g['inv_rs_dense'], K.device)
+    lik = ApproxLMCLikelihood(fk, K, dists, interp, Ys, fixed)
+
+    class _C:           # adaptor for _compare_grads
+        pass
+    c = _C()
+    c.Q, c.g = Q, g
+    _compare_grads(lik, c, rel=1e-9)

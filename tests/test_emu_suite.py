@@ -111,3 +111,7 @@ def test_embedding_lengths(D, Q, m, nvec):
 
 def test_unsorted_inputs():
     ps.check_unsorted_inputs()
+
+
+def test_split_kernels():
+    ps.check_split_kernels()

@@ -82,3 +82,7 @@ def test_model_optimize():
 
 def test_unsorted_inputs():
     ps.check_unsorted_inputs()
+
+
+def test_split_kernels():
+    ps.check_split_kernels()
