@@ -546,3 +546,39 @@ def check_split_kernels():
     c = _C()
     c.Q, c.g = Q, g
     _compare_grads(lik, c, rel=1e-9)
+
+
+def check_ragged_and_empty_outputs():
+    """Outputs of very different sizes, one of them with no data at all, and a
+    batch of one / an odd batch (the pair packing's lone vector)."""
+    from runlmc_amd.approx.interpolation import autogrid, multi_interpolant
+    from oracle.kernels import KernelSpec, RBFSpec
+    rng = np.random.RandomState(21)
+    lens = [37, 0, 5]
+    D = len(lens)
+    Xs = [rng.rand(n, 1) for n in lens]
+    Ys = [rng.randn(n) for n in lens]
+    grid = autogrid([X for X in Xs if len(X)], None, None, np.array([20.0]))[0]
+    W = multi_interpolant(Xs, grid)
+    WT = W.transpose().tocsr()
+    assert W.shape == (sum(lens), D * len(grid))
+    fk = FunctionalKernel(D=D, lmc_kernels=[RBF(3.0), RBF(30.0)], lmc_ranks=[1, 2])
+    fk.set_input_dim(1)
+    ad = (0,)
+    dists = grid - grid[0]
+    K, gks = gen_grid_kernel(fk, {ad: dists}, {ad: (W, WT)}, lens)
+    spec = KernelSpec(D, [RBFSpec(3.0), RBFSpec(30.0)], fk.coreg_vecs, fk.coreg_diags,
+                      fk.noise)
+    spec.set_input_dim(1)
+    op = olik.LMCOperatorOracle(spec, dists, W, WT, lens)
+    for k in (1, 3):
+        X = rng.randn(k, sum(lens))
+        _close(K.matmat(X.T).T, np.array([op.matvec(v) for v in X]))
+    y = np.hstack(Ys)
+    x, it, err = Iterative.solve(K, y, verbose=True)
+    assert err <= 1e-4 and np.linalg.norm(y - op.matvec(x)) <= 2e-4
+    svc = StochasticDerivService(None, None, 3, 1e-4)
+    probes = rng.randint(0, 2, (3, sum(lens))) * 2 - 1
+    lik = ApproxLMCLikelihood(fk, K, {ad: dists}, {ad: (W, WT)}, Ys, svc, probes=probes)
+    assert lik.noise_gradient().shape == (D,) and np.all(np.isfinite(lik.noise_gradient()))
+    assert lik.noise_gradient()[1] == 0.0        # no data, no gradient

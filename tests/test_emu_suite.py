@@ -115,3 +115,7 @@ def test_unsorted_inputs():
 
 def test_split_kernels():
     ps.check_split_kernels()
+
+
+def test_ragged_and_empty_outputs():
+    ps.check_ragged_and_empty_outputs()
