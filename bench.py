@@ -297,7 +297,7 @@ def main():
         # the configured batch (N+1 vectors) is latency-bound on a chip this
         # size; larger batches show what the same kernels sustain
         sweep = {}
-        for b in (64, 256, 1024):
+        for b in (64, 256, 1024, 4096):
             if b * D * p.m * 8 * 2 > 4e9:
                 continue
             Xb = torch.randn(b, D * p.m, dtype=torch.float64, device=dev)
@@ -305,7 +305,9 @@ def main():
             _, ms = time_grid_mvm(g, Xb, Yb, max(3, args.steps // 10), 2, 1)
             ab = synth.algorithmic_bytes_grid_mvm(D, Q, p.m, g.L, b)
             sweep[str(b)] = {'mvm_per_s': b / (ms * 1e-3),
-                             'roofline_frac': ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             'roofline_frac': ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             'path': 'on-chip' if g.onchip[0] and b >= g.onchip[1]
+                             else 'three-kernel'}
         out['batch_sweep'] = sweep
 
     if not args.no_nll:

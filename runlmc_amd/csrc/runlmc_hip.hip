@@ -12,6 +12,7 @@
 
 #include "rl_kernels.h"
 #include "rl_kernels2.h"
+#include "rl_kernels4.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -219,6 +220,15 @@ struct rl_gridop {
     size_t T_pairs = 0;
     size_t chunk_pairs = 1;
     size_t xcd_pairs = 0;   // pairs per XCD-affine chunk (0: affinity off)
+    // on-chip product (rl_kernels4.h): available for short 1-D grids, used for
+    // batches of at least v4_min vectors
+    bool v4 = false;
+    Plan4 p4;
+    int ep4 = 0, thr4 = 0, v4_min = 0, cus4 = 1;
+    size_t lds4 = 0;
+    double* spec4 = nullptr;   // dev [max_tops][2H + 1] (rl_kernels4.h)
+    cplx *tw4A = nullptr, *tw4B = nullptr, *tw4lo = nullptr, *tw4hi = nullptr, *untw4 = nullptr;
+    int *freq4A = nullptr, *pos4 = nullptr;
 };
 
 static size_t lds_cols(const rl_gridop* g) {
@@ -282,6 +292,171 @@ static void set_lds_attrs() {
     set_lds_attr_rows<13>(); set_lds_attr_rows<14>(); set_lds_attr_rows<15>();
     set_lds_attr_rows<16>();
 #endif
+}
+
+
+static unsigned div_magic(unsigned d);
+
+// ---------------------------------------------------------------------------
+// on-chip product plan (rl_kernels4.h): N = L / 2 = Na x Nb inside LDS
+// ---------------------------------------------------------------------------
+template <int D, int EP>
+static void set_lds_attr4() {
+#if !defined(RL_EMU)
+    (void)hipFuncSetAttribute((const void*)k4_product<D, EP>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+}
+
+// the (D, EP) instantiations: 8 * D * EP VGPRs hold the half spectra
+#define RL_V4_MAX_DEP 12
+#define RL_V4_MAX_D 6
+#define RL_V4_MAX_EP 3
+#define RL_V4_FOR_EP(M, d)                                                     \
+    if constexpr (d <= RL_V4_MAX_D) { M(d, 1) }                                \
+    if constexpr (d <= RL_V4_MAX_D && d * 2 <= RL_V4_MAX_DEP) { M(d, 2) }      \
+    if constexpr (d <= RL_V4_MAX_D && d * 3 <= RL_V4_MAX_DEP) { M(d, 3) }
+
+template <int D>
+static int launch4_d(int ep, dim3 grid, dim3 block, size_t lds, hipStream_t st, const double* X,
+                     double* Y, int nvec, const Geom& geo, int mode, const Plan4& pl,
+                     const MixParams& mp, double* spec_out) {
+#define RL_M(d, e)                                                                       \
+    if (ep == e) {                                                                       \
+        set_lds_attr4<d, e>();                                                           \
+        RL_LAUNCH((k4_product<d, e>), grid, block, lds, st, X, Y, nvec, geo, mode, pl,   \
+                  mp, spec_out);                                                         \
+        return RL_OK;                                                                    \
+    }
+    RL_V4_FOR_EP(RL_M, D)
+#undef RL_M
+    return fail(RL_ELIMIT, "on-chip product: no instantiation");
+}
+
+static int launch4(int D, int ep, dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                   const double* X, double* Y, int nvec, const Geom& geo, int mode,
+                   const Plan4& pl, const MixParams& mp, double* spec_out) {
+    switch (D) {
+#define RL_CASE(d) \
+    case d: return launch4_d<d>(ep, grid, block, lds, st, X, Y, nvec, geo, mode, pl, mp, spec_out);
+        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
+        RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
+        RL_CASE(14) RL_CASE(15) RL_CASE(16)
+#undef RL_CASE
+        default: return fail(RL_ELIMIT, "unsupported D");
+    }
+}
+
+// radix schedule for the on-chip product: odd factors first, then the power of
+// two in as few passes of radix <= 8 as possible, no radix 2 unless forced
+static FftPlan make_plan4(int n) {
+    FftPlan p;
+    p.n = n;
+    p.npass = 0;
+    for (int i = 0; i < RL_MAX_PASSES; ++i) p.radix[i] = 1;
+    int rem = n;
+    for (int odd : {3, 5})
+        while (rem % odd == 0 && p.npass < 2) {
+            p.radix[p.npass++] = odd;
+            rem /= odd;
+        }
+    const int l = ilog2(rem);
+    if (l == 1) {
+        p.radix[p.npass++] = 2;
+    } else if (l > 1) {
+        const int np = (l + 2) / 3;
+        int extra = 3 * np - l;          // passes that are radix 4 instead of 8
+        for (int i = 0; i < np; ++i) p.radix[p.npass++] = (i >= np - extra) ? 4 : 8;
+    }
+    return p;
+}
+
+static int plan4_create(rl_gridop* g) {
+    g->v4 = false;
+    if (g->geo.m1 != 0 || (g->L & 7) || g->D > RL_V4_MAX_D || getenv("RUNLMC_NO_V4"))
+        return RL_OK;
+    const int H = g->L / 4, pairs = H / 2 + 1;
+    if (H < 32) return RL_OK;
+    // smallest workgroup whose threads can hold the half spectra
+    int thr = 64, ep = 0;
+    for (; thr <= RL_THREADS4; thr *= 2) {
+        ep = (pairs + thr - 1) / thr;
+        if (ep <= RL_V4_MAX_EP && g->D * ep <= RL_V4_MAX_DEP) break;
+    }
+    if (thr > RL_THREADS4) return RL_OK;
+    // split with the cheapest pass schedule: sum over passes of
+    // (rounds of butterflies per thread) x (cost of one butterfly)
+    auto bf_cost = [](int r) {
+        switch (r) { case 2: return 10; case 3: return 30; case 4: return 34; case 5: return 74;
+                     case 8: return 106; default: return 260; }
+    };
+    int bestNb = 0;
+    long bestCost = 0;
+    for (int nb = 4; nb <= 512 && nb * 2 <= H; nb *= 2) {
+        if (H % nb) break;
+        const int na = H / nb;
+        if ((size_t)na * (nb | 1) * sizeof(cplx) > kLdsHard) continue;
+        const FftPlan pa = make_plan4(na), pb = make_plan4(nb);
+        long cost = 0;
+        for (int s = 0; s < pa.npass; ++s)
+            cost += (long)(((na / pa.radix[s]) * nb + thr - 1) / thr) * bf_cost(pa.radix[s]) + 40;
+        for (int s = 0; s < pb.npass; ++s)
+            cost += (long)(((nb / pb.radix[s]) * na + thr - 1) / thr) * bf_cost(pb.radix[s]) + 40;
+        if (bestNb == 0 || cost < bestCost) { bestNb = nb; bestCost = cost; }
+    }
+    if (!bestNb) return RL_OK;
+    Plan4& pl = g->p4;
+    pl.N = H;
+    pl.Nb = bestNb;
+    pl.Na = H / bestNb;
+    pl.ld = pl.Nb | 1;
+    pl.planA = make_plan4(pl.Na);
+    pl.planB = make_plan4(pl.Nb);
+    pl.magicNa = div_magic((unsigned)pl.Na);
+    pl.magicNb = div_magic((unsigned)pl.Nb);
+    const std::vector<int> fa = position_to_freq(pl.planA), fb = position_to_freq(pl.planB);
+    std::vector<int> inva(pl.Na), invb(pl.Nb), pos(H);
+    for (int r = 0; r < pl.Na; ++r) inva[fa[r]] = r;
+    for (int c = 0; c < pl.Nb; ++c) invb[fb[c]] = c;
+    for (int k = 0; k < H; ++k) pos[k] = inva[k % pl.Na] * pl.ld + invb[k / pl.Na];
+    int rc;
+    if ((rc = upload(&g->tw4A, unity_table(pl.Na, 1, pl.Na))) != RL_OK) return rc;
+    if ((rc = upload(&g->tw4B, unity_table(pl.Nb, 1, pl.Nb))) != RL_OK) return rc;
+    const int shift = ilog2(H) / 2;
+    pl.nlo = 1 << shift;
+    pl.nhi = (int)(((long)H + (1L << shift) - 1) >> shift);
+    if ((rc = upload(&g->tw4lo, unity_table(pl.nlo, 1, H))) != RL_OK) return rc;
+    if ((rc = upload(&g->tw4hi, unity_table(pl.nhi, 1L << shift, H))) != RL_OK) return rc;
+    if ((rc = upload(&g->untw4, unity_table(H + 1, 1, g->L))) != RL_OK) return rc;
+    if ((rc = upload(&g->freq4A, fa)) != RL_OK) return rc;
+    if ((rc = upload(&g->pos4, pos)) != RL_OK) return rc;
+    RL_HIP(hipMalloc((void**)&g->spec4, (size_t)g->max_tops * (2 * H + 1) * sizeof(double)));
+    pl.twA = g->tw4A;
+    pl.twB = g->tw4B;
+    pl.freqA = g->freq4A;
+    pl.twN.lo = g->tw4lo;
+    pl.twN.hi = g->tw4hi;
+    pl.twN.shift = shift;
+    pl.twN.mask = (1 << shift) - 1;
+    pl.pos = g->pos4;
+    pl.wl = g->untw4;
+    g->ep4 = ep;
+    g->thr4 = thr;
+    g->lds4 = plan4_lds_bytes(pl);
+    if (g->lds4 > kLdsHard) return RL_OK;
+    {
+        hipDeviceProp_t prop;
+        RL_HIP(hipGetDeviceProperties(&prop, g->device));
+        g->cus4 = std::max(1, prop.multiProcessorCount);
+    }
+    // OFF unless asked for (RUNLMC_V4_MIN=<batch>): measured on MI355X at C2 it
+    // sustains 1.5 M MVM/s against 2.5 M for the three-kernel path -- it issues
+    // 124 k VALU wave-instructions per vector (real-input untangling, two
+    // phases, radix <= 8) against 60 k, at two waves per SIMD
+    g->v4_min = 1 << 30;
+    if (const char* e = getenv("RUNLMC_V4_MIN")) g->v4_min = std::max(1, atoi(e));
+    g->v4 = true;
+    return RL_OK;
 }
 
 #define RL_MAX_D 16
@@ -426,6 +601,8 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
         const size_t ppx = (size_t)(l2_mb * 1048576.0) / per_pair;
         g->xcd_pairs = ppx >= 1 ? 8 * ppx : 0;
     }
+
+    if ((rc = plan4_create(g)) != RL_OK) return rc;
     *out = guard.release();
     return RL_OK;
 }
@@ -434,7 +611,9 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     if (!g) return RL_OK;
     (void)hipSetDevice(g->device);
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
-                    g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T};
+                    g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
+                    g->spec4, g->tw4A, g->tw4B, g->tw4lo, g->tw4hi, g->untw4, g->freq4A,
+                    g->pos4};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -452,6 +631,18 @@ extern "C" int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int*
     return RL_OK;
 }
 
+extern "C" int rl_gridop_onchip_info(const rl_gridop* g, int* available, int* min_batch, int* Na,
+                                     int* Nb, int* slots, int* threads) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (available) *available = g->v4 ? 1 : 0;
+    if (min_batch) *min_batch = g->v4_min;
+    if (Na) *Na = g->v4 ? g->p4.Na : 0;
+    if (Nb) *Nb = g->v4 ? g->p4.Nb : 0;
+    if (slots) *slots = g->ep4;
+    if (threads) *threads = g->thr4;
+    return RL_OK;
+}
+
 // spectra of tops [0, ntop) -> g->spec, on `stream`
 static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     const int npairs = (ntop + 1) / 2;
@@ -464,6 +655,11 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     dim3 gridS(g->N1 / g->rowsS, npairs);
     RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
               g->spec, ntop, g->N1, g->N2, g->rowsS, g->plan2, g->tw2);
+    if (g->v4) {
+        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        RL_TRY(launch4(1, g->ep4, dim3(ntop), dim3(g->thr4), g->lds4, stream, g->tops, nullptr,
+                       ntop, g->geo, 1, g->p4, none, g->spec4));
+    }
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -718,6 +914,19 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_HIP(hipSetDevice(g->device));
+    if (g->v4 && nvec >= g->v4_min) {
+        // the whole product on chip, one workgroup per vector
+        MixParams mp4 = mp;
+        mp4.spec = g->spec4 + (size_t)((mp.spec - g->spec) / g->L) * (2 * g->p4.N + 1);
+        // persistent workgroups: as many as can be resident, each walks vectors
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(kLdsHard / g->lds4,
+                                                                    2048 / (4 * g->thr4)));
+        const unsigned nwg = (unsigned)std::min<size_t>((size_t)nvec, per_cu * g->cus4);
+        RL_TRY(launch4(g->D, g->ep4, dim3(nwg), dim3(g->thr4), g->lds4, stream, X, Y, nvec,
+                       g->geo, 0, g->p4, mp4, nullptr));
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
     const size_t total_pairs = ((size_t)nvec + 1) / 2;
     size_t chunk = std::min(total_pairs, g->chunk_pairs);
     if (g->v2 && g->xcd_pairs > 0 && total_pairs >= 16) chunk = std::min(chunk, g->xcd_pairs);

@@ -252,6 +252,10 @@ hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 hipError_t hipSetDevice(int d) { g_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = g_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int) {
+    prop->multiProcessorCount = 2;   // few "compute units": exercises the persistent loops
+    return hipSuccess;
+}
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }

@@ -57,6 +57,10 @@ hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t s);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceCount(int* n);
+struct hipDeviceProp_t {
+    int multiProcessorCount;
+};
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int device);
 hipError_t hipDeviceSynchronize();
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipGetLastError();

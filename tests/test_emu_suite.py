@@ -119,3 +119,7 @@ def test_split_kernels():
 
 def test_ragged_and_empty_outputs():
     ps.check_ragged_and_empty_outputs()
+
+
+def test_onchip_product():
+    ps.check_onchip_product()
