@@ -301,7 +301,10 @@ __global__ void __launch_bounds__(RL_THREADS)
 k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
        const double* __restrict__ vals, int nrows, int ncols, int nvec,
        const double* __restrict__ X, double* __restrict__ Y, const double* __restrict__ diag,
-       const double* __restrict__ X2, int accumulate) {
+       const double* __restrict__ X2, int accumulate, int* __restrict__ bump) {
+    // the solver's round counter: advanced by the first kernel of a round's
+    // operator product (nothing in this kernel reads it)
+    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     const int v0 = blockIdx.y * RL_SPMV_VB;
     if (row >= nrows) return;
@@ -310,8 +313,34 @@ k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
 #pragma unroll
     for (int j = 0; j < RL_SPMV_VB; ++j) acc[j] = 0.0;
     const double* x = X + (size_t)v0 * ncols;
-    const int k1 = indptr[row + 1];
-    for (int k = indptr[row]; k < k1; ++k) {
+    const int kb = indptr[row], k1 = indptr[row + 1];
+    // the first NZ entries of the row are requested together (interpolation
+    // rows have 4): entries -> gathered values is a dependent chain per entry,
+    // and small batches are bound by exactly that latency
+    constexpr int NZ = 4;
+    // (unconditional loads from clamped indices, masked afterwards: a
+    // conditional load is a branch with a full memory wait behind it)
+    const int nnz = indptr[nrows];
+    const int last = nnz > 0 ? nnz - 1 : 0;
+    double wa[NZ];
+    int wc[NZ];
+#pragma unroll
+    for (int e = 0; e < NZ; ++e) {
+        const int k = kb + e < last ? kb + e : last;
+        const double a = vals[k];
+        wc[e] = indices[k];
+        wa[e] = kb + e < k1 ? a : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < RL_SPMV_VB; ++j) {
+        const int jj = j < nv ? j : 0;
+        double xv[NZ];
+#pragma unroll
+        for (int e = 0; e < NZ; ++e) xv[e] = x[(size_t)jj * ncols + wc[e]];
+#pragma unroll
+        for (int e = 0; e < NZ; ++e) acc[j] = fma(wa[e], xv[e], acc[j]);
+    }
+    for (int k = kb + NZ; k < k1; ++k) {
         const double a = vals[k];
         const double* xc = x + indices[k];
 #pragma unroll

@@ -34,6 +34,19 @@ struct Tile2 {
     int thrC, thrR;     // workgroup sizes of the column / row kernels
 };
 
+// Optional fused W^T product in front of the column transforms (batched
+// solves of small systems, where W^T x as a kernel of its own costs a launch
+// and a round trip): the grid vector is never materialised, k2_cols_fwd
+// gathers  g[row] = sum_k WT[row, k] v[col_k]  while it loads.
+struct Gather {
+    const int* indptr;      // NULL: plain load from X
+    const int* indices;
+    const double* vals;
+    const double* src;      // [nvec][n] data-space vectors
+    int n;                  // entries per data-space vector
+    int nnz;                // entries of the CSR (for clamping)
+};
+
 // (pair, tile-within-pair) of this workgroup; false if it is launch padding
 __device__ __forceinline__ bool xcd_slot(const Tile2& tp, int tiles_per_pair, int* pair,
                                          int* tile) {
@@ -68,14 +81,15 @@ __device__ __forceinline__ void middle_adjoint(cplx* tile, const FftPlan& plan, 
 }
 
 // ---------------------------------------------------------------------------
-// k2_cols_fwd<RA, RB>: as k_cols_fwd.  grid (N2 / C, D, npairs)
+// k2_cols_fwd<RA, RB, GATHER>: as k_cols_fwd (GATHER: with the W^T product
+// fused into the load, see Gather).  grid (N2 / C, D, npairs)
 // LDS: tile [N1][C]
 // ---------------------------------------------------------------------------
-template <int RA, int RB>
+template <int RA, int RB, bool GATHER>
 __global__ void __launch_bounds__(RL_THREADS2)
 k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
             cplx* __restrict__ T, Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1,
-            const int* __restrict__ freq1, TwiddleL twl) {
+            const int* __restrict__ freq1, TwiddleL twl, Gather gs) {
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -96,18 +110,89 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
     const bool has1 = v1 < nvec;
     const int sub = N1 / RA;
 
+    // fused W^T: the two data-space vectors of this pair
+    const double* d0 = nullptr;
+    const double* d1 = nullptr;
+    if (GATHER) {
+        d0 = gs.src + (size_t)v0 * gs.n;
+        d1 = has1 ? gs.src + (size_t)v1 * gs.n : d0;     // loads stay unconditional
+    }
     for (int w = tid; w < sub * C; w += nthr) {
         const int c = w & (C - 1), j = w >> tp.logC;
         cplx v[RA];
+        if (!GATHER) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int src = padded_source(geo, j + sub * i, c0 + c, N1, N2, mode);
-            double re = 0.0, im = 0.0;
-            if (src >= 0) {
-                re = x0[src];
-                if (has1) im = x1[src];
+            for (int i = 0; i < RA; ++i) {
+                const int src = padded_source(geo, j + sub * i, c0 + c, N1, N2, mode);
+                double re = 0.0, im = 0.0;
+                if (src >= 0) {
+                    re = x0[src];
+                    if (has1) im = x1[src];
+                }
+                v[i] = c_make(re, im);
             }
-            v[i] = c_make(re, im);
+        } else {
+            // three dependent levels (row pointers -> entries -> data values),
+            // each requested for all RA legs before the next is touched; the
+            // first NZ entries of a row are unrolled, longer rows loop
+            // Every load below is UNCONDITIONAL (indices clamped to valid
+            // entries, results masked afterwards): a conditional load compiles
+            // to a branch with a full memory wait behind it, which serialises
+            // the very latencies this code is arranged to overlap.
+            constexpr int NZ = 4;
+            constexpr int CH = RA == 3 ? 3 : (RA == 5 ? 5 : 4);   // legs in flight together
+            const int last = gs.nnz > 0 ? gs.nnz - 1 : 0;
+#pragma unroll
+            for (int i0 = 0; i0 < RA; i0 += CH) {
+                int kb[CH], ke[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int src = padded_source(geo, j + sub * (i0 + i), c0 + c, N1, N2, 0);
+                    const int row = src >= 0 ? b * m + src : 0;
+                    const int p0 = gs.indptr[row], p1 = gs.indptr[row + 1];
+                    kb[i] = src >= 0 ? p0 : 0;
+                    ke[i] = src >= 0 ? p1 : 0;
+                }
+                double wa[CH][NZ];
+                int wc[CH][NZ];
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int e = 0; e < NZ; ++e) {
+                        const int k = kb[i] + e < last ? kb[i] + e : last;
+                        const double a = gs.vals[k];
+                        wc[i][e] = gs.indices[k];
+                        wa[i][e] = kb[i] + e < ke[i] ? a : 0.0;
+                    }
+                // data values of ALL legs of the chunk before any is used (the
+                // rare rows longer than NZ finish afterwards)
+                double g0[CH][NZ], g1[CH][NZ];
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int e = 0; e < NZ; ++e) {
+                        g0[i][e] = d0[wc[i][e]];
+                        g1[i][e] = d1[wc[i][e]];
+                    }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    double re = 0.0, im = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NZ; ++e) {
+                        re = fma(wa[i][e], g0[i][e], re);
+                        im = fma(wa[i][e], g1[i][e], im);
+                    }
+                    v[i0 + i] = c_make(re, has1 ? im : 0.0);
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    for (int k = kb[i] + NZ; k < ke[i]; ++k) {
+                        const double a = gs.vals[k];
+                        const int col = gs.indices[k];
+                        v[i0 + i].x = fma(a, d0[col], v[i0 + i].x);
+                        if (has1) v[i0 + i].y = fma(a, d1[col], v[i0 + i].y);
+                    }
+            }
         }
         SmallDft<RA, false>::run(v);
 #pragma unroll
@@ -246,7 +331,10 @@ __device__ __forceinline__ void mix_point(cplx* z, const MixParams& mp, size_t L
 template <int D, int RA, int RB>
 __global__ void __launch_bounds__(RL_THREADS2)
 k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restrict__ tw2,
-            const int* __restrict__ freq1, TwiddleL twl, MixParams mp) {
+            const int* __restrict__ freq1, TwiddleL twl, MixParams mp, int* __restrict__ bump) {
+    // the solver's round counter when W^T is fused into k2_cols_fwd (which reads
+    // it): advanced here, by a kernel that does not
+    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;

@@ -34,6 +34,11 @@ enum { I_ISTOP = 0, I_ITN, I_ACTIVE, I_NFIELDS };
 #define RL_ISTOP_RESIDUAL 10   // reference rule: ||b - A x|| < tol at a check
 #define RL_ISTOP_ZERO_RHS 11
 
+// Deterministic block sums.  On the GPU: shuffles inside each wavefront (no
+// barrier), one partial per wavefront through LDS, every thread adds the few
+// partials in order.  (The emulator build has no cross-lane operations: plain
+// LDS tree there.)  `red` needs blockDim.x doubles (2 blockDim.x for the pair).
+#if defined(RL_EMU)
 __device__ __forceinline__ double block_reduce_sum(double v, double* red) {
     const int tid = threadIdx.x;
     red[tid] = v;
@@ -45,6 +50,70 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* red) {
     const double r = red[0];
     __syncthreads();
     return r;
+}
+__device__ __forceinline__ void block_reduce_sum2(double& a, double& b, double* red) {
+    a = block_reduce_sum(a, red);
+    b = block_reduce_sum(b, red);
+}
+#else
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;       // valid in lane 0
+}
+__device__ __forceinline__ double block_reduce_sum(double v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void block_reduce_sum2(double& a, double& b, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const double sa = wave_sum(a), sb = wave_sum(b);
+    if (lane == 0) {
+        red[wave] = sa;
+        red[nw + wave] = sb;
+    }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0;
+    for (int i = 0; i < nw; ++i) {
+        ra += red[i];
+        rb += red[nw + i];
+    }
+    __syncthreads();
+    a = ra;
+    b = rb;
+}
+#endif
+
+// sums of two partial arrays of one system, every thread gets both: one load
+// per thread and a block reduction instead of nblk dependent adds per thread
+// (nblk <= blockDim.x).  Every workgroup of a system computes bit-identical
+// sums (same data, same order).
+__device__ __forceinline__ void sum2_partials(const double* pa, const double* pb, int nblk,
+                                              double* red, double* sa, double* sb) {
+    double a = 0.0, b = 0.0;
+    if ((int)threadIdx.x < nblk) {
+        if (pa != nullptr) a = pa[threadIdx.x];
+        if (pb != nullptr) b = pb[threadIdx.x];
+    }
+    block_reduce_sum2(a, b, red);
+    *sa = a;
+    *sb = b;
+}
+
+// sqrt(a^2 + b^2) without the libm call (scaled: no spurious overflow)
+__device__ __forceinline__ double hypot2(double a, double b) {
+    a = fabs(a);
+    b = fabs(b);
+    const double t = a > b ? a : b;
+    if (t == 0.0) return 0.0;
+    const double u = a / t, v = b / t;
+    return t * sqrt(fma(u, u, v * v));
 }
 
 __device__ __forceinline__ double sum_partials(const double* p, int nblk) {
@@ -378,6 +447,414 @@ k_minres_test(MinresBufs mb, const double* __restrict__ partialC, int nblk, int 
     }
     __syncthreads();
     if (threadIdx.x == 0) *mb.giter = it0 + 1;
+}
+
+// ---- MINRES, two kernels per round -------------------------------------------
+// The same recurrences arranged so that one round needs only the operator
+// product and TWO vector kernels, and no normalised Lanczos vector is ever
+// stored.  With y_j the unnormalised Lanczos vectors (y_0 = b, beta_{j+1} =
+// ||y_j||, v_j = y_{j-1} / beta_j) the operator is applied to y_{k-1} itself
+// and the 1/beta_k is folded into the consumers (the operator is linear).
+// Round r (r = 1, 2, ...; q' = A y_{r-1} has just been computed):
+//   P_r : if r >= 2, FINISH iteration k = r - 1 (its alfa_k came out of P_{r-1},
+//         its beta_{k+1} out of B_{r-1}): plane rotation scalars, w_k, x_k,
+//         partial ||x_k||^2 -- then START iteration r:
+//         y' = q' / beta_r - (beta_r / beta_{r-1}) y_{r-2},  partial alfa_r = v_r . y'
+//   B_r : if r >= 2, SciPy's stopping tests for iteration k = r - 1 (they need
+//         ||x_k||); for systems that go on: y_r = y' - (alfa_r / beta_r) y_{r-1},
+//         partial beta_{r+1}^2.
+// Every rotating role has period two (the new y overwrites y_{r-2} in place, its
+// last reader is the thread that writes it), so the parity of the round is a
+// kernel ARGUMENT: a captured graph of an even number of rounds always starts
+// at the same parity, and no kernel needs a memory round trip to find its
+// buffers.  The round NUMBER (stopping tests, Lanczos index) is read from a
+// counter advanced by the first kernel of the round's operator product.
+// A system that stops at iteration k is frozen by B_{k+1}: x_k is already
+// final, the started iteration k + 1 is abandoned (one operator product more
+// than the textbook order, once per solve).  Iterates, iteration counts and
+// exit codes are SciPy's.
+//   optional fusion: q' = W g + eps (.) y_{r-1} computed row by row inside P
+//   from the grid vector g (CSR W), so that the W product needs no kernel.
+struct Minres2Bufs {
+    double* tri[2];     // ping-pong: y_{r-2} (overwritten in place by the new y), y_{r-1}
+    double* w[2];
+    double* q;          // operator output (unfused), scratch of the checks
+    double* x;
+    double* vcopy;      // non-NULL: B also copies the new y here (operator input
+                        // of the unfused product, which cannot follow the rotation)
+    double* S[2];
+    int* I;
+    int* giter;         // number of the current round: bumped by the first kernel of the
+                        // round's operator product (which does not read it)
+    double* partA[2];
+    double* partB;
+    double* partC;
+    double* lanczos;
+    int lanczos_cap;
+    // fused W product (W_indptr != NULL): q'[i] = sum_k W[i, k] g[col_k] + eps[i] y_{r-1}[i]
+    const int* W_indptr;
+    const int* W_indices;
+    const double* W_data;
+    int W_nnz;
+    const double* g;        // [nrhs][ngrid]
+    const double* eps;      // [n] or NULL
+    int ngrid;
+};
+
+// init: x = 0, y_{-1} unused, y_0 = b, w = 0; partial = b.b from k_dot_partial(b, b)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
+               Minres2Bufs mb) {
+    const int rhs = blockIdx.y;
+    const int nblk = gridDim.x;
+    const double bb = sum_partials(partial + (size_t)rhs * nblk, nblk);
+    const double beta1 = sqrt(bb);
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double bi = b[off + i];
+        mb.x[off + i] = 0.0;
+        mb.tri[0][off + i] = 0.0;      // y_{-1}: only ever multiplied by zero
+        mb.tri[1][off + i] = bi;       // y_0
+        mb.w[0][off + i] = 0.0;
+        mb.w[1][off + i] = 0.0;
+        if (mb.vcopy != nullptr) mb.vcopy[off + i] = bi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int c = 0; c < 2; ++c) {
+            double* st = mb.S[c] + (size_t)rhs * S_NFIELDS;
+            for (int f = 0; f < S_NFIELDS; ++f) st[f] = 0.0;
+            st[S_BETA1] = beta1;
+            st[S_BETA] = beta1;
+            st[S_PHIBAR] = beta1;
+            st[S_RHS1] = beta1;
+            st[S_GMIN] = 1.7976931348623157e308;
+            st[S_CS] = -1.0;
+            st[S_BNORM] = beta1;
+        }
+        int* it = mb.I + rhs * I_NFIELDS;
+        it[I_ITN] = 0;
+        it[I_ISTOP] = beta1 > 0.0 ? 0 : RL_ISTOP_ZERO_RHS;
+        it[I_ACTIVE] = beta1 > 0.0 ? 1 : 0;
+        if (rhs == 0) *mb.giter = 0;
+    }
+}
+
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres2_p(Minres2Bufs mb, int n, int par) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    const int nblk = gridDim.x;
+    const int p2 = par;                     // (round - 1) & 1, from the host
+    const double* si = mb.S[p2] + (size_t)rhs * S_NFIELDS;
+    double* so = mb.S[1 - p2] + (size_t)rhs * S_NFIELDS;
+    if (!mb.I[rhs * I_NFIELDS + I_ACTIVE]) {
+        // keep the two copies identical for frozen systems
+        if (blockIdx.x == 0 && threadIdx.x < S_NFIELDS) so[threadIdx.x] = si[threadIdx.x];
+        return;
+    }
+    double* r1 = mb.tri[p2];                // y_{r-2}; receives the new y
+    const double* r2 = mb.tri[1 - p2];      // y_{r-1}
+    double* y = r1;
+    double* w1 = mb.w[p2];
+    const double* w2 = mb.w[1 - p2];
+    const double eps = 2.220446049250313e-16;
+    const int round = *mb.giter;            // a number, not an address: off the critical path
+    const bool fin = round >= 2;            // there is an iteration to finish
+
+    // Every operand that does not depend on the scalars is requested FIRST (the
+    // scalar chain below -- partial sums, square roots -- is a long dependent
+    // sequence; the vector loads then overlap it).  PF rows per thread cover
+    // n <= PF * 256 * gridDim.x; longer systems loop.
+    constexpr int PF = 4;
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    const double* g = mb.W_indptr != nullptr ? mb.g + (size_t)rhs * mb.ngrid : nullptr;
+    double pr2[PF], pr1[PF], pq[PF], pw1[PF], pw2[PF], px[PF];
+    // the fused W rows: three dependent levels (row pointers -> entries -> grid
+    // values), each level requested for all PF rows before the next is touched;
+    // NZ entries per row are unrolled (cubic interpolation has 4), longer rows
+    // finish in a loop
+    constexpr int NZ = 4;
+    // (the partial sums of the iteration being finished: one load per thread,
+    // requested before everything else, reduced further down)
+    double part_a = 0.0, part_b = 0.0;
+    if ((int)threadIdx.x < nblk) {
+        part_a = mb.partA[p2][(size_t)rhs * nblk + threadIdx.x];
+        part_b = mb.partB[(size_t)rhs * nblk + threadIdx.x];
+    }
+    // (all loads unconditional, from clamped rows / entries, masked afterwards:
+    // a conditional load is a branch with a full memory wait behind it)
+    const int rlast = hi > lo ? hi - 1 : lo;       // lo < n: a valid row
+    const int elast = mb.W_nnz > 0 ? mb.W_nnz - 1 : 0;
+    int k0[PF], k1[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = lo + threadIdx.x + u * blockDim.x;
+        const int ic = i < hi ? i : rlast;
+        k0[u] = k1[u] = 0;
+        if (g != nullptr) {
+            const int a0 = mb.W_indptr[ic], a1 = mb.W_indptr[ic + 1];
+            k0[u] = i < hi ? a0 : 0;
+            k1[u] = i < hi ? a1 : 0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = lo + threadIdx.x + u * blockDim.x;
+        const int ic = i < hi ? i : rlast;
+        // (round 1 reads zeros for the finish operands: not waiting for the round number)
+        pr2[u] = r2[off + ic];
+        pr1[u] = r1[off + ic];
+        pw1[u] = w1[off + ic];
+        pw2[u] = w2[off + ic];
+        px[u] = mb.x[off + ic];
+        pq[u] = g == nullptr ? mb.q[off + ic] : 0.0;
+    }
+    if (g != nullptr) {
+        double wa[PF][NZ];
+        int wc[PF][NZ];
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                const int k = k0[u] + j < elast ? k0[u] + j : elast;
+                const double a = mb.W_data[k];
+                wc[u][j] = mb.W_indices[k];
+                wa[u][j] = k0[u] + j < k1[u] ? a : 0.0;
+            }
+        double gv[PF][NZ];
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) gv[u][j] = g[wc[u][j]];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = lo + threadIdx.x + u * blockDim.x;
+            const int ic = i < hi ? i : rlast;
+            double qi = mb.eps != nullptr ? mb.eps[ic] * pr2[u] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) qi = fma(wa[u][j], gv[u][j], qi);
+            pq[u] = qi;
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            for (int k = k0[u] + NZ; k < k1[u]; ++k)
+                pq[u] = fma(mb.W_data[k], g[mb.W_indices[k]], pq[u]);
+    }
+
+    // scalars of the iteration being finished (k = round - 1); statement by
+    // statement SciPy's (see k_minres_c)
+    double alfa = 0.0, beta = si[S_BETA], oldb = si[S_BETA];
+    double tnorm2 = 0.0, delta = 0.0, gbar = 0.0, epsln = 0.0, dbar = 0.0, root = 0.0;
+    double gamma = 1.0, cs = 0.0, sn = 0.0, phi = 0.0, phibar = 0.0, denom = 0.0, oldeps = 0.0;
+    block_reduce_sum2(part_a, part_b, red);
+    if (fin) {
+        alfa = part_a;
+        beta = sqrt(part_b > 0.0 ? part_b : 0.0);
+        tnorm2 = si[S_TNORM2] + alfa * alfa + oldb * oldb + beta * beta;
+        const double cs0 = si[S_CS], sn0 = si[S_SN], dbar0 = si[S_DBAR];
+        oldeps = si[S_EPSLN];
+        delta = cs0 * dbar0 + sn0 * alfa;
+        gbar = sn0 * dbar0 - cs0 * alfa;
+        epsln = sn0 * beta;
+        dbar = -cs0 * beta;
+        root = hypot2(gbar, dbar);
+        gamma = hypot2(gbar, beta);
+        gamma = gamma > eps ? gamma : eps;
+        cs = gbar / gamma;
+        sn = beta / gamma;
+        phi = cs * si[S_PHIBAR];
+        phibar = sn * si[S_PHIBAR];
+        denom = 1.0 / gamma;
+    }
+    // v_k = y_{k-1} / beta_k = r1 / oldb (finish);  v_r = r2 / beta (start)
+    const double oinv = oldb > 0.0 ? 1.0 / oldb : 0.0;
+    const double sinv = beta > 0.0 ? 1.0 / beta : 0.0;
+    const double coef = fin ? beta * oinv : 0.0;
+
+    double accA = 0.0, accC = 0.0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = lo + threadIdx.x + u * blockDim.x;
+        if (i < hi) {
+            if (fin) {
+                const double wn = (pr1[u] * oinv - oldeps * pw1[u] - delta * pw2[u]) * denom;
+                w1[off + i] = wn;
+                const double xi = px[u] + phi * wn;
+                mb.x[off + i] = xi;
+                accC = fma(xi, xi, accC);
+            }
+            const double yi = pq[u] * sinv - coef * pr1[u];
+            y[off + i] = yi;
+            accA = fma(pr2[u] * sinv, yi, accA);
+        }
+    }
+    for (int i = lo + threadIdx.x + PF * blockDim.x; i < hi; i += blockDim.x) {
+        const double r2i = r2[off + i];
+        double qi;
+        if (g != nullptr) {
+            qi = mb.eps != nullptr ? mb.eps[i] * r2i : 0.0;
+            const int k1 = mb.W_indptr[i + 1];
+            for (int k = mb.W_indptr[i]; k < k1; ++k) qi = fma(mb.W_data[k], g[mb.W_indices[k]], qi);
+        } else {
+            qi = mb.q[off + i];
+        }
+        double r1i = 0.0;
+        if (fin) {
+            r1i = r1[off + i];
+            const double wn = (r1i * oinv - oldeps * w1[off + i] - delta * w2[off + i]) * denom;
+            w1[off + i] = wn;
+            const double xi = mb.x[off + i] + phi * wn;
+            mb.x[off + i] = xi;
+            accC = fma(xi, xi, accC);
+        }
+        const double yi = qi * sinv - coef * r1i;
+        y[off + i] = yi;
+        accA = fma(r2i * sinv, yi, accA);
+    }
+    block_reduce_sum2(accA, accC, red);
+    if (threadIdx.x == 0) {
+        mb.partA[1 - p2][(size_t)rhs * nblk + blockIdx.x] = accA;
+        mb.partC[(size_t)rhs * nblk + blockIdx.x] = accC;
+    }
+
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int f = 0; f < S_NFIELDS; ++f) so[f] = si[f];
+        if (fin) {
+            // Lanczos tridiagonal entries (stochastic Lanczos quadrature of log det)
+            const int itn = round - 2;          // iterations finished before this one
+            if (mb.lanczos != nullptr && itn < mb.lanczos_cap) {
+                double* lz = mb.lanczos + ((size_t)rhs * mb.lanczos_cap + itn) * 2;
+                lz[0] = alfa;
+                lz[1] = beta;
+            }
+            so[S_OLDB] = oldb;
+            so[S_BETA] = beta;
+            so[S_TNORM2] = tnorm2;
+            so[S_DBAR] = dbar;
+            so[S_EPSLN] = epsln;
+            so[S_CS] = cs;
+            so[S_SN] = sn;
+            so[S_PHIBAR] = phibar;
+            so[S_PHI] = phi;
+            so[S_ALFA] = alfa;
+            so[S_OLDEPS] = oldeps;
+            so[S_DELTA] = delta;
+            so[S_DENOM] = denom;
+            so[S_ROOT] = root;
+            so[S_GBAR] = gbar;
+            const double gmax = si[S_GMAX] > gamma ? si[S_GMAX] : gamma;
+            const double gmin = si[S_GMIN] < gamma ? si[S_GMIN] : gamma;
+            so[S_GMAX] = gmax;
+            so[S_GMIN] = gmin;
+            const double z = si[S_RHS1] / gamma;
+            so[S_RHS1] = si[S_RHS2] - delta * z;
+            so[S_RHS2] = -epsln * z;
+        }
+    }
+}
+
+// SciPy's stopping tests for the iteration whose state is `st` (k_minres_test)
+__device__ __forceinline__ int minres_stop_test(const double* st, double ynorm, int itn,
+                                                double rtol, int maxiter) {
+    const double eps = 2.220446049250313e-16;
+    int istop = 0;
+    const double beta1 = st[S_BETA1];
+    if (itn == 1 && st[S_BETA] / beta1 <= 10 * eps) istop = -1;
+    const double Anorm = sqrt(st[S_TNORM2]);
+    const double epsx = Anorm * ynorm * eps;
+    const double rnorm = st[S_PHIBAR];
+    const double inf = 1.0 / 0.0;
+    const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? inf : rnorm / (Anorm * ynorm);
+    const double test2 = Anorm == 0.0 ? inf : st[S_ROOT] / Anorm;
+    const double Acond = st[S_GMAX] / st[S_GMIN];
+    if (istop == 0) {
+        const double t1 = 1.0 + test1, t2 = 1.0 + test2;
+        if (t2 <= 1.0) istop = 2;
+        if (t1 <= 1.0) istop = 1;
+        if (itn >= maxiter) istop = 6;
+        if (Acond >= 0.1 / eps) istop = 4;
+        if (epsx >= beta1) istop = 3;
+        if (test2 <= rtol) istop = 2;
+        if (test1 <= rtol) istop = 1;
+    }
+    return istop;
+}
+
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    const int nblk = gridDim.x;
+    const int p2 = par;
+    const double* so = mb.S[1 - p2] + (size_t)rhs * S_NFIELDS;    // published by P this round
+    int* iv = mb.I + rhs * I_NFIELDS;
+    bool go = iv[I_ACTIVE] != 0;
+    // operands first: they do not depend on the scalar chain of the tests
+    const double* r2 = mb.tri[1 - p2];
+    double* y = mb.tri[p2];
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    constexpr int PF = 4;
+    double py[PF], pr[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = lo + threadIdx.x + u * blockDim.x;
+        py[u] = pr[u] = 0.0;
+        if (go && i < hi) {
+            py[u] = y[off + i];
+            pr[u] = r2[off + i];
+        }
+    }
+    // ||x||^2 of the iteration under test and alfa of the one under way (the
+    // same reduction P uses: alfa must be bit-identical in both kernels)
+    double xx = 0.0, alfa = 0.0;
+    sum2_partials(go ? mb.partC + (size_t)rhs * nblk : nullptr,
+                  go ? mb.partA[1 - p2] + (size_t)rhs * nblk : nullptr, nblk, red, &xx, &alfa);
+    const int round = *mb.giter;
+    if (go && round >= 2) {
+        // every workgroup of this system takes the same decision from the same
+        // numbers; workgroup 0 records it
+        const double ynorm = sqrt(xx);
+        const int istop = minres_stop_test(so, ynorm, round - 1, rtol, maxiter);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            iv[I_ITN] = round - 1;
+            if (istop != 0) {
+                iv[I_ISTOP] = istop;
+                iv[I_ACTIVE] = 0;
+            }
+        }
+        if (istop != 0) go = false;
+    }
+    if (go) {
+        const double beta = so[S_BETA];
+        const double coef = alfa / beta;      // SciPy: y -= (alfa / beta) r2, r2 unnormalised
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = lo + threadIdx.x + u * blockDim.x;
+            if (i < hi) {
+                const double yi = py[u] - coef * pr[u];
+                y[off + i] = yi;
+                if (mb.vcopy != nullptr) mb.vcopy[off + i] = yi;
+                acc = fma(yi, yi, acc);
+            }
+        }
+        for (int i = lo + threadIdx.x + PF * blockDim.x; i < hi; i += blockDim.x) {
+            const double yi = y[off + i] - coef * r2[off + i];
+            y[off + i] = yi;
+            if (mb.vcopy != nullptr) mb.vcopy[off + i] = yi;
+            acc = fma(yi, yi, acc);
+        }
+        acc = block_reduce_sum(acc, red);
+        if (threadIdx.x == 0) mb.partB[(size_t)rhs * nblk + blockIdx.x] = acc;
+    }
 }
 
 // ---- CG ---------------------------------------------------------------------

@@ -264,7 +264,9 @@ static void set_lds_attr_rows() {
 template <int RA, int RB>
 static void set_lds_attr_cols2() {
 #if !defined(RL_EMU)
-    (void)hipFuncSetAttribute((const void*)k2_cols_fwd<RA, RB>,
+    (void)hipFuncSetAttribute((const void*)k2_cols_fwd<RA, RB, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k2_cols_fwd<RA, RB, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k2_cols_inv<RA, RB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -830,6 +832,26 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
     tp->thrR = (lds(R) > big && R * g->D * sub >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
     tp->thrC = ((size_t)g->N1 * C * sizeof(cplx) > big &&
                 (g->N1 / g->plan1.radix[0]) * C >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
+    // experiment knobs (tile sweeps on the GPU box)
+    if (const char* e = getenv("RUNLMC_TILE_C")) {
+        const int c = atoi(e);
+        if (c >= 1 && c <= g->N2 && (c & (c - 1)) == 0 &&
+            (size_t)g->N1 * c * sizeof(cplx) <= kLdsHard) {
+            C = c;
+            tp->C = C;
+            tp->logC = ilog2(C);
+        }
+    }
+    if (const char* e = getenv("RUNLMC_TILE_R")) {
+        const int r = atoi(e);
+        if (r >= 1 && g->N1 % r == 0 && lds(r) <= kLdsHard) {
+            R = r;
+            tp->R = R;
+            tp->colsMagic = div_magic((unsigned)(R * g->D));
+        }
+    }
+    if (const char* e = getenv("RUNLMC_THR_C")) tp->thrC = std::min(RL_THREADS2, std::max(64, atoi(e)));
+    if (const char* e = getenv("RUNLMC_THR_R")) tp->thrR = std::min(RL_THREADS2, std::max(64, atoi(e)));
     tp->pairs = (int)pairs;
     tp->tilesC = g->N2 / C;
     tp->tilesR = g->N1 / R;
@@ -838,11 +860,17 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
 
 template <int RA, int RB>
 static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
-                             const double* X, int nv, int D, int mode) {
+                             const double* X, int nv, int D, int mode, const Gather& gs) {
     dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * D));
-    RL_LAUNCH((k2_cols_fwd<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
-              st, X, nv, D, g->geo, mode, g->T, tp, g->plan1, g->tw1, g->freq1, g->twl);
+    if (gs.indptr != nullptr)
+        RL_LAUNCH((k2_cols_fwd<RA, RB, true>), grid, dim3(tp.thrC),
+                  (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->T, tp,
+                  g->plan1, g->tw1, g->freq1, g->twl, gs);
+    else
+        RL_LAUNCH((k2_cols_fwd<RA, RB, false>), grid, dim3(tp.thrC),
+                  (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->T, tp,
+                  g->plan1, g->tw1, g->freq1, g->twl, gs);
 }
 template <int RA, int RB>
 static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
@@ -855,38 +883,41 @@ static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
 }
 template <int D, int RA, int RB>
 static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
-                         const MixParams& mp) {
+                         const MixParams& mp, int* bump) {
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
     const size_t lds = (size_t)g->N2 * ((tp.R * D) | 1) * sizeof(cplx);
     RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->T, tp, g->plan2,
-              g->tw2, g->freq1, g->twl, mp);
+              g->tw2, g->freq1, g->twl, mp, bump);
 }
 template <int D>
 static void launch2_rows_code(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
-                              const MixParams& mp) {
+                              const MixParams& mp, int* bump) {
     switch (g->code2) {
-        case 808: launch2_rows<D, 8, 8>(g, tp, pairs, st, mp); break;
-        case 816: launch2_rows<D, 8, 16>(g, tp, pairs, st, mp); break;
-        default: launch2_rows<D, 16, 16>(g, tp, pairs, st, mp); break;
+        case 808: launch2_rows<D, 8, 8>(g, tp, pairs, st, mp, bump); break;
+        case 816: launch2_rows<D, 8, 16>(g, tp, pairs, st, mp, bump); break;
+        default: launch2_rows<D, 16, 16>(g, tp, pairs, st, mp, bump); break;
     }
 }
 
 static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, double* Yc, int nv,
-                        size_t pairs, hipStream_t st) {
+                        size_t pairs, hipStream_t st, const Gather* gather = nullptr,
+                        int* bump = nullptr) {
     Tile2 tp;
     choose_tiles(g, pairs, &tp);
+    Gather gs;
+    if (gather != nullptr) gs = *gather; else gs.indptr = nullptr;
     switch (g->code1) {
-        case 808: launch2_cols_fwd<8, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        case 816: launch2_cols_fwd<8, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        case 308: launch2_cols_fwd<3, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        case 316: launch2_cols_fwd<3, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        case 508: launch2_cols_fwd<5, 8>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        case 516: launch2_cols_fwd<5, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
-        default: launch2_cols_fwd<16, 16>(g, tp, pairs, st, Xc, nv, g->D, 0); break;
+        case 808: launch2_cols_fwd<8, 8>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
+        case 816: launch2_cols_fwd<8, 16>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
+        case 308: launch2_cols_fwd<3, 8>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
+        case 316: launch2_cols_fwd<3, 16>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
+        case 508: launch2_cols_fwd<5, 8>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
+        case 516: launch2_cols_fwd<5, 16>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
+        default: launch2_cols_fwd<16, 16>(g, tp, pairs, st, Xc, nv, g->D, 0, gs); break;
     }
     switch (g->D) {
-#define RL_CASE(d) case d: launch2_rows_code<d>(g, tp, pairs, st, mp); break;
+#define RL_CASE(d) case d: launch2_rows_code<d>(g, tp, pairs, st, mp, bump); break;
         RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
         RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
         RL_CASE(14) RL_CASE(15) RL_CASE(16)
@@ -1014,7 +1045,7 @@ struct rl_ski {
     std::vector<SkiTerm> extra;   // terms beyond the first (rl_ski_add_term)
     int max_ngrid = 0;
     rl_gridop* g = nullptr;
-    int n = 0, ngrid = 0;
+    int n = 0, ngrid = 0, nnz = 0;
     int *W_indptr = nullptr, *W_indices = nullptr;
     double* W_data = nullptr;
     int *WT_indptr = nullptr, *WT_indices = nullptr;
@@ -1039,16 +1070,17 @@ struct rl_ski {
 // (bandwidth-bound: the structure is 12 bytes per non-zero per pass).
 static void launch_spmv(const int* indptr, const int* indices, const double* vals, int nrows,
                         int ncols, int nvec, const double* X, double* Y, const double* diag,
-                        const double* X2, hipStream_t st, int accumulate = 0) {
+                        const double* X2, hipStream_t st, int accumulate = 0,
+                        int* bump = nullptr) {
     const unsigned gx = (nrows + RL_THREADS - 1) / RL_THREADS;
     static const int force_vb = getenv("RUNLMC_SPMV_VB") ? atoi(getenv("RUNLMC_SPMV_VB")) : 0;
     const bool blocked = force_vb ? force_vb > 1 : (size_t)nrows * nvec >= ((size_t)1 << 22);
     if (blocked) {
         RL_LAUNCH(k_spmv<8>, dim3(gx, (nvec + 7) / 8), dim3(RL_THREADS), 0, st, indptr, indices,
-                  vals, nrows, ncols, nvec, X, Y, diag, X2, accumulate);
+                  vals, nrows, ncols, nvec, X, Y, diag, X2, accumulate, bump);
     } else {
         RL_LAUNCH(k_spmv<1>, dim3(gx, nvec), dim3(RL_THREADS), 0, st, indptr, indices, vals,
-                  nrows, ncols, nvec, X, Y, diag, X2, accumulate);
+                  nrows, ncols, nvec, X, Y, diag, X2, accumulate, bump);
     }
 }
 
@@ -1159,6 +1191,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     s->W_indptr = t0.W_indptr; s->W_indices = t0.W_indices; s->W_data = t0.W_data;
     s->WT_indptr = t0.WT_indptr; s->WT_indices = t0.WT_indices; s->WT_data = t0.WT_data;
     s->max_ngrid = ngrid;
+    s->nnz = W_indptr[n];
     RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
     RL_HIP(hipMemset(s->noise_diag, 0, (size_t)n * sizeof(double)));
     *out = guard.release();
@@ -1264,9 +1297,10 @@ static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int sc
 }
 
 // the three stages in INTERNAL row order
-static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st) {
+static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st,
+                      int* bump = nullptr) {
     launch_spmv(s->WT_indptr, s->WT_indices, s->WT_data, s->ngrid, s->n, nvec, Xp, G, nullptr,
-                nullptr, st);
+                nullptr, st, 0, bump);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -1278,9 +1312,10 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
     return RL_OK;
 }
 // Yp = K~ Xp, both in internal row order (what the solver iterates on)
-static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st) {
+static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st,
+                       int* bump = nullptr) {
     RL_TRY(ski_reserve(s, nvec));
-    RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st));
+    RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st));
     RL_TRY(ski_w_int(s, s->G2, Yp, nvec, s->has_noise ? s->noise_diag : nullptr, Xp, st));
     for (const SkiTerm& t : s->extra) {       // Yp += W_t K_t W_t^T Xp
@@ -1381,8 +1416,8 @@ struct SolverWork {
                        nullptr, nullptr, nullptr, nullptr, nullptr};
     double* S[2] = {nullptr, nullptr};
     int* I = nullptr;
-    double* part[3] = {nullptr, nullptr, nullptr};
-    int* count = nullptr;   // [0] active systems, [1] global iteration counter
+    double* part[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* count = nullptr;   // [0] active systems, [1] global iteration counter, [2] done blocks
     double* resid = nullptr; // [nrhs] explicit residual norms
     double* lanczos = nullptr;
 };
@@ -1412,9 +1447,10 @@ static int solver_alloc(SolverWork& w, int nvecs, int nrhs, int n, int nblk) {
     for (int i = 0; i < 2; ++i)
         RL_HIP(hipMalloc((void**)&w.S[i], (size_t)nrhs * S_NFIELDS * sizeof(double)));
     RL_HIP(hipMalloc((void**)&w.I, (size_t)nrhs * I_NFIELDS * sizeof(int)));
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         RL_HIP(hipMalloc((void**)&w.part[i], (size_t)nrhs * nblk * sizeof(double)));
-    RL_HIP(hipMalloc((void**)&w.count, 2 * sizeof(int)));
+    RL_HIP(hipMalloc((void**)&w.count, 4 * sizeof(int)));
+    RL_HIP(hipMemset(w.count, 0, 4 * sizeof(int)));
     RL_HIP(hipMalloc((void**)&w.resid, (size_t)nrhs * sizeof(double)));
     RL_HIP(hipMemset(w.resid, 0, (size_t)nrhs * sizeof(double)));
     return RL_OK;
@@ -1454,6 +1490,39 @@ static int minres_iteration(rl_ski* s, const MinresBufs& mb, SolverWork& w, int 
               (const double*)w.part[1], w.part[2]);
     RL_LAUNCH(k_minres_test, dim3(1), blk, 0, st, mb, (const double*)w.part[2], nblk, nrhs,
               rtol, maxiter);
+    return RL_OK;
+}
+
+// one round of the two-kernel MINRES (rl_solver.h): operator product on the
+// unnormalised Lanczos vector, P, B; identical arguments every round
+static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int nblk, int round,
+                         double rtol, int maxiter, hipStream_t st) {
+    const int par = (round - 1) & 1;
+    dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
+    const size_t red = RL_SOLVER_THREADS * sizeof(double);
+    if (mb.W_indptr != nullptr && mb.vcopy == nullptr) {
+        // W^T fused into the column transforms (gathered while loading), W into
+        // P: three grid kernels, P, B
+        rl_gridop* g = s->g;
+        Gather gs;
+        gs.indptr = s->WT_indptr;
+        gs.indices = s->WT_indices;
+        gs.vals = s->WT_data;
+        gs.src = mb.tri[1 - par];        // y_{r-1}, the operator's input
+        gs.n = n;
+        gs.nnz = s->nnz;
+        MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa};
+        RL_TRY(mvm_chunk_v2(g, mp, nullptr, s->G2, nrhs, ((size_t)nrhs + 1) / 2, st, &gs,
+                            mb.giter));
+    } else if (mb.W_indptr != nullptr) {
+        // W product fused into P: only W^T and the grid product run here
+        RL_TRY(ski_wt_int(s, mb.vcopy, s->G1, nrhs, st, mb.giter));
+        RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nrhs, st));
+    } else {
+        RL_TRY(ski_mvm_int(s, mb.vcopy, mb.q, nrhs, st, mb.giter));
+    }
+    RL_LAUNCH(k_minres2_p, grid, blk, red, st, mb, n, par);
+    RL_LAUNCH(k_minres2_b, grid, blk, red, st, mb, n, par, rtol, maxiter);
     return RL_OK;
 }
 
@@ -1555,7 +1624,88 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         Xi = w.vec[9];
     }
     RL_LAUNCH(k_dot_partial, grid, blk, red, st, Bi, Bi, n, w.part[0]);
-    if (method == RL_MINRES) {
+    if (method == RL_MINRES && getenv("RUNLMC_MINRES_V1") == nullptr) {
+        // two vector kernels per round (rl_solver.h: Minres2Bufs)
+        Minres2Bufs mb;
+        mb.tri[0] = w.vec[0]; mb.tri[1] = w.vec[1];
+        mb.w[0] = w.vec[3]; mb.w[1] = w.vec[4];
+        mb.vcopy = w.vec[5];
+        mb.q = w.vec[6];
+        mb.x = Xi;
+        mb.S[0] = w.S[0]; mb.S[1] = w.S[1];
+        mb.I = w.I;
+        mb.giter = w.count + 1;
+        mb.partA[0] = w.part[0]; mb.partA[1] = w.part[3];
+        mb.partB = w.part[1];
+        mb.partC = w.part[2];
+        mb.lanczos = nullptr;
+        mb.lanczos_cap = 0;
+        // the W product rides inside P when the problem is small enough to be
+        // launch-bound (a big one amortises the CSR over 8 vectors in k_spmv<8>)
+        const bool fuse_w = s->extra.empty() && (size_t)n * nrhs < ((size_t)1 << 22) &&
+                            getenv("RUNLMC_NO_FUSE_W") == nullptr;
+        mb.W_indptr = fuse_w ? s->W_indptr : nullptr;
+        // ... and W^T inside the first grid kernel when that is a k2_cols_fwd and
+        // the batch is one chunk (the operator input is then the rotating buffer
+        // itself: no copy of the new Lanczos vector)
+        const bool fuse_wt = fuse_w && s->g->v2 && s->g->Q >= 1 &&
+                             ((size_t)nrhs + 1) / 2 <= s->g->chunk_pairs &&
+                             !(s->g->v4 && nrhs >= s->g->v4_min) &&
+                             getenv("RUNLMC_NO_FUSE_WT") == nullptr;
+        if (fuse_wt) mb.vcopy = nullptr;
+        mb.W_indices = s->W_indices;
+        mb.W_data = s->W_data;
+        mb.W_nnz = s->nnz;
+        mb.g = s->G2;
+        mb.eps = s->has_noise ? s->noise_diag : nullptr;
+        mb.ngrid = s->ngrid;
+        if (lanczos_out != nullptr) {
+            const size_t bytes = (size_t)nrhs * lanczos_cap * 2 * sizeof(double);
+            RL_HIP(hipMalloc((void**)&w.lanczos, bytes));
+            RL_HIP(hipMemsetAsync(w.lanczos, 0, bytes, st));
+            mb.lanczos = w.lanczos;
+            mb.lanczos_cap = lanczos_cap;
+        }
+        RL_LAUNCH(k_minres2_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], mb);
+        RL_TRY(active_count(w, nrhs, st, &active));
+        // x lags one round behind: after `done` rounds it holds iterate done - 1.
+        // The first round runs eagerly so that graph replays of per_graph rounds
+        // land on done = 1 + j * per_graph, i.e. on the reference's check points
+        if (active > 0) {
+            RL_TRY(minres2_round(s, mb, nrhs, n, nblk, 1, rtol, maxiter, st));
+            done = 1;
+        }
+        // graph replays start at round 2 + j * per2: the same parity every time
+        // as long as per2 is even
+        int per2 = 0;
+        for (int d = 2; d <= 10; d += 2)
+            if (check_every == 0 || check_every % d == 0) per2 = d;
+        if (use_graph && active > 0 && per2 > 0) {
+            RL_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = RL_OK;
+            for (int k = 0; k < per2 && rc == RL_OK; ++k)
+                rc = minres2_round(s, mb, nrhs, n, nblk, 2 + k, rtol, maxiter, st);
+            hipError_t e = hipStreamEndCapture(st, &guard.graph);
+            if (rc != RL_OK) return rc;
+            RL_HIP(e);
+            RL_HIP(hipGraphInstantiate(&guard.exec, guard.graph, nullptr, nullptr, 0));
+        }
+        while (done <= maxiter && active > 0) {
+            if (guard.exec) {
+                RL_HIP(hipGraphLaunch(guard.exec, st));
+                done += per2;
+            } else {
+                RL_TRY(minres2_round(s, mb, nrhs, n, nblk, done + 1, rtol, maxiter, st));
+                done += 1;
+            }
+            const bool check = check_every > 0 && (done - 1) % check_every == 0;
+            if (check)
+                RL_TRY(residual_check(s, w, Bi, Xi, mb.q, nrhs, n, nblk, tol, 1, st));
+            if (check || guard.exec || (done - 1) % 10 == 0)
+                RL_TRY(active_count(w, nrhs, st, &active));
+        }
+        RL_TRY(residual_check(s, w, Bi, Xi, mb.q, nrhs, n, nblk, tol, 0, st));
+    } else if (method == RL_MINRES) {
         MinresBufs mb;
         mb.tri[0] = w.vec[0]; mb.tri[1] = w.vec[1]; mb.tri[2] = w.vec[2];
         mb.w[0] = w.vec[3]; mb.w[1] = w.vec[4];

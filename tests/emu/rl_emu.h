@@ -38,6 +38,9 @@ void rl_emu_launch(dim3 grid, dim3 block, size_t smem_bytes,
                    const std::function<void()>& body);
 
 #define __syncthreads() rl_emu_syncthreads()
+// workgroups run on several host threads: real atomics and fences
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // --- the sliver of the HIP runtime API the host code uses -----------------
 typedef int hipError_t;

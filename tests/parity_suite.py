@@ -633,3 +633,59 @@ def check_onchip_product(big=True):
             del os.environ['RUNLMC_V4_MIN']
         else:
             os.environ['RUNLMC_V4_MIN'] = old
+
+
+def check_solver_fusions():
+    """The batched MINRES variants agree: two-kernel rounds with the W product
+    inside P and the W^T product inside the first grid kernel (a grid long
+    enough for the k2_* kernels), the same without each fusion, and the
+    four-kernel original; against the oracle's MINRES as well."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch
+    p = synth.make_problem(3, 2, 1, 1200, eps=1.0)
+    p.noise = p.noise + 0.5                      # well conditioned: converges
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    op = K.device_operator()
+    assert op.grids[0].N2 >= 64                  # k2_* kernels
+    rng = np.random.RandomState(0)
+    B = np.vstack([p.y, rng.randint(0, 2, (2, p.n)) * 2.0 - 1])
+    knobs = ('RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_MINRES_V1')
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    res = {}
+    try:
+        for mode, env in (('fused', {}), ('no_wt', {'RUNLMC_NO_FUSE_WT': '1'}),
+                          ('no_w', {'RUNLMC_NO_FUSE_W': '1'}),
+                          ('four_kernel', {'RUNLMC_MINRES_V1': '1'})):
+            for k in knobs:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            X, it, rs, st = solve_batch(op, torch.from_numpy(B).to(op.device), tol=1e-4)[:4]
+            res[mode] = (X.cpu().numpy(), np.array(it), np.array(rs), np.array(st))
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+    ref = res['four_kernel']
+    assert np.all(ref[3] == 1) and np.all(ref[2] < 1e-4)
+    for mode, (X, it, rs, st) in res.items():
+        assert np.all(st == ref[3]), (mode, st)
+        # the 1e-10 inner tolerance sits at the roundoff floor of these systems:
+        # the count at which it is crossed moves by a few iterations with the
+        # summation order
+        assert np.all(np.abs(it - ref[1]) <= 5), (mode, it, ref[1])
+        assert np.all(rs < 1e-4), (mode, rs)
+        _close(X, ref[0], 2e-5)      # they stop a few iterations apart (residual ~1e-5)
+    _close(res['fused'][0], res['no_wt'][0], 1e-12)
+    # the oracle's statement of SciPy's MINRES on the same systems
+    from oracle.kernels import KernelSpec, RBFSpec
+    spec = KernelSpec(p.D, [RBFSpec(g) for g in p.inv_lengthscales], p.coreg_vecs,
+                      p.coreg_diags, p.noise)
+    spec.set_input_dim(1)
+    oop = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    for v in range(len(B)):
+        xo, ito, erro, _ = iterative_solve(oop.matvec, B[v], tol=1e-4)
+        assert abs(int(res["fused"][1][v]) - ito) <= 5
+        _close(res["fused"][0][v], xo, 2e-5)

@@ -123,3 +123,7 @@ def test_ragged_and_empty_outputs():
 
 def test_onchip_product():
     ps.check_onchip_product()
+
+
+def test_solver_fusions():
+    ps.check_solver_fusions()
