@@ -288,7 +288,7 @@ def main():
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': MEASURED_TRAFFIC.get((args.config, batch), (None, None))[0],
                      'traffic_source': MEASURED_TRAFFIC.get((args.config, batch), (None, None))[1],
-                     'kernel': 'grid MVM = k_cols_fwd + k_rows_mix<%d> + k_cols_inv' % D,
+                     'kernel': 'grid MVM = k2_cols_fwd + k2_rows_mix<%d> + k2_cols_inv' % D,
                      'algorithmic_bytes_per_step': alg,
                      'device_ms_per_step': ev_ms},
     }

@@ -1,4 +1,11 @@
-"""Timing probe for the on-chip product (k4_product): C2 grid, one batch size."""
+"""Timing probe of the grid product at the C2 grid size, one batch size (GPU box).
+
+    python tools/v4_probe.py [batch]
+
+Environment: RUNLMC_V4_MIN=<batch> turns the on-chip product on, RUNLMC_NO_V4=1
+removes it, RUNLMC_TILE_C / RUNLMC_TILE_R / RUNLMC_THR_C / RUNLMC_THR_R override
+the tile choice of the three-kernel path (tools/tile_sweep.sh).
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,5 +28,5 @@ for _ in range(n):
     g.mvm(X, out=Y)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
-print('dbg=%s batch=%d onchip=%s  %.1f us/product  %.2f M MVM/s  per-vector-CU %.1f us' % (
-    os.environ.get('RUNLMC_V4_DBG', '0'), b, g.onchip, ms * 1e3, b / ms / 1e3, ms * 1e3 / max(1, b / 256)))
+print('batch=%d onchip=%s  %.1f us/product  %.2f M MVM/s  (%.1f us of one CU per vector)' % (
+    b, g.onchip, ms * 1e3, b / ms / 1e3, ms * 1e3 / max(1, b / 256)))
