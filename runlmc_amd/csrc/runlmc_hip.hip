@@ -48,6 +48,17 @@ extern "C" int rl_device_count(int* count) {
 // ---------------------------------------------------------------------------
 // small host helpers
 // ---------------------------------------------------------------------------
+// RUNLMC_TRACE=1: one line on stderr the first time each kernel variant is chosen
+static void trace_once(const char* what) {
+    static const bool on = getenv("RUNLMC_TRACE") != nullptr;
+    if (!on) return;
+    static std::vector<std::string> seen;
+    for (const std::string& s : seen)
+        if (s == what) return;
+    seen.push_back(what);
+    fprintf(stderr, "[runlmc] %s\n", what);
+}
+
 static int ilog2(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -947,6 +958,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     RL_HIP(hipSetDevice(g->device));
     if (g->v4 && nvec >= g->v4_min) {
         // the whole product on chip, one workgroup per vector
+        trace_once("grid product: k4_product (on chip)");
         MixParams mp4 = mp;
         mp4.spec = g->spec4 + (size_t)((mp.spec - g->spec) / g->L) * (2 * g->p4.N + 1);
         // persistent workgroups: as many as can be resident, each walks vectors
@@ -1501,6 +1513,7 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
     if (mb.W_indptr != nullptr && mb.vcopy == nullptr) {
+        trace_once("minres round: W^T in k2_cols_fwd, W in P");
         // W^T fused into the column transforms (gathered while loading), W into
         // P: three grid kernels, P, B
         rl_gridop* g = s->g;
