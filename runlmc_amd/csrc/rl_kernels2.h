@@ -45,6 +45,8 @@ struct Gather {
     const double* src;      // [nvec][n] data-space vectors
     int n;                  // entries per data-space vector
     int nnz;                // entries of the CSR (for clamping)
+    const int* lo;          // non-NULL: the columns of row r are lo[r], lo[r] + 1, ...
+                            // (one level of dependent loads less: SkiTerm)
 };
 
 // (pair, tile-within-pair) of this workgroup; false if it is launch padding
@@ -147,7 +149,9 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
                 int kb[CH], ke[CH];
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    const int src = padded_source(geo, j + sub * (i0 + i), c0 + c, N1, N2, 0);
+                    // (a leg past RA in the last chunk behaves like padding)
+                    const int src = i0 + i < RA
+                        ? padded_source(geo, j + sub * (i0 + i), c0 + c, N1, N2, 0) : -1;
                     const int row = src >= 0 ? b * m + src : 0;
                     const int p0 = gs.indptr[row], p1 = gs.indptr[row + 1];
                     kb[i] = src >= 0 ? p0 : 0;
@@ -155,15 +159,39 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
                 }
                 double wa[CH][NZ];
                 int wc[CH][NZ];
+                if (gs.lo != nullptr) {
+                    // consecutive columns: first column with the row pointers,
+                    // weights and data values together in the next level
 #pragma unroll
-                for (int i = 0; i < CH; ++i)
+                    for (int i = 0; i < CH; ++i) {
+                        const int src = i0 + i < RA
+                            ? padded_source(geo, j + sub * (i0 + i), c0 + c, N1, N2, 0) : -1;
+                        const int l0 = gs.lo[src >= 0 ? b * m + src : 0];
 #pragma unroll
-                    for (int e = 0; e < NZ; ++e) {
-                        const int k = kb[i] + e < last ? kb[i] + e : last;
-                        const double a = gs.vals[k];
-                        wc[i][e] = gs.indices[k];
-                        wa[i][e] = kb[i] + e < ke[i] ? a : 0.0;
+                        for (int e = 0; e < NZ; ++e) {
+                            const int col = l0 + e;
+                            wc[i][e] = col < gs.n ? col : gs.n - 1;
+                        }
                     }
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int e = 0; e < NZ; ++e) {
+                            const int k = kb[i] + e < last ? kb[i] + e : last;
+                            const double a = gs.vals[k];
+                            wa[i][e] = kb[i] + e < ke[i] ? a : 0.0;
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+#pragma unroll
+                        for (int e = 0; e < NZ; ++e) {
+                            const int k = kb[i] + e < last ? kb[i] + e : last;
+                            const double a = gs.vals[k];
+                            wc[i][e] = gs.indices[k];
+                            wa[i][e] = kb[i] + e < ke[i] ? a : 0.0;
+                        }
+                }
                 // data values of ALL legs of the chunk before any is used (the
                 // rare rows longer than NZ finish afterwards)
                 double g0[CH][NZ], g1[CH][NZ];
@@ -182,16 +210,17 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
                         re = fma(wa[i][e], g0[i][e], re);
                         im = fma(wa[i][e], g1[i][e], im);
                     }
-                    v[i0 + i] = c_make(re, has1 ? im : 0.0);
+                    if (i0 + i < RA) v[i0 + i] = c_make(re, has1 ? im : 0.0);
                 }
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
-                    for (int k = kb[i] + NZ; k < ke[i]; ++k) {
-                        const double a = gs.vals[k];
-                        const int col = gs.indices[k];
-                        v[i0 + i].x = fma(a, d0[col], v[i0 + i].x);
-                        if (has1) v[i0 + i].y = fma(a, d1[col], v[i0 + i].y);
-                    }
+                    if (i0 + i < RA)
+                        for (int k = kb[i] + NZ; k < ke[i]; ++k) {
+                            const double a = gs.vals[k];
+                            const int col = gs.indices[k];
+                            v[i0 + i].x = fma(a, d0[col], v[i0 + i].x);
+                            if (has1) v[i0 + i].y = fma(a, d1[col], v[i0 + i].y);
+                        }
             }
         }
         SmallDft<RA, false>::run(v);

@@ -496,6 +496,8 @@ struct Minres2Bufs {
     const int* W_indices;
     const double* W_data;
     int W_nnz;
+    const int* W4_base;     // non-NULL: W as base column + 4 weights per row (SkiTerm)
+    const double* W4_w;
     const double* g;        // [nrhs][ngrid]
     const double* eps;      // [n] or NULL
     int ngrid;
@@ -590,16 +592,33 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     // a conditional load is a branch with a full memory wait behind it)
     const int rlast = hi > lo ? hi - 1 : lo;       // lo < n: a valid row
     const int elast = mb.W_nnz > 0 ? mb.W_nnz - 1 : 0;
+    const bool ell = g != nullptr && mb.W4_base != nullptr;
     int k0[PF], k1[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int i = lo + threadIdx.x + u * blockDim.x;
         const int ic = i < hi ? i : rlast;
         k0[u] = k1[u] = 0;
-        if (g != nullptr) {
+        if (g != nullptr && !ell) {
             const int a0 = mb.W_indptr[ic], a1 = mb.W_indptr[ic + 1];
             k0[u] = i < hi ? a0 : 0;
             k1[u] = i < hi ? a1 : 0;
+        }
+    }
+    // structured W: base column and the four weights come with the first level
+    int eb[PF];
+    double ew[PF][NZ];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int i = lo + threadIdx.x + u * blockDim.x;
+        const int ic = i < hi ? i : rlast;
+        eb[u] = 0;
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) ew[u][j] = 0.0;
+        if (ell) {
+            eb[u] = mb.W4_base[ic];
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) ew[u][j] = mb.W4_w[(size_t)4 * ic + j];
         }
     }
 #pragma unroll
@@ -614,7 +633,22 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
         px[u] = mb.x[off + ic];
         pq[u] = g == nullptr ? mb.q[off + ic] : 0.0;
     }
-    if (g != nullptr) {
+    if (ell) {
+        double gv[PF][NZ];
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) gv[u][j] = g[eb[u] + j];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = lo + threadIdx.x + u * blockDim.x;
+            const int ic = i < hi ? i : rlast;
+            double qi = mb.eps != nullptr ? mb.eps[ic] * pr2[u] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) qi = fma(ew[u][j], gv[u][j], qi);
+            pq[u] = qi;
+        }
+    } else if (g != nullptr) {
         double wa[PF][NZ];
         int wc[PF][NZ];
 #pragma unroll
@@ -696,7 +730,12 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     for (int i = lo + threadIdx.x + PF * blockDim.x; i < hi; i += blockDim.x) {
         const double r2i = r2[off + i];
         double qi;
-        if (g != nullptr) {
+        if (ell) {
+            qi = mb.eps != nullptr ? mb.eps[i] * r2i : 0.0;
+            const int b = mb.W4_base[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qi = fma(mb.W4_w[(size_t)4 * i + j], g[b + j], qi);
+        } else if (g != nullptr) {
             qi = mb.eps != nullptr ? mb.eps[i] * r2i : 0.0;
             const int k1 = mb.W_indptr[i + 1];
             for (int k = mb.W_indptr[i]; k < k1; ++k) qi = fma(mb.W_data[k], g[mb.W_indices[k]], qi);

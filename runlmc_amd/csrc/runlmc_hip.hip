@@ -668,7 +668,7 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     dim3 gridS(g->N1 / g->rowsS, npairs);
     RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
               g->spec, ntop, g->N1, g->N2, g->rowsS, g->plan2, g->tw2);
-    if (g->v4) {
+    if (g->v4 && g->v4_min < (1 << 30)) {        // only when the path is switched on
         MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
         RL_TRY(launch4(1, g->ep4, dim3(ntop), dim3(g->thr4), g->lds4, stream, g->tops, nullptr,
                        ntop, g->geo, 1, g->p4, none, g->spec4));
@@ -1051,13 +1051,25 @@ struct SkiTerm {
     double* W_data = nullptr;
     int *WT_indptr = nullptr, *WT_indices = nullptr;
     double* WT_data = nullptr;
+    int nnzWT = 0;
+    // Interpolation structure, when W has it (every row at most 4 entries in
+    // consecutive columns, rows sorted by first column -- cubic interpolation of
+    // sorted inputs): W as base column + 4 weights per row, and W^T rebuilt so
+    // that the data rows of every grid row are one CONSECUTIVE range starting
+    // at WT_lo[r] (zero weights kept).  Both remove one level of dependent
+    // loads from the fused products of the small-batch solver.
+    int* W4_base = nullptr;
+    double* W4_w = nullptr;
+    int* WT_lo = nullptr;
 };
 
 struct rl_ski {
     std::vector<SkiTerm> extra;   // terms beyond the first (rl_ski_add_term)
     int max_ngrid = 0;
     rl_gridop* g = nullptr;
-    int n = 0, ngrid = 0, nnz = 0;
+    int n = 0, ngrid = 0, nnz = 0, nnzWT = 0;
+    int *W4_base = nullptr, *WT_lo = nullptr;     // interpolation structure (SkiTerm)
+    double* W4_w = nullptr;
     int *W_indptr = nullptr, *W_indices = nullptr;
     double* W_data = nullptr;
     int *WT_indptr = nullptr, *WT_indices = nullptr;
@@ -1155,12 +1167,55 @@ static int upload_term(SkiTerm* t, int n, int ngrid, const int* W_indptr, const 
         WT_indices = wtp_idx.data(); WT_data = wtp_val.data();
     }
     t->ngrid = ngrid;
+    // interpolation structure (see SkiTerm)
+    std::vector<int> base, lo, sp_ptr, sp_idx;
+    std::vector<double> w4, sp_val;
+    {
+        bool ok = ngrid >= 4 && getenv("RUNLMC_NO_ELL") == nullptr;
+        base.resize(n);
+        w4.assign((size_t)4 * n, 0.0);
+        int prev = 0;
+        for (int i = 0; i < n && ok; ++i) {
+            const int k0 = W_indptr[i], cnt = W_indptr[i + 1] - k0;
+            if (cnt > 4) { ok = false; break; }
+            for (int j = 1; j < cnt; ++j)
+                if (W_indices[k0 + j] != W_indices[k0] + j) ok = false;
+            int b = cnt ? W_indices[k0] : prev, shift = 0;
+            if (b > ngrid - 4) { shift = b - (ngrid - 4); b = ngrid - 4; }
+            if (shift + cnt > 4 || b < prev) { ok = false; break; }
+            prev = b;
+            base[i] = b;
+            for (int j = 0; j < cnt; ++j) w4[(size_t)4 * i + shift + j] = W_data[k0 + j];
+        }
+        if (ok) {
+            // W^T: grid row r is touched by the rows with base in [r - 3, r]
+            lo.resize(ngrid);
+            sp_ptr.assign(ngrid + 1, 0);
+            int a = 0, e = 0;
+            for (int r = 0; r < ngrid; ++r) {
+                while (a < n && base[a] < r - 3) ++a;
+                while (e < n && base[e] <= r) ++e;
+                lo[r] = a;
+                sp_ptr[r + 1] = sp_ptr[r] + (e - a);
+                for (int i = a; i < e; ++i) {
+                    sp_idx.push_back(i);
+                    sp_val.push_back(w4[(size_t)4 * i + (r - base[i])]);
+                }
+            }
+            RL_TRY(upload_raw((void**)&t->W4_base, base.data(), (size_t)n * sizeof(int)));
+            RL_TRY(upload_raw((void**)&t->W4_w, w4.data(), (size_t)4 * n * sizeof(double)));
+            RL_TRY(upload_raw((void**)&t->WT_lo, lo.data(), (size_t)ngrid * sizeof(int)));
+            WT_indptr = sp_ptr.data(); WT_indices = sp_idx.data(); WT_data = sp_val.data();
+        }
+    }
+    const size_t nnzT = WT_indptr[ngrid];
+    t->nnzWT = (int)nnzT;
     RL_TRY(upload_raw((void**)&t->W_indptr, W_indptr, (size_t)(n + 1) * sizeof(int)));
     RL_TRY(upload_raw((void**)&t->W_indices, W_indices, nnz * sizeof(int)));
     RL_TRY(upload_raw((void**)&t->W_data, W_data, nnz * sizeof(double)));
     RL_TRY(upload_raw((void**)&t->WT_indptr, WT_indptr, (size_t)(ngrid + 1) * sizeof(int)));
-    RL_TRY(upload_raw((void**)&t->WT_indices, WT_indices, nnz * sizeof(int)));
-    RL_TRY(upload_raw((void**)&t->WT_data, WT_data, nnz * sizeof(double)));
+    RL_TRY(upload_raw((void**)&t->WT_indices, WT_indices, nnzT * sizeof(int)));
+    RL_TRY(upload_raw((void**)&t->WT_data, WT_data, nnzT * sizeof(double)));
     return RL_OK;
 }
 
@@ -1202,6 +1257,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
                        WT_data, s->permuted ? &s->h_perm : nullptr));
     s->W_indptr = t0.W_indptr; s->W_indices = t0.W_indices; s->W_data = t0.W_data;
     s->WT_indptr = t0.WT_indptr; s->WT_indices = t0.WT_indices; s->WT_data = t0.WT_data;
+    s->W4_base = t0.W4_base; s->W4_w = t0.W4_w; s->WT_lo = t0.WT_lo; s->nnzWT = t0.nnzWT;
     s->max_ngrid = ngrid;
     s->nnz = W_indptr[n];
     RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
@@ -1241,13 +1297,15 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     if (!s) return RL_OK;
     (void)hipSetDevice(s->g->device);
     for (SkiTerm& t : s->extra) {
-        void* tp[] = {t.W_indptr, t.W_indices, t.W_data, t.WT_indptr, t.WT_indices, t.WT_data};
+        void* tp[] = {t.W_indptr, t.W_indices, t.W_data, t.WT_indptr, t.WT_indices, t.WT_data,
+                      t.W4_base, t.W4_w, t.WT_lo};
         for (void* p : tp)
             if (p) (void)hipFree(p);
     }
     if (s->solver_stream) (void)hipStreamDestroy(s->solver_stream);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
-                    s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2};
+                    s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
+                    s->W4_base, s->W4_w, s->WT_lo};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -1523,7 +1581,8 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         gs.vals = s->WT_data;
         gs.src = mb.tri[1 - par];        // y_{r-1}, the operator's input
         gs.n = n;
-        gs.nnz = s->nnz;
+        gs.nnz = s->nnzWT;
+        gs.lo = s->WT_lo;
         MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa};
         RL_TRY(mvm_chunk_v2(g, mp, nullptr, s->G2, nrhs, ((size_t)nrhs + 1) / 2, st, &gs,
                             mb.giter));
@@ -1669,6 +1728,8 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         mb.W_indices = s->W_indices;
         mb.W_data = s->W_data;
         mb.W_nnz = s->nnz;
+        mb.W4_base = s->W4_base;
+        mb.W4_w = s->W4_w;
         mb.g = s->G2;
         mb.eps = s->has_noise ? s->noise_diag : nullptr;
         mb.ngrid = s->ngrid;
