@@ -46,8 +46,10 @@ int rl_device_count(int* count);
  * SumMatrix.matvec (sum_matrix.py:31-32) and the three grid representations
  * _gen_sum_grid/_gen_bt_grid/_gen_slfm_grid (runlmc/lmc/grid_kernel.py:77-136),
  * which are the same linear operator.
- *   D outputs, m grid points (1-D grid), embedding length L = pow2 >= 2m
- *   (>= 16).  max_tops bounds Q in later rl_gridop_set_* calls.            */
+ *   D outputs, m grid points (1-D grid), embedding length L = the smallest
+ *   odd * 2^k >= 2m with odd in {1, 3, 5, 9, 15, 25} (any length >= 2m - 1
+ *   embeds the Toeplitz matrix exactly; the reference takes the next power
+ *   of two, bttb.py:16-19).  max_tops bounds Q in later rl_gridop_set_* calls. */
 int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out);
 /* Same for a two-dimensional m1 x m2 grid: T_q is then a block-Toeplitz matrix
  * of Toeplitz blocks, BTTB(top, (m1, m2)) (bttb.py:91-148 with two sizes; grid
