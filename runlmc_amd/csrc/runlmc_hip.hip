@@ -599,8 +599,10 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     std::vector<double> ones(D, 1.0);
     if ((rc = upload(&g->ones, ones)) != RL_OK) return rc;
 
-    // intermediates of one chunk should stay inside the 256 MiB Infinity Cache
-    size_t chunk_mb = 96;
+    // intermediates of one chunk: large enough that a launch's tail does not
+    // matter, small enough to sit in the 256 MiB Infinity Cache (measured: C2,
+    // 1024 vectors 2.17 / 2.31 / 2.50 / 2.24 M MVM/s at 64 / 96 / 192 / 384 MB)
+    size_t chunk_mb = 192;
     if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
     // XCD affinity (experiment knob, OFF by default: measured slower on MI355X --
