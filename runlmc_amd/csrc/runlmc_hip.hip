@@ -229,6 +229,14 @@ struct rl_gridop {
     // workspace: packed intermediates [pairs][D][L] complex
     cplx* T = nullptr;
     size_t T_pairs = 0;
+    // a second chunk of intermediates and a side stream: consecutive chunks of a
+    // large batched product run on two streams, so that one chunk's kernels fill
+    // the compute units another chunk's tail leaves idle
+    cplx* T2 = nullptr;
+    size_t T2_pairs = 0;
+    cplx* Tcur = nullptr;       // workspace of the chunk being launched
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t chunk_pairs = 1;
     size_t xcd_pairs = 0;   // pairs per XCD-affine chunk (0: affinity off)
     // on-chip product (rl_kernels4.h): available for short 1-D grids, used for
@@ -628,9 +636,12 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->spec4, g->tw4A, g->tw4B, g->tw4lo, g->tw4hi, g->untw4, g->freq4A,
-                    g->pos4};
+                    g->pos4, g->T2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->aux) (void)hipStreamDestroy(g->aux);
     delete g;
     return RL_OK;
 }
@@ -878,11 +889,11 @@ static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * D));
     if (gs.indptr != nullptr)
         RL_LAUNCH((k2_cols_fwd<RA, RB, true>), grid, dim3(tp.thrC),
-                  (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->T, tp,
+                  (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->Tcur, tp,
                   g->plan1, g->tw1, g->freq1, g->twl, gs);
     else
         RL_LAUNCH((k2_cols_fwd<RA, RB, false>), grid, dim3(tp.thrC),
-                  (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->T, tp,
+                  (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->Tcur, tp,
                   g->plan1, g->tw1, g->freq1, g->twl, gs);
 }
 template <int RA, int RB>
@@ -892,7 +903,7 @@ static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
     dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * g->D));
     RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
-              st, g->T, Y, nv, g->D, g->geo, tp, g->plan1, g->tw1);
+              st, g->Tcur, Y, nv, g->D, g->geo, tp, g->plan1, g->tw1);
 }
 template <int D, int RA, int RB>
 static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
@@ -900,7 +911,7 @@ static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
     if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
     const size_t lds = (size_t)g->N2 * ((tp.R * D) | 1) * sizeof(cplx);
-    RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->T, tp, g->plan2,
+    RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->Tcur, tp, g->plan2,
               g->tw2, g->freq1, g->twl, mp, bump);
 }
 template <int D>
@@ -915,7 +926,8 @@ static void launch2_rows_code(rl_gridop* g, const Tile2& tp, size_t pairs, hipSt
 
 static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, double* Yc, int nv,
                         size_t pairs, hipStream_t st, const Gather* gather = nullptr,
-                        int* bump = nullptr) {
+                        int* bump = nullptr, cplx* Tbuf = nullptr) {
+    g->Tcur = Tbuf ? Tbuf : g->T;      // the launches below read it
     Tile2 tp;
     choose_tiles(g, pairs, &tp);
     Gather gs;
@@ -977,6 +989,37 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (g->v2 && g->xcd_pairs > 0 && total_pairs >= 16) chunk = std::min(chunk, g->xcd_pairs);
     RL_TRY(ensure_workspace(g, chunk));
     const size_t vec_len = (size_t)g->D * g->m;
+    // two streams for a product of several chunks (not while the caller's stream
+    // is being captured into a graph: the solver's rounds stay on one stream)
+    bool two = false;
+    // (measured: pays when a pair's intermediates are large and a chunk holds
+    // only a few pairs -- C5, 4.01 -> 3.77 ms per 129-vector product; hurts
+    // when chunks hold hundreds of pairs -- C2, 2.51 -> 2.32 M MVM/s)
+    const char* two_env = getenv("RUNLMC_TWO_STREAMS");
+    const bool want_two = two_env ? atoi(two_env) != 0
+                                  : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
+    if (g->v2 && total_pairs > chunk && want_two) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream == nullptr || hipStreamIsCapturing(stream, &cs) != hipSuccess ||
+            cs == hipStreamCaptureStatusNone) {
+            if (g->T2_pairs < chunk) {
+                if (g->T2) RL_HIP(hipFree(g->T2));
+                g->T2 = nullptr;
+                g->T2_pairs = 0;
+                RL_HIP(hipMalloc((void**)&g->T2, chunk * g->D * (size_t)g->L * sizeof(cplx)));
+                g->T2_pairs = chunk;
+            }
+            if (!g->aux) {
+                RL_HIP(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
+                RL_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+                RL_HIP(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+            }
+            RL_HIP(hipEventRecord(g->ev_fork, stream));
+            RL_HIP(hipStreamWaitEvent(g->aux, g->ev_fork, 0));
+            two = true;
+        }
+    }
+    int parity = 0;
     const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
     const unsigned tilesInv = (colsNeeded + g->colsA - 1) / g->colsA;
     for (size_t p0 = 0; p0 < total_pairs; p0 += chunk) {
@@ -986,7 +1029,14 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         const double* Xc = X + (size_t)v0 * vec_len;
         double* Yc = Y + (size_t)v0 * vec_len;
         if (g->v2) {
-            RL_TRY(mvm_chunk_v2(g, mp, Xc, Yc, nv, pairs, stream));
+            hipStream_t cst = stream;
+            cplx* tb = g->T;
+            if (two) {
+                cst = parity ? g->aux : stream;
+                tb = parity ? g->T2 : g->T;
+                parity ^= 1;
+            }
+            RL_TRY(mvm_chunk_v2(g, mp, Xc, Yc, nv, pairs, cst, nullptr, nullptr, tb));
             continue;
         }
         dim3 gridA(g->N2 / g->colsA, g->D, (unsigned)pairs);
@@ -1003,6 +1053,10 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         dim3 gridI(tilesInv, g->D, (unsigned)pairs);
         RL_LAUNCH(k_cols_inv, gridI, dim3(RL_THREADS), lds_cols(g), stream, g->T, Yc, nv, g->D,
                   g->geo, g->N1, g->N2, g->colsA, g->plan1, g->tw1);
+    }
+    if (two) {
+        RL_HIP(hipEventRecord(g->ev_join, g->aux));
+        RL_HIP(hipStreamWaitEvent(stream, g->ev_join, 0));
     }
     RL_HIP(hipGetLastError());
     return RL_OK;

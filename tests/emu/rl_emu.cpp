@@ -293,6 +293,13 @@ hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* graph) {
     g_capture = nullptr;
     return *graph ? hipSuccess : hipErrorInvalidValue;
 }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* status) {
+    *status = g_capture ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+// every emulated stream runs its work at launch time, in order: nothing to wait for
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, void*, void*, size_t) {
     graph->refs += 1;
     *exec = graph;

@@ -86,6 +86,11 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode mode);
 hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* graph);
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone, hipStreamCaptureStatusActive };
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* status);
+enum { hipEventDisableTiming = 2 };
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipGraphInstantiate(hipGraphExec_t* exec, hipGraph_t graph, void*, void*, size_t);
 hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t s);
 hipError_t hipGraphExecDestroy(hipGraphExec_t exec);

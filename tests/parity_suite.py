@@ -689,3 +689,39 @@ def check_solver_fusions():
         xo, ito, erro, _ = iterative_solve(oop.matvec, B[v], tol=1e-4)
         assert abs(int(res["fused"][1][v]) - ito) <= 5
         _close(res["fused"][0][v], xo, 2e-5)
+
+
+def check_chunked_product():
+    """A batched grid product split into several chunks of intermediates, on one
+    stream and on two (RUNLMC_CHUNK_MB / RUNLMC_TWO_STREAMS), against the
+    oracle and against the unchunked product."""
+    from runlmc_amd._native import GridOp
+    D, Q, m, nvec = 3, 2, 3000, 23
+    rng = np.random.RandomState(11)
+    tops = np.array([np.exp(-(0.02 + 0.1 * q) * np.arange(m)) for q in range(Q)])
+    A = [rng.randn(1, D) for q in range(Q)]
+    kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+    X = rng.randn(nvec, D * m)
+    Bs = ops.coreg_mats(A, kap)
+    toeps = [ops.BTTBOracle(t) for t in tops]
+    ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X[:4]])
+    knobs = ('RUNLMC_CHUNK_MB', 'RUNLMC_TWO_STREAMS')
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    try:
+        g = GridOp(D, m, Q)
+        g.set_lmc(tops, A, kap)
+        whole = g.matmat_host(X)
+        _close(whole[:4], ref, 1e-11)
+        for two in ('0', '1'):
+            os.environ['RUNLMC_CHUNK_MB'] = '1'      # 2-3 pairs per chunk
+            os.environ['RUNLMC_TWO_STREAMS'] = two
+            g2 = GridOp(D, m, Q)
+            g2.set_lmc(tops, A, kap)
+            for _ in range(2):                       # second call reuses both workspaces
+                got = g2.matmat_host(X)
+                assert np.array_equal(got, whole), two
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]

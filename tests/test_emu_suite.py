@@ -127,3 +127,7 @@ def test_onchip_product():
 
 def test_solver_fusions():
     ps.check_solver_fusions()
+
+
+def test_chunked_product():
+    ps.check_chunked_product()
