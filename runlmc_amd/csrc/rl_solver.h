@@ -480,8 +480,7 @@ struct Minres2Bufs {
     double* w[2];
     double* q;          // operator output (unfused), scratch of the checks
     double* x;
-    double* vcopy;      // non-NULL: B also copies the new y here (operator input
-                        // of the unfused product, which cannot follow the rotation)
+    int fuse_wt;        // host side: W^T rides inside the first grid kernel
     double* S[2];
     int* I;
     int* giter;         // number of the current round: bumped by the first kernel of the
@@ -521,7 +520,6 @@ k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ p
         mb.tri[1][off + i] = bi;       // y_0
         mb.w[0][off + i] = 0.0;
         mb.w[1][off + i] = 0.0;
-        if (mb.vcopy != nullptr) mb.vcopy[off + i] = bi;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int c = 0; c < 2; ++c) {
@@ -881,14 +879,12 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
             if (i < hi) {
                 const double yi = py[u] - coef * pr[u];
                 y[off + i] = yi;
-                if (mb.vcopy != nullptr) mb.vcopy[off + i] = yi;
                 acc = fma(yi, yi, acc);
             }
         }
         for (int i = lo + threadIdx.x + PF * blockDim.x; i < hi; i += blockDim.x) {
             const double yi = y[off + i] - coef * r2[off + i];
             y[off + i] = yi;
-            if (mb.vcopy != nullptr) mb.vcopy[off + i] = yi;
             acc = fma(yi, yi, acc);
         }
         acc = block_reduce_sum(acc, red);

@@ -961,6 +961,28 @@ static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, dou
     return RL_OK;
 }
 
+// second chunk of intermediates + side stream of the two-stream batched product
+static int prepare_two_streams(rl_gridop* g, size_t chunk) {
+    if (g->T2_pairs < chunk) {
+        if (g->T2) RL_HIP(hipFree(g->T2));
+        g->T2 = nullptr;
+        g->T2_pairs = 0;
+        RL_HIP(hipMalloc((void**)&g->T2, chunk * g->D * (size_t)g->L * sizeof(cplx)));
+        g->T2_pairs = chunk;
+    }
+    if (!g->aux) {
+        RL_HIP(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
+        RL_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        RL_HIP(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+    }
+    return RL_OK;
+}
+static bool wants_two_streams(const rl_gridop* g) {
+    const char* two_env = getenv("RUNLMC_TWO_STREAMS");
+    return two_env ? atoi(two_env) != 0
+                   : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
+}
+
 static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
                         hipStream_t stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
@@ -989,31 +1011,21 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (g->v2 && g->xcd_pairs > 0 && total_pairs >= 16) chunk = std::min(chunk, g->xcd_pairs);
     RL_TRY(ensure_workspace(g, chunk));
     const size_t vec_len = (size_t)g->D * g->m;
-    // two streams for a product of several chunks (not while the caller's stream
-    // is being captured into a graph: the solver's rounds stay on one stream)
+    // two streams for a product of several chunks
     bool two = false;
     // (measured: pays when a pair's intermediates are large and a chunk holds
     // only a few pairs -- C5, 4.01 -> 3.77 ms per 129-vector product; hurts
     // when chunks hold hundreds of pairs -- C2, 2.51 -> 2.32 M MVM/s)
-    const char* two_env = getenv("RUNLMC_TWO_STREAMS");
-    const bool want_two = two_env ? atoi(two_env) != 0
-                                  : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
+    const bool want_two = wants_two_streams(g);
     if (g->v2 && total_pairs > chunk && want_two) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream == nullptr || hipStreamIsCapturing(stream, &cs) != hipSuccess ||
-            cs == hipStreamCaptureStatusNone) {
-            if (g->T2_pairs < chunk) {
-                if (g->T2) RL_HIP(hipFree(g->T2));
-                g->T2 = nullptr;
-                g->T2_pairs = 0;
-                RL_HIP(hipMalloc((void**)&g->T2, chunk * g->D * (size_t)g->L * sizeof(cplx)));
-                g->T2_pairs = chunk;
-            }
-            if (!g->aux) {
-                RL_HIP(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
-                RL_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-                RL_HIP(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
-            }
+        const bool capturing = stream != nullptr &&
+                               hipStreamIsCapturing(stream, &cs) == hipSuccess &&
+                               cs != hipStreamCaptureStatusNone;
+        // inside a capture nothing may be allocated: the solver prepares the
+        // second workspace beforehand (prepare_two_streams) or stays on one
+        if (!capturing) RL_TRY(prepare_two_streams(g, chunk));
+        if (g->T2_pairs >= chunk && g->aux != nullptr) {
             RL_HIP(hipEventRecord(g->ev_fork, stream));
             RL_HIP(hipStreamWaitEvent(g->aux, g->ev_fork, 0));
             two = true;
@@ -1626,7 +1638,8 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
     const int par = (round - 1) & 1;
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
-    if (mb.W_indptr != nullptr && mb.vcopy == nullptr) {
+    const double* yin = mb.tri[1 - par];      // y_{r-1}: the operator's input this round
+    if (mb.W_indptr != nullptr && mb.fuse_wt) {
         trace_once("minres round: W^T in k2_cols_fwd, W in P");
         // W^T fused into the column transforms (gathered while loading), W into
         // P: three grid kernels, P, B
@@ -1635,7 +1648,7 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         gs.indptr = s->WT_indptr;
         gs.indices = s->WT_indices;
         gs.vals = s->WT_data;
-        gs.src = mb.tri[1 - par];        // y_{r-1}, the operator's input
+        gs.src = yin;
         gs.n = n;
         gs.nnz = s->nnzWT;
         gs.lo = s->WT_lo;
@@ -1644,10 +1657,10 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
                             mb.giter));
     } else if (mb.W_indptr != nullptr) {
         // W product fused into P: only W^T and the grid product run here
-        RL_TRY(ski_wt_int(s, mb.vcopy, s->G1, nrhs, st, mb.giter));
+        RL_TRY(ski_wt_int(s, yin, s->G1, nrhs, st, mb.giter));
         RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nrhs, st));
     } else {
-        RL_TRY(ski_mvm_int(s, mb.vcopy, mb.q, nrhs, st, mb.giter));
+        RL_TRY(ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter));
     }
     RL_LAUNCH(k_minres2_p, grid, blk, red, st, mb, n, par);
     RL_LAUNCH(k_minres2_b, grid, blk, red, st, mb, n, par, rtol, maxiter);
@@ -1732,10 +1745,13 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
 
     SolverWork w;
     SolverWorkGuard guard(&w);
-    RL_TRY(solver_alloc(w, method == RL_MINRES ? 7 : 4, nrhs, n, nblk));
+    RL_TRY(solver_alloc(w, method == RL_MINRES ? 7 : 4, nrhs, n, nblk));      // (vec[5]: v of the
+                                                                             // four-kernel MINRES only)
     // everything the operator product allocates lazily must exist before capture
     RL_TRY(ski_reserve(s, nrhs));
     RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
+    if (s->g->v2 && ((size_t)nrhs + 1) / 2 > s->g->chunk_pairs && wants_two_streams(s->g))
+        RL_TRY(prepare_two_streams(s->g, s->g->chunk_pairs));
     for (const SkiTerm& t : s->extra)
         RL_TRY(ensure_workspace(t.g, std::min(((size_t)nrhs + 1) / 2, t.g->chunk_pairs)));
     int active = nrhs;
@@ -1757,7 +1773,6 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         Minres2Bufs mb;
         mb.tri[0] = w.vec[0]; mb.tri[1] = w.vec[1];
         mb.w[0] = w.vec[3]; mb.w[1] = w.vec[4];
-        mb.vcopy = w.vec[5];
         mb.q = w.vec[6];
         mb.x = Xi;
         mb.S[0] = w.S[0]; mb.S[1] = w.S[1];
@@ -1780,7 +1795,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
                              ((size_t)nrhs + 1) / 2 <= s->g->chunk_pairs &&
                              !(s->g->v4 && nrhs >= s->g->v4_min) &&
                              getenv("RUNLMC_NO_FUSE_WT") == nullptr;
-        if (fuse_wt) mb.vcopy = nullptr;
+        mb.fuse_wt = fuse_wt ? 1 : 0;
         mb.W_indices = s->W_indices;
         mb.W_data = s->W_data;
         mb.W_nnz = s->nnz;
