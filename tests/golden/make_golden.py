@@ -339,6 +339,9 @@ def gen_lmc():
 
 
 def _main():
+    if '--fit-data-only' in sys.argv:
+        gen_fit_data()
+        return
     if '--2d-only' in sys.argv:
         return gen_2d()
     if '--split-only' in sys.argv:
@@ -398,6 +401,54 @@ def load_weather():
         xss.append(xy['time'].values.astype(float))
         yss.append(xy['ATMP'].values.astype(float))
     return xss, yss
+
+
+def gen_fit_data():
+    """Train / held-out splits of the two real-data workloads exactly as the
+    reference's benchmark drivers build them (standard_tester.py:86-148), raw
+    (un-normalised): inputs of examples/fit_real_data.py."""
+    import pandas as pd
+    d = os.path.join(REF, 'data', 'fx')
+    fx = pd.concat([pd.read_csv(os.path.join(d, f), index_col=1)
+                    for f in ('2007-2009.csv', '2010-2013.csv', '2014-2017.csv')])
+    fx.drop(['Wdy', 'Jul.Day'], axis=1, inplace=True)
+    fx.rename(columns={c: c[:3] for c in fx.columns}, inplace=True)
+    fx = fx.loc['2007/01/01':'2008/01/01']
+    holdout = {'CAD': slice(49, 99), 'JPY': slice(99, 149), 'AUD': slice(149, 199)}
+    arrs = {'names': np.array(list(fx.columns))}
+    all_ixs = np.arange(len(fx))
+    for i, col in enumerate(fx.columns):
+        hold = holdout.get(col, slice(0, 0))
+        keep = np.ones(len(fx), dtype=bool)
+        keep[fx[col].isnull().values] = False
+        keep[hold] = False
+        idx = np.flatnonzero(keep)
+        arrs['x%d' % i] = idx.astype(float)
+        arrs['y%d' % i] = np.reciprocal(fx[col].values[idx])
+        arrs['tx%d' % i] = all_ixs[hold].astype(float)
+        arrs['ty%d' % i] = np.reciprocal(fx.iloc[hold][col].values.astype(float))
+    _save('fit_fx2007.npz', **arrs)
+
+    d = os.path.join(REF, 'data', 'weather')
+    holds = [None, (10.2, 10.8), (13.5, 14.2), None]
+    arrs = {'names': np.array(['bra', 'cam', 'chi', 'sot'])}
+    for i, (sensor, hold) in enumerate(zip(['bra', 'cam', 'chi', 'sot'], holds)):
+        y = pd.read_csv(os.path.join(d, sensor + 'y.csv'), header=None,
+                        names=['WSPD', 'WD', 'GST', 'ATMP'], usecols=['ATMP'])
+        x = pd.read_csv(os.path.join(d, sensor + 'x.csv'), header=None, names=['time'])
+        y.loc[y['ATMP'] == -1, 'ATMP'] = np.nan
+        y = y.dropna()
+        xy = pd.concat([x, y], axis=1, join='inner')
+        if hold is None:
+            tr, te = xy, xy.iloc[0:0]
+        else:
+            sel = xy['time'].between(hold[0], hold[1])
+            tr, te = xy.loc[~sel], xy.loc[sel]
+        arrs['x%d' % i] = tr['time'].values.astype(float)
+        arrs['y%d' % i] = tr['ATMP'].values.astype(float)
+        arrs['tx%d' % i] = te['time'].values.astype(float)
+        arrs['ty%d' % i] = te['ATMP'].values.astype(float)
+    _save('fit_weather.npz', **arrs)
 
 
 def _normalise(yss):
