@@ -725,3 +725,25 @@ def check_chunked_product():
             os.environ.pop(k, None)
             if saved[k] is not None:
                 os.environ[k] = saved[k]
+
+
+def check_block_cg_weather():
+    """BASELINE config 4: the weather workload (D=4, 2 SLFM + 4 independent
+    kernels, n=15789), a block of 8 right-hand sides solved with CG in one
+    batched call; against the oracle's CG on the first two, residuals
+    recomputed through the oracle operator on all."""
+    c = Case('weather')
+    fk, K, gk = build_operator(c)
+    op = olik.LMCOperatorOracle(c.spec(), c.grid_dists, c.W, c.WT, c.lens, active_dim=c.ad)
+    rng = np.random.RandomState(4)
+    B = np.vstack([c.y] + [rng.randint(0, 2, c.n) * 2.0 - 1 for _ in range(7)])
+    X, iters, resid = Iterative.solve(K, B, verbose=True, minres=False, tol=1e-4)
+    assert X.shape == B.shape
+    for i in range(len(B)):
+        true_res = np.linalg.norm(B[i] - op.matvec(X[i]))
+        assert abs(true_res - resid[i]) <= 1e-9 + 1e-6 * true_res
+        assert resid[i] < 1e-4
+    for i in range(2):
+        xo, ito, erro, _ = iterative_solve(op.matvec, B[i], tol=1e-4, minres=False)
+        assert abs(int(iters[i]) - ito) <= max(6, ito // 5), (iters[i], ito)
+        _close(X[i], xo, rel=1e-5)

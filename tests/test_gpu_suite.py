@@ -102,3 +102,7 @@ def test_solver_fusions():
 
 def test_chunked_product():
     ps.check_chunked_product()
+
+
+def test_block_cg_weather():
+    ps.check_block_cg_weather()

@@ -82,6 +82,59 @@ def test_two_rank_probe_sharding():
     assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
 
 
+def _block_solve():
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import parity_suite as ps
+    from cases import Case
+    from runlmc_amd.approx.iterative import Iterative
+    c = Case('lmc_c1')
+    fk, K, gk = ps.build_operator(c)
+    rng = np.random.RandomState(9)
+    B = np.vstack([c.y] + [rng.randn(c.n) for _ in range(4)])      # 5 right-hand sides
+    return Iterative.solve_sharded(K, B, minres=False, tol=1e-4)    # CG, as config 4
+
+
+def _worker_block(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.EMU_LIB)
+    X, it, rs = _block_solve()
+    q.put((rank, X, it, rs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_block_of_right_hand_sides():
+    """BASELINE config 4's axis: a block of right-hand sides (CG) split over
+    ranks, gathered with one all-reduce; both ranks end with every solution,
+    equal to the one-process block solve."""
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.build_emu())
+    try:
+        Xr, itr, rsr = _block_solve()
+    finally:
+        _lib.use_library(None)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_block, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+    assert np.all(got[0][3] < 1e-4) and np.all(rsr < 1e-4)
+    # (which vectors share a transform differs between the two partitions)
+    assert np.abs(got[0][1] - Xr).max() < 1e-6 * np.abs(Xr).max()
+    assert np.all(np.abs(got[0][2] - itr) <= np.maximum(6, itr // 5))
+
+
 def test_shard_rows_partition():
     from runlmc_amd.util.dist import shard_rows, rank_world
     assert rank_world() == (0, 1)
