@@ -745,5 +745,8 @@ def check_block_cg_weather():
         assert resid[i] < 1e-4
     for i in range(2):
         xo, ito, erro, _ = iterative_solve(op.matvec, B[i], tol=1e-4, minres=False)
-        assert abs(int(iters[i]) - ito) <= max(6, ito // 5), (iters[i], ito)
-        _close(X[i], xo, rel=1e-5)
+        # both stop on the explicit ||b - K x|| < 1e-4 rule, evaluated every 100
+        # iterations: a residual within roundoff of 1e-4 at a check moves the
+        # exit by one check period
+        assert abs(int(iters[i]) - ito) <= 100, (iters[i], ito)
+        _close(X[i], xo, rel=1e-4)
