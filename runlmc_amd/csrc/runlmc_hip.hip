@@ -147,6 +147,10 @@ static void choose_length(int m, int* L_out, int* N1_out, int* N2_out) {
         }
         if (bestN2) N2 = bestN2;
     }
+    if (const char* e = getenv("RUNLMC_N2")) {      // experiment knob: force the row length
+        const int n2 = atoi(e);
+        if (n2 >= 8 && (n2 & (n2 - 1)) == 0 && L % n2 == 0 && L / n2 >= 4) N2 = n2;
+    }
     *L_out = L;
     *N2_out = N2;
     *N1_out = L / N2;
