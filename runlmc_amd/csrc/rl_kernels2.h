@@ -431,3 +431,90 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// k1_product<D>: the whole product of one PAIR of vectors in one workgroup,
+// for grids short enough that all D transforms of the pair fit one LDS tile
+// (L * (D | 1) * 16 bytes: the reference's README, FX2007 and weather
+// workloads).  One kernel instead of three, no intermediates in global memory,
+// and -- unlike k4_product -- pair packing is kept, so nothing is untangled:
+//   pad + pack the pair ->
+//   single-level in-place transform of all D outputs side by side ->
+//   real D x D mix at every position -> adjoint transform -> crop, unpack.
+// Spectra for this kernel: [Q][L] in the scrambled order of the single-level
+// transform, made by the same kernel (mode 1: X = tops, two per transform).
+//   grid (npairs)   block up to RL_THREADS2
+// LDS: tile [L][ld], ld = D | 1, then the twiddle table [L]
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(RL_THREADS2)
+k1_product(const double* __restrict__ X, double* __restrict__ Y, int nvec, Geom geo, int mode,
+           FftPlan plan, const cplx* __restrict__ twL, MixParams mp,
+           double* __restrict__ spec_out) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int L = plan.n, m = geo.m;
+    constexpr int ld = D | 1;
+    cplx* tw = tile + (size_t)L * ld;
+    const int pair = blockIdx.x;
+    const int v0 = 2 * pair, v1 = 2 * pair + 1;
+    const bool has1 = v1 < nvec;
+
+    load_table(tw, twL, L, tid, nthr);
+    if (mode == 1) {
+        // spectra: circulant columns of tops v0, v1 (one output column)
+        const double* t0 = X + (size_t)v0 * m;
+        const double* t1 = X + (size_t)v1 * m;
+        for (int n = tid; n < L; n += nthr) {
+            const int src = padded_source(geo, 0, n, 1, L, 1);
+            double re = 0.0, im = 0.0;
+            if (src >= 0) {
+                re = t0[src];
+                if (has1) im = t1[src];
+            }
+            tile[(size_t)n * ld] = c_make(re, im);
+        }
+    } else {
+        for (int w = tid; w < D * L; w += nthr) {
+            const int b = w / L, n = w - b * L;         // n fastest: coalesced reads
+            double re = 0.0, im = 0.0;
+            if (n < m) {
+                re = X[((size_t)v0 * D + b) * m + n];
+                if (has1) im = X[((size_t)v1 * D + b) * m + n];
+            }
+            tile[(size_t)n * ld + b] = c_make(re, im);
+        }
+    }
+    __syncthreads();
+    const int cols = mode == 1 ? 1 : D;
+    fft_tile_forward(tile, plan, cols, ld, tw, tid, nthr);
+
+    if (mode == 1) {
+        const double scale = 1.0 / (double)L;
+        for (int pos = tid; pos < L; pos += nthr) {
+            const cplx z = tile[(size_t)pos * ld];
+            spec_out[(size_t)v0 * L + pos] = z.x * scale;
+            if (has1) spec_out[(size_t)v1 * L + pos] = z.y * scale;
+        }
+        return;
+    }
+    for (int pos = tid; pos < L; pos += nthr) {
+        cplx* zp = tile + (size_t)pos * ld;
+        cplx z[D];
+#pragma unroll
+        for (int b = 0; b < D; ++b) z[b] = zp[b];
+        mix_point<D>(z, mp, (size_t)L, (size_t)pos);
+#pragma unroll
+        for (int a = 0; a < D; ++a) zp[a] = z[a];
+    }
+    __syncthreads();
+    fft_tile_adjoint(tile, plan, D, ld, tw, tid, nthr);
+
+    for (int w = tid; w < D * m; w += nthr) {
+        const int b = w / m, n = w - b * m;
+        const cplx z = tile[(size_t)n * ld + b];
+        Y[((size_t)v0 * D + b) * m + n] = z.x;
+        if (has1) Y[((size_t)v1 * D + b) * m + n] = z.y;
+    }
+}

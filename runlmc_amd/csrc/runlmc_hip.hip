@@ -243,6 +243,15 @@ struct rl_gridop {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t chunk_pairs = 1;
     size_t xcd_pairs = 0;   // pairs per XCD-affine chunk (0: affinity off)
+    // single-tile product (k1_product): grids short enough that all D transforms
+    // of a pair fit one LDS tile
+    bool v1p = false;
+    FftPlan planL;
+    cplx* twL = nullptr;       // exp(-2 pi i k / L)
+    double* spec1 = nullptr;   // dev [max_tops][L], scrambled order of the single-level transform
+    size_t lds1 = 0;
+    int thr1 = 256;
+    int v1p_min = 64;          // vectors from which the single-tile product is used
     // on-chip product (rl_kernels4.h): available for short 1-D grids, used for
     // batches of at least v4_min vectors
     bool v4 = false;
@@ -394,6 +403,35 @@ static FftPlan make_plan4(int n) {
         for (int i = 0; i < np; ++i) p.radix[p.npass++] = (i >= np - extra) ? 4 : 8;
     }
     return p;
+}
+
+// single-tile product (k1_product<D>)
+template <int D>
+static void launch1p_d(rl_gridop* g, unsigned pairs, hipStream_t st, const double* X, double* Y,
+                       int nvec, int mode, const MixParams& mp, double* spec_out) {
+#if !defined(RL_EMU)
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        (void)hipFuncSetAttribute((const void*)k1_product<D>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+#endif
+    const size_t lds = ((size_t)g->L * (D | 1) + g->L) * sizeof(cplx);
+    RL_LAUNCH((k1_product<D>), dim3(pairs), dim3(g->thr1), lds, st, X, Y, nvec, g->geo, mode,
+              g->planL, g->twL, mp, spec_out);
+}
+static int launch1p(rl_gridop* g, int D, unsigned pairs, hipStream_t st, const double* X,
+                    double* Y, int nvec, int mode, const MixParams& mp, double* spec_out) {
+    switch (D) {
+#define RL_CASE(d) \
+    case d: launch1p_d<d>(g, pairs, st, X, Y, nvec, mode, mp, spec_out); return RL_OK;
+        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
+        RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
+        RL_CASE(14) RL_CASE(15) RL_CASE(16)
+#undef RL_CASE
+        default: return fail(RL_ELIMIT, "unsupported D");
+    }
 }
 
 static int plan4_create(rl_gridop* g) {
@@ -630,6 +668,19 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     }
 
     if ((rc = plan4_create(g)) != RL_OK) return rc;
+    // single-tile product for short grids
+    if (m1 == 0 && L <= 2048 && getenv("RUNLMC_NO_V1P") == nullptr) {
+        const size_t lds = ((size_t)L * (D | 1) + L) * sizeof(cplx);
+        if (lds <= kLdsHard) {
+            g->planL = make_plan(L);
+            if ((rc = upload(&g->twL, unity_table(L, 1, L))) != RL_OK) return rc;
+            RL_HIP(hipMalloc((void**)&g->spec1, (size_t)max_tops * L * sizeof(double)));
+            g->lds1 = lds;
+            g->thr1 = (size_t)D * L >= 4096 ? 512 : 256;
+            g->v1p = true;
+            if (const char* e = getenv("RUNLMC_V1P_MIN")) g->v1p_min = std::max(1, atoi(e));
+        }
+    }
     *out = guard.release();
     return RL_OK;
 }
@@ -640,7 +691,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->spec4, g->tw4A, g->tw4B, g->tw4lo, g->tw4hi, g->untw4, g->freq4A,
-                    g->pos4, g->T2};
+                    g->pos4, g->T2, g->twL, g->spec1};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -685,6 +736,11 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     dim3 gridS(g->N1 / g->rowsS, npairs);
     RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
               g->spec, ntop, g->N1, g->N2, g->rowsS, g->plan2, g->tw2);
+    if (g->v1p) {
+        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        RL_TRY(launch1p(g, 1, (unsigned)npairs, stream, g->tops, nullptr, ntop, 1, none,
+                        g->spec1));
+    }
     if (g->v4 && g->v4_min < (1 << 30)) {        // only when the path is switched on
         MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
         RL_TRY(launch4(1, g->ep4, dim3(ntop), dim3(g->thr4), g->lds4, stream, g->tops, nullptr,
@@ -996,6 +1052,20 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_HIP(hipSetDevice(g->device));
+    if (g->v1p && (nvec >= g->v1p_min || g->D <= 2)) {
+        // short grid, enough pairs to fill the chip with one workgroup per pair
+        // (measured: D=13, m=238: 21 vs 46 us at 256 vectors, 95 vs 228 us at 2048,
+        // but 19.6 vs 16.5 us at 16 -- a few workgroups walking all D transforms
+        // are slower than three launches spread over the chip): one kernel,
+        // nothing through global memory
+        trace_once("grid product: k1_product (single tile)");
+        MixParams mp1 = mp;
+        mp1.spec = g->spec1 + (mp.spec - g->spec);
+        RL_TRY(launch1p(g, g->D, (unsigned)(((size_t)nvec + 1) / 2), stream, X, Y, nvec, 0, mp1,
+                        nullptr));
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
     if (g->v4 && nvec >= g->v4_min) {
         // the whole product on chip, one workgroup per vector
         trace_once("grid product: k4_product (on chip)");

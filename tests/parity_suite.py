@@ -750,3 +750,45 @@ def check_block_cg_weather():
         # exit by one check period
         assert abs(int(iters[i]) - ito) <= 100, (iters[i], ito)
         _close(X[i], xo, rel=1e-4)
+
+
+def check_single_tile_product():
+    """The single-tile product (k1_product: one workgroup per pair, short
+    grids), forced for every batch size, against the oracle: factored and
+    dense mixes, single top row, odd batches; and at its default threshold."""
+    from runlmc_amd._native import GridOp
+    old = os.environ.get('RUNLMC_V1P_MIN')
+    try:
+        for forced in (True, False):
+            if forced:
+                os.environ['RUNLMC_V1P_MIN'] = '1'
+            else:
+                os.environ.pop('RUNLMC_V1P_MIN', None)
+            for D, Q, m, nvec in [(1, 1, 3, 1), (2, 1, 104, 3), (13, 1, 238, 5), (4, 6, 504, 7),
+                                  (3, 2, 640, 2), (16, 2, 100, 4), (5, 3, 200, 70)]:
+                if not forced and nvec < 64:
+                    continue
+                rng = np.random.RandomState(D * 1000 + Q * 100 + m)
+                tops = np.array([np.exp(-(0.02 + 0.1 * q) * np.arange(m) ** (1 + 0.3 * (q % 2)))
+                                 for q in range(Q)])
+                A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+                kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+                g = GridOp(D, m, Q)
+                g.set_lmc(tops, A, kap)
+                X = rng.randn(nvec, D * m)
+                Y = g.matmat_host(X)
+                Bs = ops.coreg_mats(A, kap)
+                toeps = [ops.BTTBOracle(t) for t in tops]
+                ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X[:6]])
+                _close(Y[:6], ref, 1e-11)
+                g.set_dense(tops, np.array(Bs))
+                _close(g.matmat_host(X), Y, 1e-11)
+                Y1 = g.matmat_host(X[:1], top=Q - 1) if forced else None
+                if Y1 is not None:
+                    ref1 = np.array([toeps[Q - 1].matvec(r) for r in X[0].reshape(D, m)]).ravel()
+                    _close(Y1[0], ref1, 1e-11)
+    finally:
+        if old is None:
+            os.environ.pop('RUNLMC_V1P_MIN', None)
+        else:
+            os.environ['RUNLMC_V1P_MIN'] = old

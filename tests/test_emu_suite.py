@@ -131,3 +131,7 @@ def test_solver_fusions():
 
 def test_chunked_product():
     ps.check_chunked_product()
+
+
+def test_single_tile_product():
+    ps.check_single_tile_product()

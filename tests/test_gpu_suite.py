@@ -106,3 +106,7 @@ def test_chunked_product():
 
 def test_block_cg_weather():
     ps.check_block_cg_weather()
+
+
+def test_single_tile_product():
+    ps.check_single_tile_product()
