@@ -784,8 +784,29 @@ extern "C" int rl_gridop_set_lmc(rl_gridop* g, int Q, const double* tops, const 
     std::vector<double> A, W, kap(coreg_diags, coreg_diags + (size_t)Q * D);
     std::vector<int> Qi;
     size_t row = 0;
+    long total_rank = 0;
     for (int q = 0; q < Q; ++q) {
         if (ranks[q] < 0) return fail(RL_EINVAL, "rl_gridop_set_lmc: negative rank");
+        total_rank += ranks[q];
+    }
+    if (total_rank > g->max_fac) {
+        // more factors than the handle was sized for (ranks above D are redundant
+        // but legal in the reference): fold into dense B_q = A_q^T A_q + diag(kappa_q),
+        // which re-factors to at most D factors per kernel
+        if (!coreg_vecs) return fail(RL_EINVAL, "rl_gridop_set_lmc: coreg_vecs is NULL");
+        std::vector<double> B((size_t)Q * D * D, 0.0);
+        for (int q = 0; q < Q; ++q) {
+            for (int r = 0; r < ranks[q]; ++r, ++row)
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j)
+                        B[((size_t)q * D + i) * D + j] +=
+                            coreg_vecs[row * D + i] * coreg_vecs[row * D + j];
+            for (int i = 0; i < D; ++i)
+                B[((size_t)q * D + i) * D + i] += coreg_diags[(size_t)q * D + i];
+        }
+        return rl_gridop_set_dense(g, Q, tops, B.data());
+    }
+    for (int q = 0; q < Q; ++q) {
         if (ranks[q] > 0 && !coreg_vecs)
             return fail(RL_EINVAL, "rl_gridop_set_lmc: coreg_vecs is NULL");
         for (int r = 0; r < ranks[q]; ++r, ++row) {
