@@ -792,3 +792,23 @@ def check_single_tile_product():
             os.environ.pop('RUNLMC_V1P_MIN', None)
         else:
             os.environ['RUNLMC_V1P_MIN'] = old
+
+
+def check_rank_above_outputs():
+    """Coregionalisation ranks above D (redundant, legal in the reference:
+    functional_kernel.py:113-133 draws any R_q x D block): more factors than the
+    handle holds are folded into the dense re-factorisation."""
+    from runlmc_amd._native import GridOp
+    rng = np.random.RandomState(5)
+    for D, ranks in ((1, [2, 2]), (2, [3, 4]), (3, [5])):
+        Q, m = len(ranks), 90
+        tops = np.array([np.exp(-(0.05 + 0.1 * q) * np.arange(m)) for q in range(Q)])
+        A = [rng.randn(r, D) for r in ranks]
+        kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+        g = GridOp(D, m, Q)
+        g.set_lmc(tops, A, kap)
+        X = rng.randn(3, D * m)
+        Bs = ops.coreg_mats(A, kap)
+        toeps = [ops.BTTBOracle(t) for t in tops]
+        ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X])
+        _close(g.matmat_host(X), ref, 1e-11)

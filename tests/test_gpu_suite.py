@@ -110,3 +110,7 @@ def test_block_cg_weather():
 
 def test_single_tile_product():
     ps.check_single_tile_product()
+
+
+def test_rank_above_outputs():
+    ps.check_rank_above_outputs()
