@@ -24,22 +24,32 @@ def test_random_shapes_vs_oracle():
         nvec = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70, 130]))
         if D * m * nvec > 3e6:
             nvec = max(1, int(3e6 // (D * m)))
-        tops = np.array([np.exp(-(0.01 + 0.2 * rng.rand()) * np.arange(m) ** (1 + 0.4 * rng.rand()))
-                         for _ in range(Q)])
+        sizes = None
+        if rng.rand() < 0.25:                       # a two-dimensional (BTTB) grid
+            sizes = (int(rng.randint(1, 60)), int(rng.randint(1, 60)))
+            m = sizes[0] * sizes[1]
+            if D * m * nvec > 3e6:
+                nvec = max(1, int(3e6 // (D * m)))
+            i1, i2 = np.meshgrid(np.arange(sizes[0]), np.arange(sizes[1]), indexing='ij')
+            r = np.sqrt(i1 ** 2 + (0.7 * i2) ** 2).ravel()
+            tops = np.array([np.exp(-(0.05 + 0.3 * rng.rand()) * r) for _ in range(Q)])
+        else:
+            tops = np.array([np.exp(-(0.01 + 0.2 * rng.rand()) *
+                                    np.arange(m) ** (1 + 0.4 * rng.rand())) for _ in range(Q)])
         A = [rng.randn(int(rng.randint(0, 3)), D) for _ in range(Q)]
         A = [a if len(a) else None for a in A]
         kap = [np.abs(rng.randn(D)) + 0.05 for _ in range(Q)]
-        g = GridOp(D, m, Q)
+        g = GridOp(D, m, Q, sizes=sizes)
         g.set_lmc(tops, A, kap)
         X = rng.randn(nvec, D * m)
         Y = g.matmat_host(X)
         Bs = ops.coreg_mats([a if a is not None else np.zeros((0, D)) for a in A], kap)
-        toeps = [ops.BTTBOracle(t) for t in tops]
+        toeps = [ops.BTTBOracle(t, sizes) if sizes else ops.BTTBOracle(t) for t in tops]
         for v in sorted(set([0, nvec - 1, nvec // 2])):
             ref = ops.grid_sum_matvec(Bs, toeps, X[v])
             err = np.abs(Y[v] - ref).max() / max(np.abs(ref).max(), 1e-300)
             worst = max(worst, err)
-            assert err < 1e-11, (draw, D, Q, m, nvec, v, g.L, g.N1, g.N2, err)
+            assert err < 1e-11, (draw, D, Q, m, sizes, nvec, v, g.L, g.N1, g.N2, err)
     print('fuzz: %d shapes, worst relative error %.2e' % (n_draws, worst))
 
 
