@@ -75,7 +75,10 @@ def build_emu(force=False, sanitize=False):
 
 
 if __name__ == '__main__':
-    if '--emu' in sys.argv:
+    if '--timing' in sys.argv:
+        # experiment build with in-kernel phase stamps (rl_device.h: RL_TIMING)
+        print(build_hip(force=True, extra=['-DRL_TIMING']))
+    elif '--emu' in sys.argv:
         print(build_emu(force='--force' in sys.argv, sanitize='--asan' in sys.argv))
     else:
         print(build_hip(force='--force' in sys.argv))

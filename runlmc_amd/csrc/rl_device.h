@@ -26,6 +26,21 @@
 
 #include <stdint.h>
 
+// RL_TIMING (experiment builds only: python -m runlmc_amd.build --timing):
+// kernels stamp s_memtime at their phase boundaries into a global buffer that
+// rl_debug_timing() reads back -- the only way to see where a latency-bound
+// kernel's microseconds go.
+#if defined(RL_TIMING) && !defined(RL_EMU)
+__device__ long long rl_timing_buf[256];
+#define RL_STAMP(slot)                                                           \
+    do {                                                                         \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+            rl_timing_buf[slot] = wall_clock64();                                \
+    } while (0)
+#else
+#define RL_STAMP(slot) do { } while (0)
+#endif
+
 struct __attribute__((aligned(16))) cplx {
     double x, y;
 };

@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(RL_THREADS2)
 k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
             cplx* __restrict__ T, Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1,
             const int* __restrict__ freq1, TwiddleL twl, Gather gs) {
+    RL_STAMP(10);
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -229,8 +230,10 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
 #pragma unroll
         for (int k = 0; k < RA; ++k) tile[(size_t)(j + sub * k) * C + c] = v[k];
     }
+    RL_STAMP(11);
     __syncthreads();
     middle_forward(tile, plan1, C, C, tw1, tid, nthr, 0);
+    RL_STAMP(12);
 
     cplx* out = T + ((size_t)pair * D + b) * L;
     for (int w = tid; w < (N1 / RB) * C; w += nthr) {
@@ -248,6 +251,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
             out[(size_t)r * N2 + n2] = z;
         }
     }
+    RL_STAMP(13);
 }
 
 // ---------------------------------------------------------------------------
@@ -257,6 +261,7 @@ template <int RA, int RB>
 __global__ void __launch_bounds__(RL_THREADS2)
 k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, Geom geo,
             Tile2 tp, FftPlan plan1, const cplx* __restrict__ tw1) {
+    RL_STAMP(30);
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -282,8 +287,10 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
 #pragma unroll
         for (int i = 0; i < RB; ++i) tile[(size_t)(g + i) * C + c] = v[i];
     }
+    RL_STAMP(32);
     __syncthreads();
     middle_adjoint(tile, plan1, C, C, tw1, tid, nthr, 0);
+    RL_STAMP(33);
 
     // adjoint of the first forward pass, straight into the cropped output
     const int sub = N1 / RA;
@@ -312,6 +319,7 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
             }
         }
     }
+    RL_STAMP(31);
 }
 
 // ---------------------------------------------------------------------------
@@ -363,6 +371,7 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
             const int* __restrict__ freq1, TwiddleL twl, MixParams mp, int* __restrict__ bump) {
     // the solver's round counter when W^T is fused into k2_cols_fwd (which reads
     // it): advanced here, by a kernel that does not
+    RL_STAMP(20);
     if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
@@ -391,10 +400,12 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
 #pragma unroll
         for (int k = 0; k < RA; ++k) tile[(size_t)(j + sub * k) * ld + col] = v[k];
     }
+    RL_STAMP(22);
     __syncthreads();
     middle_forward(tile, plan2, cols, ld, tw2, tid, nthr, tp.colsMagic);
     fft_pass<RB, false>(tile, N2, RB, cols, ld, tw2, tid, nthr, tp.colsMagic);
     __syncthreads();
+    RL_STAMP(23);
 
     for (int idx = tid; idx < R * N2; idx += nthr) {
         const int pos = idx & (N2 - 1), rr = idx / N2;
@@ -406,10 +417,12 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
 #pragma unroll
         for (int a = 0; a < D; ++a) zp[a] = z[a];
     }
+    RL_STAMP(24);
     __syncthreads();
     fft_pass<RB, true>(tile, N2, RB, cols, ld, tw2, tid, nthr, tp.colsMagic);
     __syncthreads();
     middle_adjoint(tile, plan2, cols, ld, tw2, tid, nthr, tp.colsMagic);
+    RL_STAMP(25);
 
     for (int w = tid; w < sub * cols; w += nthr) {
         const int j = w & (sub - 1), col = w >> logsub;
@@ -430,6 +443,7 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
             dst[n2] = z;
         }
     }
+    RL_STAMP(21);
 }
 
 // ---------------------------------------------------------------------------

@@ -543,6 +543,7 @@ k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ p
 
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_p(Minres2Bufs mb, int n, int par) {
+    RL_STAMP(0);
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y;
@@ -683,7 +684,9 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     double alfa = 0.0, beta = si[S_BETA], oldb = si[S_BETA];
     double tnorm2 = 0.0, delta = 0.0, gbar = 0.0, epsln = 0.0, dbar = 0.0, root = 0.0;
     double gamma = 1.0, cs = 0.0, sn = 0.0, phi = 0.0, phibar = 0.0, denom = 0.0, oldeps = 0.0;
+    RL_STAMP(1);
     block_reduce_sum2(part_a, part_b, red);
+    RL_STAMP(2);
     if (fin) {
         alfa = part_a;
         beta = sqrt(part_b > 0.0 ? part_b : 0.0);
@@ -708,6 +711,7 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     const double sinv = beta > 0.0 ? 1.0 / beta : 0.0;
     const double coef = fin ? beta * oinv : 0.0;
 
+    RL_STAMP(3);
     double accA = 0.0, accC = 0.0;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -753,15 +757,49 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
         y[off + i] = yi;
         accA = fma(r2i * sinv, yi, accA);
     }
+    RL_STAMP(4);
     block_reduce_sum2(accA, accC, red);
+    RL_STAMP(5);
     if (threadIdx.x == 0) {
         mb.partA[1 - p2][(size_t)rhs * nblk + blockIdx.x] = accA;
         mb.partC[(size_t)rhs * nblk + blockIdx.x] = accC;
     }
 
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int f = 0; f < S_NFIELDS; ++f) so[f] = si[f];
+    // publish the new scalar state: one field per thread of workgroup 0 (every
+    // thread holds the scalars; a single thread writing 45 values one after the
+    // other was 2.9 us of this kernel)
+    if (blockIdx.x == 0 && threadIdx.x < S_NFIELDS) {
+        const int f = threadIdx.x;
+        double v = si[f];
         if (fin) {
+            const double gmax = si[S_GMAX] > gamma ? si[S_GMAX] : gamma;
+            const double gmin = si[S_GMIN] < gamma ? si[S_GMIN] : gamma;
+            const double z = si[S_RHS1] / gamma;
+            switch (f) {
+                case S_OLDB: v = oldb; break;
+                case S_BETA: v = beta; break;
+                case S_TNORM2: v = tnorm2; break;
+                case S_DBAR: v = dbar; break;
+                case S_EPSLN: v = epsln; break;
+                case S_CS: v = cs; break;
+                case S_SN: v = sn; break;
+                case S_PHIBAR: v = phibar; break;
+                case S_PHI: v = phi; break;
+                case S_ALFA: v = alfa; break;
+                case S_OLDEPS: v = oldeps; break;
+                case S_DELTA: v = delta; break;
+                case S_DENOM: v = denom; break;
+                case S_ROOT: v = root; break;
+                case S_GBAR: v = gbar; break;
+                case S_GMAX: v = gmax; break;
+                case S_GMIN: v = gmin; break;
+                case S_RHS1: v = si[S_RHS2] - delta * z; break;
+                case S_RHS2: v = -epsln * z; break;
+                default: break;
+            }
+        }
+        so[f] = v;
+        if (f == 0 && fin) {
             // Lanczos tridiagonal entries (stochastic Lanczos quadrature of log det)
             const int itn = round - 2;          // iterations finished before this one
             if (mb.lanczos != nullptr && itn < mb.lanczos_cap) {
@@ -769,30 +807,9 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
                 lz[0] = alfa;
                 lz[1] = beta;
             }
-            so[S_OLDB] = oldb;
-            so[S_BETA] = beta;
-            so[S_TNORM2] = tnorm2;
-            so[S_DBAR] = dbar;
-            so[S_EPSLN] = epsln;
-            so[S_CS] = cs;
-            so[S_SN] = sn;
-            so[S_PHIBAR] = phibar;
-            so[S_PHI] = phi;
-            so[S_ALFA] = alfa;
-            so[S_OLDEPS] = oldeps;
-            so[S_DELTA] = delta;
-            so[S_DENOM] = denom;
-            so[S_ROOT] = root;
-            so[S_GBAR] = gbar;
-            const double gmax = si[S_GMAX] > gamma ? si[S_GMAX] : gamma;
-            const double gmin = si[S_GMIN] < gamma ? si[S_GMIN] : gamma;
-            so[S_GMAX] = gmax;
-            so[S_GMIN] = gmin;
-            const double z = si[S_RHS1] / gamma;
-            so[S_RHS1] = si[S_RHS2] - delta * z;
-            so[S_RHS2] = -epsln * z;
         }
     }
+    RL_STAMP(6);
 }
 
 // SciPy's stopping tests for the iteration whose state is `st` (k_minres_test)
@@ -824,6 +841,7 @@ __device__ __forceinline__ int minres_stop_test(const double* st, double ynorm, 
 
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
+    RL_STAMP(40);
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y;
@@ -890,6 +908,7 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
         acc = block_reduce_sum(acc, red);
         if (threadIdx.x == 0) mb.partB[(size_t)rhs * nblk + blockIdx.x] = acc;
     }
+    RL_STAMP(41);
 }
 
 // ---- CG ---------------------------------------------------------------------

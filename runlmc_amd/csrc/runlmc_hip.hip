@@ -2046,6 +2046,16 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     return RL_OK;
 }
 
+#if defined(RL_TIMING) && !defined(RL_EMU)
+// experiment builds: the phase stamps of the last launches (see rl_device.h)
+extern "C" int rl_debug_timing(long long* out, int count) {
+    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rl_timing_buf),
+                               (size_t)std::min(count, 256) * sizeof(long long)));
+    return RL_OK;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // gradient partial sums
 // ---------------------------------------------------------------------------
