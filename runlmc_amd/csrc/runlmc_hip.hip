@@ -937,6 +937,30 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
     tp->thrR = (lds(R) > big && R * g->D * sub >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
     tp->thrC = ((size_t)g->N1 * C * sizeof(cplx) > big &&
                 (g->N1 / g->plan1.radix[0]) * C >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
+    // Launches that do not fill the chip (the probe batches of a solve: 9 pairs at
+    // C2) are chains of instruction / LDS latencies with one wavefront per SIMD:
+    // smaller tiles spread the same work over more, narrower workgroups
+    // (measured at C2, 17 vectors: 26.1 -> 23.7 us per product; 64 vectors are
+    // already past the point where it helps)
+    if (getenv("RUNLMC_NO_SMALL_TILES") == nullptr) {
+        bool shrunk = false;
+        while (R > 1 && (size_t)(g->N1 / R) * pairs < 512) {
+            R /= 2;
+            shrunk = true;
+        }
+        if (shrunk) {
+            tp->R = R;
+            tp->colsMagic = div_magic((unsigned)(R * g->D));
+            tp->thrR = std::max(64, std::min(RL_THREADS, ((R * g->N2 + 63) / 64) * 64));
+        }
+        if (C > 8 && (size_t)(g->N2 / C) * g->D * pairs < 512) {
+            C = 8;
+            tp->C = C;
+            tp->logC = ilog2(C);
+            const int items = (g->N1 / g->plan1.radix[0]) * C;
+            tp->thrC = std::max(64, std::min(RL_THREADS, ((items + 63) / 64) * 64));
+        }
+    }
     // experiment knobs (tile sweeps on the GPU box)
     if (const char* e = getenv("RUNLMC_TILE_C")) {
         const int c = atoi(e);
