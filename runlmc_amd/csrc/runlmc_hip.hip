@@ -1848,7 +1848,9 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     const int n = s->n;
     if (maxiter <= 0) maxiter = n;
     const double rtol = tol < 1e-10 ? tol : 1e-10;
-    int nblk = (n + 1023) / 1024;
+    int rows_per_blk = 1024;
+    if (const char* e = getenv("RUNLMC_SOLVER_ROWS")) rows_per_blk = std::max(64, atoi(e));
+    int nblk = (n + rows_per_blk - 1) / rows_per_blk;
     nblk = std::max(1, std::min(nblk, 64));
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
