@@ -67,6 +67,57 @@ __device__ __forceinline__ void load_table(cplx* dst, const cplx* src, int n, in
     for (int i = tid; i < n; i += nthr) dst[i] = src[i];
 }
 
+// Optional fused W^T product in front of the column transforms (batched
+// solves of small systems, where W^T x as a kernel of its own costs a launch
+// and a round trip): the grid vector is never materialised, the column kernels
+// gather  g[row] = sum_k WT[row, k] v[col_k]  while it loads.
+struct Gather {
+    const int* indptr;      // NULL: plain load from X
+    const int* indices;
+    const double* vals;
+    const double* src;      // [nvec][n] data-space vectors
+    int n;                  // entries per data-space vector
+    int nnz;                // entries of the CSR (for clamping)
+    const int* lo;          // non-NULL: the columns of row r are lo[r], lo[r] + 1, ...
+                            // (one level of dependent loads less: SkiTerm)
+};
+
+// one grid value for the two vectors of a pair (unconditional loads from
+// clamped indices, masked afterwards; the first four entries of the row
+// together, longer rows finish in a loop)
+__device__ __forceinline__ void gather_row(const Gather& gs, int row, const double* d0,
+                                           const double* d1, double* re, double* im) {
+    constexpr int NZ = 4;
+    const int last = gs.nnz > 0 ? gs.nnz - 1 : 0;
+    const int kb = gs.indptr[row], ke = gs.indptr[row + 1];
+    const int l0 = gs.lo != nullptr ? gs.lo[row] : 0;
+    double wa[NZ], g0[NZ], g1[NZ];
+#pragma unroll
+    for (int e = 0; e < NZ; ++e) {
+        const int k = kb + e < last ? kb + e : last;
+        const double a = gs.vals[k];
+        int col = gs.lo != nullptr ? l0 + e : gs.indices[k];
+        col = col < gs.n ? col : gs.n - 1;
+        g0[e] = d0[col];
+        g1[e] = d1[col];
+        wa[e] = kb + e < ke ? a : 0.0;
+    }
+    double r = 0.0, i = 0.0;
+#pragma unroll
+    for (int e = 0; e < NZ; ++e) {
+        r = fma(wa[e], g0[e], r);
+        i = fma(wa[e], g1[e], i);
+    }
+    for (int k = kb + NZ; k < ke; ++k) {
+        const double a = gs.vals[k];
+        const int col = gs.indices[k];
+        r = fma(a, d0[col], r);
+        i = fma(a, d1[col], i);
+    }
+    *re = r;
+    *im = i;
+}
+
 // ---------------------------------------------------------------------------
 // k_cols_fwd: pad + pack two real vectors -> N1-point column FFTs -> twiddle.
 //   grid (N2 / C, D, npairs)   block RL_THREADS
@@ -79,7 +130,12 @@ __device__ __forceinline__ void load_table(cplx* dst, const cplx* src, int n, in
 __global__ void __launch_bounds__(RL_THREADS)
 k_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode, cplx* __restrict__ T,
            int N1, int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1,
-           const int* __restrict__ freq1, TwiddleL twl) {
+           const int* __restrict__ freq1, TwiddleL twl, Gather gs, int* __restrict__ bump) {
+    // (the solver's round counter, see rl_solver.h: advanced by the first kernel
+    // of a round's operator product)
+    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 &&
+        threadIdx.x == 0)
+        *bump += 1;
     RL_SMEM(smem);
     cplx* tile = reinterpret_cast<cplx*>(smem);
     cplx* tw = tile + (size_t)N1 * C;
@@ -93,15 +149,28 @@ k_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode, cp
     const bool has1 = v1 < nvec;
 
     load_table(tw, tw1, N1, tid, nthr);
-    for (int idx = tid; idx < N1 * C; idx += nthr) {
-        const int c = idx % C, n1 = idx / C;
-        double re = 0.0, im = 0.0;
-        const int src = padded_source(geo, n1, c0 + c, N1, N2, mode);
-        if (src >= 0) {
-            re = x0[src];
-            if (has1) im = x1[src];
+    if (gs.indptr == nullptr) {
+        for (int idx = tid; idx < N1 * C; idx += nthr) {
+            const int c = idx % C, n1 = idx / C;
+            double re = 0.0, im = 0.0;
+            const int src = padded_source(geo, n1, c0 + c, N1, N2, mode);
+            if (src >= 0) {
+                re = x0[src];
+                if (has1) im = x1[src];
+            }
+            tile[idx] = c_make(re, im);
         }
-        tile[idx] = c_make(re, im);
+    } else {
+        // fused W^T (see Gather)
+        const double* d0 = gs.src + (size_t)v0 * gs.n;
+        const double* d1 = has1 ? gs.src + (size_t)v1 * gs.n : d0;
+        for (int idx = tid; idx < N1 * C; idx += nthr) {
+            const int c = idx % C, n1 = idx / C;
+            double re = 0.0, im = 0.0;
+            const int src = padded_source(geo, n1, c0 + c, N1, N2, 0);
+            if (src >= 0) gather_row(gs, b * m + src, d0, d1, &re, &im);
+            tile[idx] = c_make(re, has1 ? im : 0.0);
+        }
     }
     __syncthreads();
     fft_tile_forward(tile, plan1, C, C, tw, tid, nthr);

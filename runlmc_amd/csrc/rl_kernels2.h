@@ -34,21 +34,6 @@ struct Tile2 {
     int thrC, thrR;     // workgroup sizes of the column / row kernels
 };
 
-// Optional fused W^T product in front of the column transforms (batched
-// solves of small systems, where W^T x as a kernel of its own costs a launch
-// and a round trip): the grid vector is never materialised, k2_cols_fwd
-// gathers  g[row] = sum_k WT[row, k] v[col_k]  while it loads.
-struct Gather {
-    const int* indptr;      // NULL: plain load from X
-    const int* indices;
-    const double* vals;
-    const double* src;      // [nvec][n] data-space vectors
-    int n;                  // entries per data-space vector
-    int nnz;                // entries of the CSR (for clamping)
-    const int* lo;          // non-NULL: the columns of row r are lo[r], lo[r] + 1, ...
-                            // (one level of dependent loads less: SkiTerm)
-};
-
 // (pair, tile-within-pair) of this workgroup; false if it is launch padding
 __device__ __forceinline__ bool xcd_slot(const Tile2& tp, int tiles_per_pair, int* pair,
                                          int* tile) {

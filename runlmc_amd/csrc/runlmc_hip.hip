@@ -731,8 +731,12 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     const size_t need = ((size_t)npairs + g->D - 1) / g->D;
     RL_TRY(ensure_workspace(g, std::max<size_t>(need, 1)));
     dim3 gridA(g->N2 / g->colsA, 1, npairs);
+    Gather no_gather;
+    no_gather.indptr = nullptr;
+    no_gather.lo = nullptr;
     RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, g->tops, ntop, 1, g->geo,
-              1, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);
+              1, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl, no_gather,
+              (int*)nullptr);
     dim3 gridS(g->N1 / g->rowsS, npairs);
     RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
               g->spec, ntop, g->N1, g->N2, g->rowsS, g->plan2, g->tw2);
@@ -1066,6 +1070,36 @@ static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, dou
     return RL_OK;
 }
 
+// one chunk through the first-generation kernels (every pass in LDS)
+static int mvm_chunk_v1(rl_gridop* g, const MixParams& mp, const double* Xc, double* Yc, int nv,
+                        size_t pairs, hipStream_t stream, const Gather* gather = nullptr,
+                        int* bump = nullptr) {
+    Gather gs;
+    if (gather != nullptr) {
+        gs = *gather;
+    } else {
+        gs.indptr = nullptr;
+        gs.lo = nullptr;
+    }
+    const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
+    const unsigned tilesInv = (colsNeeded + g->colsA - 1) / g->colsA;
+    dim3 gridA(g->N2 / g->colsA, g->D, (unsigned)pairs);
+    RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, Xc, nv, g->D, g->geo, 0,
+              g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl, gs, bump);
+    switch (g->D) {
+#define RL_CASE(d) case d: launch_rows_mix<d>(g, pairs, stream, mp); break;
+        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
+        RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
+        RL_CASE(14) RL_CASE(15) RL_CASE(16)
+#undef RL_CASE
+        default: return fail(RL_ELIMIT, "unsupported D");
+    }
+    dim3 gridI(tilesInv, g->D, (unsigned)pairs);
+    RL_LAUNCH(k_cols_inv, gridI, dim3(RL_THREADS), lds_cols(g), stream, g->T, Yc, nv, g->D,
+              g->geo, g->N1, g->N2, g->colsA, g->plan1, g->tw1);
+    return RL_OK;
+}
+
 // second chunk of intermediates + side stream of the two-stream batched product
 static int prepare_two_streams(rl_gridop* g, size_t chunk) {
     if (g->T2_pairs < chunk) {
@@ -1151,8 +1185,6 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         }
     }
     int parity = 0;
-    const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
-    const unsigned tilesInv = (colsNeeded + g->colsA - 1) / g->colsA;
     for (size_t p0 = 0; p0 < total_pairs; p0 += chunk) {
         const size_t pairs = std::min(chunk, total_pairs - p0);
         const int v0 = (int)(2 * p0);
@@ -1170,20 +1202,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
             RL_TRY(mvm_chunk_v2(g, mp, Xc, Yc, nv, pairs, cst, nullptr, nullptr, tb));
             continue;
         }
-        dim3 gridA(g->N2 / g->colsA, g->D, (unsigned)pairs);
-        RL_LAUNCH(k_cols_fwd, gridA, dim3(RL_THREADS), lds_cols(g), stream, Xc, nv, g->D, g->geo,
-                  0, g->T, g->N1, g->N2, g->colsA, g->plan1, g->tw1, g->freq1, g->twl);
-        switch (g->D) {
-#define RL_CASE(d) case d: launch_rows_mix<d>(g, pairs, stream, mp); break;
-            RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
-            RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
-            RL_CASE(14) RL_CASE(15) RL_CASE(16)
-#undef RL_CASE
-            default: return fail(RL_ELIMIT, "unsupported D");
-        }
-        dim3 gridI(tilesInv, g->D, (unsigned)pairs);
-        RL_LAUNCH(k_cols_inv, gridI, dim3(RL_THREADS), lds_cols(g), stream, g->T, Yc, nv, g->D,
-                  g->geo, g->N1, g->N2, g->colsA, g->plan1, g->tw1);
+        RL_TRY(mvm_chunk_v1(g, mp, Xc, Yc, nv, pairs, stream));
     }
     if (two) {
         RL_HIP(hipEventRecord(g->ev_join, g->aux));
@@ -1752,6 +1771,8 @@ static int minres_iteration(rl_ski* s, const MinresBufs& mb, SolverWork& w, int 
 
 // one round of the two-kernel MINRES (rl_solver.h): operator product on the
 // unnormalised Lanczos vector, P, B; identical arguments every round
+static bool g_is_v2(const rl_gridop* g) { return g->v2; }
+
 static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int nblk, int round,
                          double rtol, int maxiter, hipStream_t st) {
     const int par = (round - 1) & 1;
@@ -1759,7 +1780,8 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
     const double* yin = mb.tri[1 - par];      // y_{r-1}: the operator's input this round
     if (mb.W_indptr != nullptr && mb.fuse_wt) {
-        trace_once("minres round: W^T in k2_cols_fwd, W in P");
+        trace_once(g_is_v2(s->g) ? "minres round: W^T in k2_cols_fwd, W in P"
+                                 : "minres round: W^T in k_cols_fwd, W in P");
         // W^T fused into the column transforms (gathered while loading), W into
         // P: three grid kernels, P, B
         rl_gridop* g = s->g;
@@ -1772,8 +1794,12 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         gs.nnz = s->nnzWT;
         gs.lo = s->WT_lo;
         MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa};
-        RL_TRY(mvm_chunk_v2(g, mp, nullptr, s->G2, nrhs, ((size_t)nrhs + 1) / 2, st, &gs,
-                            mb.giter));
+        if (g->v2)
+            RL_TRY(mvm_chunk_v2(g, mp, nullptr, s->G2, nrhs, ((size_t)nrhs + 1) / 2, st, &gs,
+                                mb.giter));
+        else
+            RL_TRY(mvm_chunk_v1(g, mp, nullptr, s->G2, nrhs, ((size_t)nrhs + 1) / 2, st, &gs,
+                                mb.giter));
     } else if (mb.W_indptr != nullptr) {
         // W product fused into P: only W^T and the grid product run here
         RL_TRY(ski_wt_int(s, yin, s->G1, nrhs, st, mb.giter));
@@ -1912,7 +1938,11 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         // ... and W^T inside the first grid kernel when that is a k2_cols_fwd and
         // the batch is one chunk (the operator input is then the rotating buffer
         // itself: no copy of the new Lanczos vector)
-        const bool fuse_wt = fuse_w && s->g->v2 && s->g->Q >= 1 &&
+        // (only while the rows of W^T are short -- about as many data points as grid
+        // points: a row of 30 entries, as on the weather workload, is a serial chain
+        // of gathers inside the transform kernel: 1.45 vs 1.23 s per fit)
+        const bool short_rows = (size_t)s->nnzWT <= (size_t)8 * s->ngrid;
+        const bool fuse_wt = fuse_w && short_rows && s->g->Q >= 1 &&
                              ((size_t)nrhs + 1) / 2 <= s->g->chunk_pairs &&
                              !(s->g->v4 && nrhs >= s->g->v4_min) &&
                              getenv("RUNLMC_NO_FUSE_WT") == nullptr;
