@@ -428,6 +428,54 @@ k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
 }
 
 // ---------------------------------------------------------------------------
+// k_spmv_wide: the same product for LONG rows (W^T when there are many more
+// data points than grid points: 30 entries per row on the weather workload,
+// which one thread per row walks as a serial chain of gathers).  LPR lanes
+// share a row, each takes every LPR-th entry (4 of them requested together),
+// the partial sums meet in LDS.
+//   grid (ceil(nrows * LPR / RL_THREADS), nvec)   LDS: RL_THREADS doubles
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ void __launch_bounds__(RL_THREADS)
+k_spmv_wide(const int* __restrict__ indptr, const int* __restrict__ indices,
+            const double* __restrict__ vals, int nrows, int ncols, const double* __restrict__ X,
+            double* __restrict__ Y, int* __restrict__ bump) {
+    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
+    RL_SMEM(smem);
+    double* part = reinterpret_cast<double*>(smem);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rowu = t / LPR, lane = t - rowu * LPR;
+    const int row = rowu < nrows ? rowu : nrows - 1;
+    const double* x = X + (size_t)blockIdx.y * ncols;
+    const int nnz = indptr[nrows];
+    const int last = nnz > 0 ? nnz - 1 : 0;
+    const int kb = indptr[row], k1 = indptr[row + 1];
+    double acc = 0.0;
+    constexpr int NZ = 4;
+    for (int k0 = kb + lane; k0 < k1; k0 += NZ * LPR) {
+        double wa[NZ], xv[NZ];
+#pragma unroll
+        for (int e = 0; e < NZ; ++e) {
+            const int ku = k0 + e * LPR;
+            const int k = ku < last ? ku : last;
+            const double a = vals[k];
+            xv[e] = x[indices[k]];
+            wa[e] = ku < k1 ? a : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < NZ; ++e) acc = fma(wa[e], xv[e], acc);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane == 0 && rowu < nrows) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) s += part[threadIdx.x + j];
+        Y[(size_t)blockIdx.y * nrows + rowu] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row permutation of a batch of data-space vectors.
 //   gather : Y[v][i]       = X[v][perm[i]]
 //   scatter: Y[v][perm[i]] = X[v][i]

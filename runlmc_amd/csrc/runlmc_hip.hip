@@ -1301,10 +1301,18 @@ struct rl_ski {
 static void launch_spmv(const int* indptr, const int* indices, const double* vals, int nrows,
                         int ncols, int nvec, const double* X, double* Y, const double* diag,
                         const double* X2, hipStream_t st, int accumulate = 0,
-                        int* bump = nullptr) {
+                        int* bump = nullptr, int avg_nnz = 0) {
     const unsigned gx = (nrows + RL_THREADS - 1) / RL_THREADS;
     static const int force_vb = getenv("RUNLMC_SPMV_VB") ? atoi(getenv("RUNLMC_SPMV_VB")) : 0;
     const bool blocked = force_vb ? force_vb > 1 : (size_t)nrows * nvec >= ((size_t)1 << 22);
+    // long rows of a small product: eight lanes per row (k_spmv_wide)
+    if (!blocked && avg_nnz > 12 && diag == nullptr && !accumulate &&
+        getenv("RUNLMC_NO_WIDE_SPMV") == nullptr) {
+        const unsigned gw = (unsigned)(((size_t)nrows * 8 + RL_THREADS - 1) / RL_THREADS);
+        RL_LAUNCH(k_spmv_wide<8>, dim3(gw, nvec), dim3(RL_THREADS), RL_THREADS * sizeof(double), st,
+                  indptr, indices, vals, nrows, ncols, X, Y, bump);
+        return;
+    }
     if (blocked) {
         RL_LAUNCH(k_spmv<8>, dim3(gx, (nvec + 7) / 8), dim3(RL_THREADS), 0, st, indptr, indices,
                   vals, nrows, ncols, nvec, X, Y, diag, X2, accumulate, bump);
@@ -1576,7 +1584,7 @@ static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int sc
 static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st,
                       int* bump = nullptr) {
     launch_spmv(s->WT_indptr, s->WT_indices, s->WT_data, s->ngrid, s->n, nvec, Xp, G, nullptr,
-                nullptr, st, 0, bump);
+                nullptr, st, 0, bump, s->ngrid > 0 ? s->nnzWT / s->ngrid : 0);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

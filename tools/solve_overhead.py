@@ -7,7 +7,7 @@ import numpy as np, torch
 import parity_suite as ps
 from cases import Case
 from runlmc_amd._native import solve_batch
-c = Case('fx2007')
+c = Case(sys.argv[1] if len(sys.argv) > 1 else 'fx2007')
 fk, K, gk = ps.build_operator(c)
 op = K.device_operator()
 rng = np.random.RandomState(0)
