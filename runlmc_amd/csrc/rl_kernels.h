@@ -391,31 +391,30 @@ k_spmv(const int* __restrict__ indptr, const int* __restrict__ indices,
     // conditional load is a branch with a full memory wait behind it)
     const int nnz = indptr[nrows];
     const int last = nnz > 0 ? nnz - 1 : 0;
-    double wa[NZ];
-    int wc[NZ];
+    // (rows longer than NZ -- W^T where several data points share a grid cell --
+    // go on in further groups of NZ, each requested together like the first)
+    int kg = kb;
+    do {
+        double wa[NZ];
+        int wc[NZ];
 #pragma unroll
-    for (int e = 0; e < NZ; ++e) {
-        const int k = kb + e < last ? kb + e : last;
-        const double a = vals[k];
-        wc[e] = indices[k];
-        wa[e] = kb + e < k1 ? a : 0.0;
-    }
+        for (int e = 0; e < NZ; ++e) {
+            const int k = kg + e < last ? kg + e : last;
+            const double a = vals[k];
+            wc[e] = indices[k];
+            wa[e] = kg + e < k1 ? a : 0.0;
+        }
 #pragma unroll
-    for (int j = 0; j < RL_SPMV_VB; ++j) {
-        const int jj = j < nv ? j : 0;
-        double xv[NZ];
+        for (int j = 0; j < RL_SPMV_VB; ++j) {
+            const int jj = j < nv ? j : 0;
+            double xv[NZ];
 #pragma unroll
-        for (int e = 0; e < NZ; ++e) xv[e] = x[(size_t)jj * ncols + wc[e]];
+            for (int e = 0; e < NZ; ++e) xv[e] = x[(size_t)jj * ncols + wc[e]];
 #pragma unroll
-        for (int e = 0; e < NZ; ++e) acc[j] = fma(wa[e], xv[e], acc[j]);
-    }
-    for (int k = kb + NZ; k < k1; ++k) {
-        const double a = vals[k];
-        const double* xc = x + indices[k];
-#pragma unroll
-        for (int j = 0; j < RL_SPMV_VB; ++j)
-            if (j < nv) acc[j] = fma(a, xc[(size_t)j * ncols], acc[j]);
-    }
+            for (int e = 0; e < NZ; ++e) acc[j] = fma(wa[e], xv[e], acc[j]);
+        }
+        kg += NZ;
+    } while (kg < k1);
     const double dg = diag != nullptr ? diag[row] : 0.0;
 #pragma unroll
     for (int j = 0; j < RL_SPMV_VB; ++j)

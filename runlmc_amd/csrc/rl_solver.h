@@ -729,7 +729,39 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
             accA = fma(pr2[u] * sinv, yi, accA);
         }
     }
-    for (int i = lo + threadIdx.x + PF * blockDim.x; i < hi; i += blockDim.x) {
+    int it0 = lo + threadIdx.x + PF * blockDim.x;
+    if (g == nullptr) {
+        // long systems (operator output in q): the remaining rows PF at a time,
+        // every load of a group requested before the first is used
+        for (; it0 + (PF - 1) * (int)blockDim.x < hi; it0 += PF * blockDim.x) {
+            double tr2[PF], tr1[PF], tq[PF], tw1[PF], tw2[PF], tx[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const size_t i = off + it0 + u * blockDim.x;
+                tr2[u] = r2[i];
+                tr1[u] = r1[i];
+                tq[u] = mb.q[i];
+                tw1[u] = w1[i];
+                tw2[u] = w2[i];
+                tx[u] = mb.x[i];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const size_t i = off + it0 + u * blockDim.x;
+                if (fin) {
+                    const double wn = (tr1[u] * oinv - oldeps * tw1[u] - delta * tw2[u]) * denom;
+                    w1[i] = wn;
+                    const double xi = tx[u] + phi * wn;
+                    mb.x[i] = xi;
+                    accC = fma(xi, xi, accC);
+                }
+                const double yi = tq[u] * sinv - coef * tr1[u];
+                y[i] = yi;
+                accA = fma(tr2[u] * sinv, yi, accA);
+            }
+        }
+    }
+    for (int i = it0; i < hi; i += blockDim.x) {
         const double r2i = r2[off + i];
         double qi;
         if (ell) {
@@ -900,7 +932,22 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
                 acc = fma(yi, yi, acc);
             }
         }
-        for (int i = lo + threadIdx.x + PF * blockDim.x; i < hi; i += blockDim.x) {
+        int it0 = lo + threadIdx.x + PF * blockDim.x;
+        for (; it0 + (PF - 1) * (int)blockDim.x < hi; it0 += PF * blockDim.x) {
+            double ty[PF], tr[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                ty[u] = y[off + it0 + u * blockDim.x];
+                tr[u] = r2[off + it0 + u * blockDim.x];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const double yi = ty[u] - coef * tr[u];
+                y[off + it0 + u * blockDim.x] = yi;
+                acc = fma(yi, yi, acc);
+            }
+        }
+        for (int i = it0; i < hi; i += blockDim.x) {
             const double yi = y[off + i] - coef * r2[off + i];
             y[off + i] = yi;
             acc = fma(yi, yi, acc);

@@ -1885,7 +1885,10 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     int rows_per_blk = 1024;
     if (const char* e = getenv("RUNLMC_SOLVER_ROWS")) rows_per_blk = std::max(64, atoi(e));
     int nblk = (n + rows_per_blk - 1) / rows_per_blk;
-    nblk = std::max(1, std::min(nblk, 64));
+    int max_blk = 64;       // <= RL_SOLVER_THREADS: the partial sums are read one per thread
+    if (const char* e = getenv("RUNLMC_SOLVER_MAXBLK"))
+        max_blk = std::max(1, std::min(atoi(e), RL_SOLVER_THREADS));
+    nblk = std::max(1, std::min(nblk, max_blk));
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
 

@@ -651,12 +651,15 @@ def check_solver_fusions():
     assert op.grids[0].N2 >= 64                  # k2_* kernels
     rng = np.random.RandomState(0)
     B = np.vstack([p.y, rng.randint(0, 2, (2, p.n)) * 2.0 - 1])
-    knobs = ('RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_MINRES_V1')
+    knobs = ('RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_MINRES_V1', 'RUNLMC_SOLVER_MAXBLK')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     res = {}
     try:
         for mode, env in (('fused', {}), ('no_wt', {'RUNLMC_NO_FUSE_WT': '1'}),
                           ('no_w', {'RUNLMC_NO_FUSE_W': '1'}),
+                          # one workgroup per system: the long-system loops of P and B
+                          ('long_rows', {'RUNLMC_SOLVER_MAXBLK': '1', 'RUNLMC_NO_FUSE_W': '1'}),
+                          ('long_rows_fused', {'RUNLMC_SOLVER_MAXBLK': '1'}),
                           ('four_kernel', {'RUNLMC_MINRES_V1': '1'})):
             for k in knobs:
                 os.environ.pop(k, None)
