@@ -1269,6 +1269,18 @@ struct SkiTerm {
     int* WT_lo = nullptr;
 };
 
+// buffers of one rl_solve_batch call
+struct SolverWork {
+    double* vec[10] = {nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr};
+    double* S[2] = {nullptr, nullptr};
+    int* I = nullptr;
+    double* part[4] = {nullptr, nullptr, nullptr, nullptr};
+    int* count = nullptr;   // [0] active systems, [1] global iteration counter, [2] done blocks
+    double* resid = nullptr; // [nrhs] explicit residual norms
+    double* lanczos = nullptr;
+};
+
 struct rl_ski {
     std::vector<SkiTerm> extra;   // terms beyond the first (rl_ski_add_term)
     int max_ngrid = 0;
@@ -1293,6 +1305,12 @@ struct rl_ski {
     double *P1 = nullptr, *P2 = nullptr;
     int pcap = 0;
     hipStream_t solver_stream = nullptr;   // capturable stream of rl_solve_batch
+    // the solver's buffers are kept between calls (a solve frees eighteen of them
+    // and a hipFree is ~100 us: 1.7 of the 2.9 ms a C2 solve spent outside its
+    // rounds); capacities in elements.  RUNLMC_WS_CACHE_MB bounds what is kept.
+    SolverWork ws;
+    bool ws_valid = false;
+    size_t ws_vec_cap = 0, ws_rhs_cap = 0, ws_part_cap = 0;
 };
 
 // Small batches want every (row, vector) on its own thread (latency-bound);
@@ -1507,6 +1525,8 @@ extern "C" int rl_ski_add_term(rl_ski* s, rl_gridop* g, const int* W_indptr,
     return RL_OK;
 }
 
+static void free_work(SolverWork& w);
+
 extern "C" int rl_ski_destroy(rl_ski* s) {
     if (!s) return RL_OK;
     (void)hipSetDevice(s->g->device);
@@ -1517,6 +1537,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
             if (p) (void)hipFree(p);
     }
     if (s->solver_stream) (void)hipStreamDestroy(s->solver_stream);
+    if (s->ws_valid) free_work(s->ws);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo};
@@ -1695,48 +1716,77 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
 // ---------------------------------------------------------------------------
 #include "rl_solver.h"
 
-struct SolverWork {
-    double* vec[10] = {nullptr, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, nullptr};
-    double* S[2] = {nullptr, nullptr};
-    int* I = nullptr;
-    double* part[4] = {nullptr, nullptr, nullptr, nullptr};
-    int* count = nullptr;   // [0] active systems, [1] global iteration counter, [2] done blocks
-    double* resid = nullptr; // [nrhs] explicit residual norms
-    double* lanczos = nullptr;
-};
-// frees a SolverWork (and a captured graph) at scope exit; kept apart so the
-// plain struct can be copied into launch closures
+static void free_work(SolverWork& w) {
+    for (double*& p : w.vec) { if (p) (void)hipFree(p); p = nullptr; }
+    for (double*& p : w.S) { if (p) (void)hipFree(p); p = nullptr; }
+    for (double*& p : w.part) { if (p) (void)hipFree(p); p = nullptr; }
+    if (w.I) (void)hipFree(w.I);
+    if (w.count) (void)hipFree(w.count);
+    if (w.resid) (void)hipFree(w.resid);
+    if (w.lanczos) (void)hipFree(w.lanczos);
+    w.I = nullptr; w.count = nullptr; w.resid = nullptr; w.lanczos = nullptr;
+}
+
+static size_t ws_cache_limit() {
+    size_t mb = 16384;
+    if (const char* e = getenv("RUNLMC_WS_CACHE_MB")) mb = (size_t)std::max(0LL, atoll(e));
+    return mb << 20;
+}
+
+// hands the buffers back to the handle (or frees them) and destroys a captured
+// graph at scope exit; kept apart so the plain struct can be copied into launch
+// closures
 struct SolverWorkGuard {
+    rl_ski* s;
     SolverWork* w;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    explicit SolverWorkGuard(SolverWork* w_) : w(w_) {}
+    SolverWorkGuard(rl_ski* s_, SolverWork* w_) : s(s_), w(w_) {}
     ~SolverWorkGuard() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
-        for (double* p : w->vec) if (p) (void)hipFree(p);
-        for (double* p : w->S) if (p) (void)hipFree(p);
-        for (double* p : w->part) if (p) (void)hipFree(p);
-        if (w->I) (void)hipFree(w->I);
-        if (w->count) (void)hipFree(w->count);
-        if (w->resid) (void)hipFree(w->resid);
-        if (w->lanczos) (void)hipFree(w->lanczos);
+        if (w->lanczos) { (void)hipFree(w->lanczos); w->lanczos = nullptr; }
+        size_t nv = 0;
+        for (double* p : w->vec) nv += p != nullptr;
+        const size_t bytes = nv * s->ws_vec_cap * sizeof(double);
+        if (w->I != nullptr && !s->ws_valid && bytes <= ws_cache_limit()) {
+            s->ws = *w;
+            s->ws_valid = true;
+        } else {
+            free_work(*w);
+        }
     }
 };
 
-static int solver_alloc(SolverWork& w, int nvecs, int nrhs, int n, int nblk) {
-    for (int i = 0; i < nvecs; ++i)
-        RL_HIP(hipMalloc((void**)&w.vec[i], (size_t)nrhs * n * sizeof(double)));
-    for (int i = 0; i < 2; ++i)
-        RL_HIP(hipMalloc((void**)&w.S[i], (size_t)nrhs * S_NFIELDS * sizeof(double)));
-    RL_HIP(hipMalloc((void**)&w.I, (size_t)nrhs * I_NFIELDS * sizeof(int)));
-    for (int i = 0; i < 4; ++i)
-        RL_HIP(hipMalloc((void**)&w.part[i], (size_t)nrhs * nblk * sizeof(double)));
-    RL_HIP(hipMalloc((void**)&w.count, 4 * sizeof(int)));
-    RL_HIP(hipMemset(w.count, 0, 4 * sizeof(int)));
-    RL_HIP(hipMalloc((void**)&w.resid, (size_t)nrhs * sizeof(double)));
-    RL_HIP(hipMemset(w.resid, 0, (size_t)nrhs * sizeof(double)));
+// `need`: bit i set = vec[i] is used by this call
+static int solver_alloc(rl_ski* s, SolverWork& w, unsigned need, int nrhs, int n, int nblk,
+                        hipStream_t st) {
+    const size_t ve = (size_t)nrhs * n, pe = (size_t)nrhs * nblk;
+    if (s->ws_valid) {
+        if (s->ws_vec_cap >= ve && s->ws_rhs_cap >= (size_t)nrhs && s->ws_part_cap >= pe)
+            w = s->ws;              // checked out; the guard hands it back
+        else
+            free_work(s->ws);
+        s->ws = SolverWork();
+        s->ws_valid = false;
+    }
+    if (w.I == nullptr) {
+        s->ws_vec_cap = ve;
+        s->ws_rhs_cap = (size_t)nrhs;
+        s->ws_part_cap = pe;
+        for (int i = 0; i < 2; ++i)
+            RL_HIP(hipMalloc((void**)&w.S[i], (size_t)nrhs * S_NFIELDS * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&w.I, (size_t)nrhs * I_NFIELDS * sizeof(int)));
+        for (int i = 0; i < 4; ++i)
+            RL_HIP(hipMalloc((void**)&w.part[i], pe * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&w.count, 4 * sizeof(int)));
+        RL_HIP(hipMalloc((void**)&w.resid, (size_t)nrhs * sizeof(double)));
+    }
+    for (int i = 0; i < 10; ++i)
+        if (((need >> i) & 1u) && w.vec[i] == nullptr)
+            RL_HIP(hipMalloc((void**)&w.vec[i], s->ws_vec_cap * sizeof(double)));
+    RL_HIP(hipMemsetAsync(w.count, 0, 4 * sizeof(int), st));
+    RL_HIP(hipMemsetAsync(w.resid, 0, (size_t)nrhs * sizeof(double), st));
     return RL_OK;
 }
 
@@ -1902,9 +1952,13 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     const bool use_graph = getenv("RUNLMC_NO_GRAPH") == nullptr;
 
     SolverWork w;
-    SolverWorkGuard guard(&w);
-    RL_TRY(solver_alloc(w, method == RL_MINRES ? 7 : 4, nrhs, n, nblk));      // (vec[5]: v of the
-                                                                             // four-kernel MINRES only)
+    SolverWorkGuard guard(s, &w);
+    // (vec[5]: v of the four-kernel MINRES only; vec[8], vec[9]: right-hand sides
+    // and solutions in the handle's internal row order)
+    unsigned need = method == RL_MINRES ? 0x5bu : 0x0fu;      // two-kernel MINRES: 0, 1, 3, 4, 6
+    if (method == RL_MINRES && getenv("RUNLMC_MINRES_V1") != nullptr) need = 0x7fu;
+    if (s->permuted) need |= 0x300u;
+    RL_TRY(solver_alloc(s, w, need, nrhs, n, nblk, st));
     // everything the operator product allocates lazily must exist before capture
     RL_TRY(ski_reserve(s, nrhs));
     RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
@@ -1919,8 +1973,6 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     const double* Bi = B;
     double* Xi = X;
     if (s->permuted) {
-        RL_HIP(hipMalloc((void**)&w.vec[8], (size_t)nrhs * n * sizeof(double)));
-        RL_HIP(hipMalloc((void**)&w.vec[9], (size_t)nrhs * n * sizeof(double)));
         permute_rows(s, B, w.vec[8], nrhs, 0, st);
         Bi = w.vec[8];
         Xi = w.vec[9];
