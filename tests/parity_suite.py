@@ -815,3 +815,45 @@ def check_rank_above_outputs():
         toeps = [ops.BTTBOracle(t) for t in tops]
         ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X])
         _close(g.matmat_host(X), ref, 1e-11)
+
+
+def check_solver_workspace_reuse():
+    """The solver's buffers live on the SKI handle between calls: batches that
+    grow, shrink and change method on one handle, and the same with the cache
+    disabled (RUNLMC_WS_CACHE_MB=0), give the same iterates."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch, MINRES, CG
+    p = synth.make_problem(2, 2, 1, 300, eps=1.0)
+    p.noise = p.noise + 0.5
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    op = K.device_operator()
+    rng = np.random.RandomState(3)
+    B = rng.randint(0, 2, (5, p.n)) * 2.0 - 1
+    saved = os.environ.pop('RUNLMC_WS_CACHE_MB', None)
+
+    def run(rows, minres=True):
+        X, it, rs, st = solve_batch(op, torch.from_numpy(B[rows]).to(op.device),
+                                    method=MINRES if minres else CG, tol=1e-4)[:4]
+        return X.cpu().numpy(), np.array(it)
+    try:
+        os.environ['RUNLMC_WS_CACHE_MB'] = '0'
+        ref3, it3 = run([0, 1, 2])
+        ref5, it5 = run([0, 1, 2, 3, 4])
+        ref2, it2 = run([3, 4])      # (its own reference: the pair packing differs from 0..4)
+        refc, itc = run([1, 4], minres=False)
+        os.environ.pop('RUNLMC_WS_CACHE_MB')
+        for _ in range(2):
+            x3, i3 = run([0, 1, 2])              # allocate
+            x5, i5 = run([0, 1, 2, 3, 4])        # grow
+            x2, i2 = run([3, 4])                 # reuse a larger workspace
+            xc, ic = run([1, 4], minres=False)   # another method's vectors
+            assert np.array_equal(x3, ref3) and np.array_equal(i3, it3)
+            assert np.array_equal(x5, ref5) and np.array_equal(i5, it5)
+            assert np.array_equal(x2, ref2) and np.array_equal(i2, it2)
+            assert np.array_equal(xc, refc) and np.array_equal(ic, itc)
+    finally:
+        os.environ.pop('RUNLMC_WS_CACHE_MB', None)
+        if saved is not None:
+            os.environ['RUNLMC_WS_CACHE_MB'] = saved

@@ -129,6 +129,10 @@ def test_solver_fusions():
     ps.check_solver_fusions()
 
 
+def test_solver_workspace_reuse():
+    ps.check_solver_workspace_reuse()
+
+
 def test_chunked_product():
     ps.check_chunked_product()
 
