@@ -142,7 +142,9 @@ int rl_ski_apply_w_term(rl_ski* s, int term, const double* G, double* Y, int nve
  *             10 = reference residual rule; 11 = zero right-hand side.
  * Any of the three output pointers may be NULL.  Synchronises before it
  * returns.  Non-convergence is NOT an error (the reference logs and returns
- * the iterate, iterative.py:55-58).                                          */
+ * the iterate, iterative.py:55-58).  The solver's work vectors stay on the
+ * handle between calls (freed by rl_ski_destroy; environment variable
+ * RUNLMC_WS_CACHE_MB bounds what is kept).                                     */
 #define RL_MINRES 0
 #define RL_CG 1
 int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method, double tol,
