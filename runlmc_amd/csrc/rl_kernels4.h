@@ -400,3 +400,183 @@ k4_product(const double* __restrict__ X, double* __restrict__ Y, int nvec, Geom 
     }   // phases
     }   // vectors
 }
+
+// ---------------------------------------------------------------------------
+// Small-batch variant of the same scheme: TWO kernels, the half spectra of
+// every (vector, output, phase) travel through global memory once.
+//   k5_forward <EP>    grid (D, nvec, 2): pad, H-point transform, untangle ->
+//                      Sg[((v * 2 + ph) * D + b)][slot][thread]
+//   k5_inverse <D, EP> grid (D, nvec): for each phase read the D half spectra
+//                      at the owned frequencies, mix, keep output a, re-tangle,
+//                      transform back, write (E) / add (O) the outputs
+// k4_product needs one workgroup per vector and runs its 2 * 2 * D transforms
+// one after the other -- fine when there are hundreds of vectors, a long serial
+// chain at the 17 of a probe batch.  Here every transform of the batch has its
+// own workgroup (2 * D * nvec forward, D * nvec backward), for one kernel
+// boundary instead of the two of the three-kernel product.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_tab4(cplx* tile, const Plan4& gp, int ld, int H, Tab4& tb,
+                                          int tid, int nthr) {
+    cplx* l_twA = tile + (size_t)gp.Na * ld;
+    cplx* l_twB = l_twA + gp.Na;
+    cplx* l_lo = l_twB + gp.Nb;
+    cplx* l_hi = l_lo + gp.nlo;
+    cplx* l_wl = l_hi + gp.nhi;
+    int* l_fa = reinterpret_cast<int*>(l_wl + H + 1);
+    for (int i = tid; i < gp.Na; i += nthr) { l_twA[i] = gp.twA[i]; l_fa[i] = gp.freqA[i]; }
+    for (int i = tid; i < gp.Nb; i += nthr) l_twB[i] = gp.twB[i];
+    for (int i = tid; i < gp.nlo; i += nthr) l_lo[i] = gp.twN.lo[i];
+    for (int i = tid; i < gp.nhi; i += nthr) l_hi[i] = gp.twN.hi[i];
+    for (int i = tid; i <= H; i += nthr) l_wl[i] = gp.wl[i];
+    tb.twA = l_twA;
+    tb.twB = l_twB;
+    tb.wl = l_wl;
+    tb.freqA = l_fa;
+    tb.twN.lo = l_lo;
+    tb.twN.hi = l_hi;
+    tb.twN.shift = gp.twN.shift;
+    tb.twN.mask = gp.twN.mask;
+}
+
+template <int EP>
+__global__ void __launch_bounds__(RL_THREADS4)
+k5_forward(const double* __restrict__ X, int D, Geom geo, Plan4 gp, cplx* __restrict__ Sg) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int b = blockIdx.x, v = blockIdx.y;
+    const bool odd = blockIdx.z == 1;
+    const int H = gp.N, Hb = gp.Nb, ld = gp.ld, hh = H >> 1;
+    const int N2 = 2 * H;
+    const int m = geo.m;
+    constexpr int NS = 2 * EP;
+    const double* x = X + ((size_t)v * D + b) * m;
+    // the input first: it does not depend on the tables
+    for (int idx = tid; idx < H; idx += nthr) {
+        const int n1 = (int)fast_div((unsigned)idx, gp.magicNb);
+        const int n2 = idx - n1 * Hb;
+        cplx z;
+        if (!odd) {
+            z = c_make(load4(x, 2 * idx, m, N2, 0, 1.0), load4(x, 2 * idx + 1, m, N2, 0, 1.0));
+        } else {
+            z = c_mul(c_make(load4(x, idx, m, N2, 0, -1.0), -load4(x, idx + H, m, N2, 0, -1.0)),
+                      gp.wl[idx]);
+        }
+        tile[(size_t)n1 * ld + n2] = z;
+    }
+    Tab4 tb;
+    load_tab4(tile, gp, ld, H, tb, tid, nthr);
+    __syncthreads();
+    onchip_transform(tile, false, gp, tb, tid, nthr);
+    cplx* out = Sg + ((size_t)(v * 2 + (odd ? 1 : 0)) * D + b) * NS * nthr;
+    if (!odd) {
+#pragma unroll
+        for (int s = 0; s < EP; ++s) {
+            const int c = tid + s * nthr;
+            if (c <= hh) {
+                const cplx A = tile[gp.pos[c]], Bc = c_conj(tile[gp.pos[c == 0 ? 0 : H - c]]);
+                const cplx w = tb.wl[2 * c];            // W_N2^c
+                const cplx P = c_add(A, Bc);
+                const cplx Qd = c_mul_pi(c_mul(w, c_sub(A, Bc)));     // i w (A - conj B)
+                out[(size_t)(2 * s) * nthr + tid] = c_sub(P, Qd);
+                out[(size_t)(2 * s + 1) * nthr + tid] = c_conj(c_add(P, Qd));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = tid + s * nthr;
+            if (idx < H) {
+                const int n1 = (int)fast_div((unsigned)idx, gp.magicNb);
+                out[(size_t)s * nthr + tid] = tile[n1 * ld + (idx - n1 * Hb)];
+            }
+        }
+    }
+}
+
+template <int D, int EP>
+__global__ void __launch_bounds__(RL_THREADS4)
+k5_inverse(const cplx* __restrict__ Sg, double* __restrict__ Y, Geom geo, Plan4 gp,
+           MixParams mp) {
+    RL_SMEM(smem);
+    cplx* tile = reinterpret_cast<cplx*>(smem);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int a = blockIdx.x, v = blockIdx.y;
+    const int H = gp.N, Hb = gp.Nb, ld = gp.ld, hh = H >> 1;
+    const int m = geo.m;
+    const size_t sps = (size_t)2 * H + 1;
+    constexpr int NS = 2 * EP;
+    Tab4 tb;
+    load_tab4(tile, gp, ld, H, tb, tid, nthr);
+    double* y = Y + ((size_t)v * D + a) * m;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        const bool odd = ph == 1;
+        const cplx* in = Sg + (size_t)(v * 2 + ph) * D * NS * nthr;
+        cplx tmp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = tid + (s >> 1) * nthr;
+            const bool live = odd ? tid + s * nthr < H : c <= hh;
+            tmp[s] = c_make(0.0, 0.0);
+            if (live) {
+                const size_t o = odd ? (size_t)(H + 1 + tid + s * nthr)
+                                     : (size_t)((s & 1) ? H - c : c);
+                cplx z[D];
+#pragma unroll
+                for (int b = 0; b < D; ++b) z[b] = in[((size_t)b * NS + s) * nthr + tid];
+                mix_point<D>(z, mp, sps, o);
+#pragma unroll
+                for (int b = 0; b < D; ++b)
+                    if (b == a) tmp[s] = z[b];
+            }
+        }
+        __syncthreads();        // tables loaded (first phase) / previous outputs read (second)
+        if (!odd) {
+#pragma unroll
+            for (int s = 0; s < EP; ++s) {
+                const int c = tid + s * nthr;
+                if (c <= hh) {
+                    const cplx U = tmp[2 * s], Vc = c_conj(tmp[2 * s + 1]);
+                    const cplx w = tb.wl[2 * c];
+                    const cplx P = c_add(U, Vc);
+                    const cplx Qd = c_mul_pi(c_mulc(c_sub(U, Vc), w));  // i conj(w) (U - conj V)
+                    tile[gp.pos[c]] = c_add(P, Qd);
+                    tile[gp.pos[c == 0 ? 0 : H - c]] = c_conj(c_sub(P, Qd));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int idx = tid + s * nthr;
+                if (idx < H) {
+                    const int n1 = (int)fast_div((unsigned)idx, gp.magicNb);
+                    tile[n1 * ld + (idx - n1 * Hb)] = tmp[s];
+                }
+            }
+        }
+        __syncthreads();
+        onchip_transform(tile, true, gp, tb, tid, nthr);
+        // thread n owns y[n] and y[n + H] in both phases (k4_product)
+        for (int n = tid; n < H; n += nthr) {
+            if (n >= m) continue;
+            if (!odd) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int i = n + half * H;
+                    if (i < m) {
+                        const int idx = i >> 1;
+                        const int n1 = (int)fast_div((unsigned)idx, gp.magicNb);
+                        const cplx z = tile[(size_t)n1 * ld + (idx - n1 * Hb)];
+                        y[i] = (i & 1) ? z.y : z.x;
+                    }
+                }
+            } else {
+                const int n1 = (int)fast_div((unsigned)n, gp.magicNb);
+                const cplx h = c_mulc(tile[(size_t)n1 * ld + (n - n1 * Hb)], tb.wl[n]);
+                y[n] += h.x;
+                if (n + H < m) y[n + H] -= h.y;
+            }
+        }
+    }
+}

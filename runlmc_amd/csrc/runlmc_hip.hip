@@ -259,6 +259,11 @@ struct rl_gridop {
     int ep4 = 0, thr4 = 0, v4_min = 0, cus4 = 1;
     size_t lds4 = 0;
     double* spec4 = nullptr;   // dev [max_tops][2H + 1] (rl_kernels4.h)
+    // two-kernel form of the same scheme for small batches (k5_forward / k5_inverse)
+    bool v5 = false;
+    int v5_max = 0;            // largest batch it is used for
+    cplx* S5 = nullptr;        // half spectra in flight [nvec][2][D][2 EP][thr4]
+    size_t S5_cap = 0;         // vectors
     cplx *tw4A = nullptr, *tw4B = nullptr, *tw4lo = nullptr, *tw4hi = nullptr, *untw4 = nullptr;
     int *freq4A = nullptr, *pos4 = nullptr;
 };
@@ -376,6 +381,41 @@ static int launch4(int D, int ep, dim3 grid, dim3 block, size_t lds, hipStream_t
         RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
         RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
         RL_CASE(14) RL_CASE(15) RL_CASE(16)
+#undef RL_CASE
+        default: return fail(RL_ELIMIT, "unsupported D");
+    }
+}
+
+template <int D>
+static int launch5_d(rl_gridop* g, hipStream_t st, const double* X, double* Y, int nvec,
+                     const MixParams& mp) {
+    const dim3 block(g->thr4);
+#define RL_M(d, e)                                                                          \
+    if (g->ep4 == e) {                                                                      \
+        static bool attr = false;                                                           \
+        if (!attr) {                                                                        \
+            attr = true;                                                                    \
+            (void)hipFuncSetAttribute((const void*)k5_forward<e>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k5_inverse<d, e>,                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        }                                                                                   \
+        RL_LAUNCH((k5_forward<e>), dim3(d, nvec, 2), block, g->lds4, st, X, (int)d, g->geo, \
+                  g->p4, g->S5);                                                            \
+        RL_LAUNCH((k5_inverse<d, e>), dim3(d, nvec), block, g->lds4, st,                    \
+                  (const cplx*)g->S5, Y, g->geo, g->p4, mp);                                \
+        return RL_OK;                                                                       \
+    }
+    RL_V4_FOR_EP(RL_M, D)
+#undef RL_M
+    return fail(RL_ELIMIT, "two-kernel on-chip product: no instantiation");
+}
+
+static int launch5(rl_gridop* g, hipStream_t st, const double* X, double* Y, int nvec,
+                   const MixParams& mp) {
+    switch (g->D) {
+#define RL_CASE(d) case d: return launch5_d<d>(g, st, X, Y, nvec, mp);
+        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6)
 #undef RL_CASE
         default: return fail(RL_ELIMIT, "unsupported D");
     }
@@ -519,6 +559,12 @@ static int plan4_create(rl_gridop* g) {
     g->v4_min = 1 << 30;
     if (const char* e = getenv("RUNLMC_V4_MIN")) g->v4_min = std::max(1, atoi(e));
     g->v4 = true;
+    // two-kernel small-batch form: opt-in (RUNLMC_V5_MAX=<largest batch>)
+    g->v5 = false;
+    if (const char* e = getenv("RUNLMC_V5_MAX")) {
+        g->v5_max = atoi(e);
+        g->v5 = g->v5_max > 0;
+    }
     return RL_OK;
 }
 
@@ -691,7 +737,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->spec4, g->tw4A, g->tw4B, g->tw4lo, g->tw4hi, g->untw4, g->freq4A,
-                    g->pos4, g->T2, g->twL, g->spec1};
+                    g->pos4, g->T2, g->twL, g->spec1, g->S5};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -745,7 +791,7 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
         RL_TRY(launch1p(g, 1, (unsigned)npairs, stream, g->tops, nullptr, ntop, 1, none,
                         g->spec1));
     }
-    if (g->v4 && g->v4_min < (1 << 30)) {        // only when the path is switched on
+    if (g->v4 && (g->v4_min < (1 << 30) || g->v5)) {     // only when a path that reads them is on
         MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
         RL_TRY(launch4(1, g->ep4, dim3(ntop), dim3(g->thr4), g->lds4, stream, g->tops, nullptr,
                        ntop, g->geo, 1, g->p4, none, g->spec4));
@@ -1144,6 +1190,34 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
                         nullptr));
         RL_HIP(hipGetLastError());
         return RL_OK;
+    }
+    if (g->v4 && g->v5 && nvec <= g->v5_max) {
+        // small batch: one workgroup per (vector, output) transform, two kernels
+        bool ok = g->S5_cap >= (size_t)nvec;
+        if (!ok) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = stream != nullptr &&
+                                   hipStreamIsCapturing(stream, &cs) == hipSuccess &&
+                                   cs != hipStreamCaptureStatusNone;
+            if (!capturing) {       // (nothing may be allocated inside a capture)
+                if (g->S5) RL_HIP(hipFree(g->S5));
+                g->S5 = nullptr;
+                g->S5_cap = 0;
+                const size_t cap = std::max<size_t>((size_t)nvec, 32);
+                RL_HIP(hipMalloc((void**)&g->S5, cap * 2 * g->D * 2 * g->ep4 * g->thr4 *
+                                                     sizeof(cplx)));
+                g->S5_cap = cap;
+                ok = true;
+            }
+        }
+        if (ok) {
+            trace_once("grid product: k5_forward + k5_inverse (on chip, two kernels)");
+            MixParams mp4 = mp;
+            mp4.spec = g->spec4 + (size_t)((mp.spec - g->spec) / g->L) * (2 * g->p4.N + 1);
+            RL_TRY(launch5(g, stream, X, Y, nvec, mp4));
+            RL_HIP(hipGetLastError());
+            return RL_OK;
+        }
     }
     if (g->v4 && nvec >= g->v4_min) {
         // the whole product on chip, one workgroup per vector

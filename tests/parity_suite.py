@@ -584,17 +584,19 @@ def check_ragged_and_empty_outputs():
     assert lik.noise_gradient()[1] == 0.0        # no data, no gradient
 
 
-def check_onchip_product(big=True):
+def check_onchip_product(big=True, knob='RUNLMC_V4_MIN', value='1'):
     """The on-chip product path (one workgroup per vector, rl_kernels4.h),
     forced for every batch size, against the oracle: full mix, dense-B entry,
-    single top row, and agreement with the three-kernel path."""
+    single top row, and agreement with the three-kernel path.  With
+    knob='RUNLMC_V5_MAX' the two-kernel small-batch form of the same scheme
+    (k5_forward / k5_inverse)."""
     from runlmc_amd._native import GridOp
     cases = [(1, 1, 40, 1), (3, 2, 50, 3), (2, 2, 104, 5), (4, 3, 300, 4), (4, 6, 504, 3),
              (2, 2, 777, 4), (6, 1, 238, 2), (5, 2, 1000, 3), (3, 2, 700, 3), (6, 2, 1100, 2)]
     if big:
         cases += [(4, 3, 5004, 3), (2, 2, 5120, 2)]
-    old = os.environ.get('RUNLMC_V4_MIN')
-    os.environ['RUNLMC_V4_MIN'] = '1'
+    old = os.environ.get(knob)
+    os.environ[knob] = value
     try:
         for D, Q, m, nvec in cases:
             rng = np.random.RandomState(D * 1000 + Q * 100 + m)
@@ -603,7 +605,9 @@ def check_onchip_product(big=True):
             A = [rng.randn(1 + q % 2, D) for q in range(Q)]
             kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
             g = GridOp(D, m, Q)
-            assert g.onchip[0] == 1 and g.onchip[1] == 1, (D, Q, m, g.onchip)
+            assert g.onchip[0] == 1, (D, Q, m, g.onchip)
+            if knob == 'RUNLMC_V4_MIN':
+                assert g.onchip[1] == 1, (D, Q, m, g.onchip)
             g.set_lmc(tops, A, kap)
             X = rng.randn(nvec, D * m)
             Y = g.matmat_host(X)
@@ -630,9 +634,9 @@ def check_onchip_product(big=True):
         assert g.onchip[0] == 0
     finally:
         if old is None:
-            del os.environ['RUNLMC_V4_MIN']
+            del os.environ[knob]
         else:
-            os.environ['RUNLMC_V4_MIN'] = old
+            os.environ[knob] = old
 
 
 def check_solver_fusions():
