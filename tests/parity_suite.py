@@ -58,12 +58,6 @@ def check_bttb_examples():
     lin = _lin()
     for i in range(int(lin['bttb_count'])):
         top, sizes = lin[f'bttb{i}_top'], lin[f'bttb{i}_sizes']
-        if len(sizes) > 2:          # 3-D and up: no device path, refused loudly
-            try:
-                BTTB(top, sizes)
-            except NotImplementedError:
-                continue
-            raise AssertionError('3-D BTTB should be refused')
         M = BTTB(top, sizes)
         n = top.size
         np.testing.assert_array_equal(M.as_numpy(), lin[f'bttb{i}_dense'])
@@ -77,6 +71,21 @@ def check_bttb_examples():
         np.testing.assert_allclose(M.matmat(X), M.as_numpy().dot(X),
                                    rtol=1e-6, atol=1e-6)
         assert M.matvec(x).shape == (n,) and M.dtype == np.float64
+    # three and four dimensions beyond the reference's one example (reduced to
+    # batched 2-D device products, runlmc_amd/linalg/bttb.py) against the
+    # oracle's rfftn statement and the dense matrix
+    rng = np.random.RandomState(11)
+    for sizes in ((3, 4, 5), (4, 1, 6), (2, 3, 4, 5), (1, 1, 7), (5, 2, 1)):
+        n = int(np.prod(sizes))
+        top = rng.rand(n) + 0.1
+        M = BTTB(top, np.array(sizes))
+        O = ops.BTTBOracle(top, sizes)
+        x = rng.randn(n)
+        X = rng.randn(n, 3)
+        _close(M.matvec(x), O.matvec(x), 1e-12)
+        _close(M.matmat(X), O.as_numpy().dot(X), 1e-12)
+        np.testing.assert_array_equal(M.as_numpy(), O.as_numpy())
+        assert M.matmat(np.empty((n, 0))).shape == (n, 0)
 
 
 def check_toeplitz_examples():
