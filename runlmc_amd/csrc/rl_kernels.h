@@ -475,6 +475,66 @@ k_spmv_wide(const int* __restrict__ indptr, const int* __restrict__ indices,
 }
 
 // ---------------------------------------------------------------------------
+// k_spmv_wt_staged<VB>: W^T x for LARGE batches when W^T has the consecutive-
+// range structure (SkiTerm::WT_lo: the entries of grid row r multiply the data
+// rows lo[r], lo[r] + 1, ...; lo is non-decreasing).  The data range of a
+// workgroup's RL_THREADS grid rows is then one contiguous piece of every
+// vector: it is staged into LDS with coalesced loads together with the
+// workgroup's weights, and the rows -- whose lengths vary (as many entries as
+// data points near the grid point) -- are summed out of LDS.  One phase of
+// global loads per wavefront instead of one per group of four entries of its
+// longest row (k_spmv), same summation order, same results.
+//   grid (ceil(nrows / RL_THREADS), ceil(nvec / VB))
+//   LDS: VB * xcap doubles (vector pieces) + ecap doubles (weights); the host
+//   guarantees every workgroup's range <= xcap and entries <= ecap
+// ---------------------------------------------------------------------------
+template <int VB>
+__global__ void __launch_bounds__(RL_THREADS)
+k_spmv_wt_staged(const int* __restrict__ indptr, const int* __restrict__ lo,
+                 const double* __restrict__ vals, int nrows, int ncols, int nvec,
+                 const double* __restrict__ X, double* __restrict__ Y, int xcap,
+                 int* __restrict__ bump) {
+    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
+    RL_SMEM(smem);
+    double* xs = reinterpret_cast<double*>(smem);          // [VB][xcap]
+    double* vs = xs + (size_t)VB * xcap;                   // [ecap]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int r0 = blockIdx.x * nthr;
+    const int rl = (r0 + nthr < nrows ? r0 + nthr : nrows) - 1;      // last row of the workgroup
+    const int v0 = blockIdx.y * VB;
+    const int nv = nvec - v0 < VB ? nvec - v0 : VB;
+    const int k0 = indptr[r0], k1 = indptr[rl + 1];
+    const int c0 = lo[r0], c1 = lo[rl] + (k1 - indptr[rl]);
+    const int row = r0 + tid;
+    const int rowc = row <= rl ? row : rl;
+    const int kb = indptr[rowc];
+    const int cnt = row <= rl ? indptr[rowc + 1] - kb : 0;
+    const int l = lo[rowc];
+    for (int i = tid; i < k1 - k0; i += nthr) vs[i] = vals[k0 + i];
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+        const double* x = X + (size_t)(v0 + (j < nv ? j : 0)) * ncols + c0;
+        for (int i = tid; i < c1 - c0; i += nthr) xs[(size_t)j * xcap + i] = x[i];
+    }
+    __syncthreads();
+    double acc[VB];
+#pragma unroll
+    for (int j = 0; j < VB; ++j) acc[j] = 0.0;
+    const double* a = vs + (kb - k0);
+    const double* xr = xs + (l - c0);
+    for (int e = 0; e < cnt; ++e) {
+        const double w = a[e];
+#pragma unroll
+        for (int j = 0; j < VB; ++j) acc[j] = fma(w, xr[(size_t)j * xcap + e], acc[j]);
+    }
+    if (row <= rl) {
+#pragma unroll
+        for (int j = 0; j < VB; ++j)
+            if (j < nv) Y[(size_t)(v0 + j) * nrows + row] = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row permutation of a batch of data-space vectors.
 //   gather : Y[v][i]       = X[v][perm[i]]
 //   scatter: Y[v][perm[i]] = X[v][i]

@@ -1341,6 +1341,9 @@ struct SkiTerm {
     int* W4_base = nullptr;
     double* W4_w = nullptr;
     int* WT_lo = nullptr;
+    // largest data range / entry count of any RL_THREADS consecutive grid rows
+    // (k_spmv_wt_staged stages them in LDS); 0 = no structure
+    int wt_xmax = 0, wt_emax = 0;
 };
 
 // buffers of one rl_solve_batch call
@@ -1361,6 +1364,7 @@ struct rl_ski {
     rl_gridop* g = nullptr;
     int n = 0, ngrid = 0, nnz = 0, nnzWT = 0;
     int *W4_base = nullptr, *WT_lo = nullptr;     // interpolation structure (SkiTerm)
+    int wt_xmax = 0, wt_emax = 0;
     double* W4_w = nullptr;
     int *W_indptr = nullptr, *W_indices = nullptr;
     double* W_data = nullptr;
@@ -1512,6 +1516,12 @@ static int upload_term(SkiTerm* t, int n, int ngrid, const int* W_indptr, const 
             RL_TRY(upload_raw((void**)&t->W4_w, w4.data(), (size_t)4 * n * sizeof(double)));
             RL_TRY(upload_raw((void**)&t->WT_lo, lo.data(), (size_t)ngrid * sizeof(int)));
             WT_indptr = sp_ptr.data(); WT_indices = sp_idx.data(); WT_data = sp_val.data();
+            for (int r0 = 0; r0 < ngrid; r0 += RL_THREADS) {
+                const int rl = std::min(ngrid, r0 + RL_THREADS) - 1;
+                const int c1 = lo[rl] + (sp_ptr[rl + 1] - sp_ptr[rl]);
+                t->wt_xmax = std::max(t->wt_xmax, c1 - lo[r0]);
+                t->wt_emax = std::max(t->wt_emax, sp_ptr[rl + 1] - sp_ptr[r0]);
+            }
         }
     }
     const size_t nnzT = WT_indptr[ngrid];
@@ -1564,6 +1574,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     s->W_indptr = t0.W_indptr; s->W_indices = t0.W_indices; s->W_data = t0.W_data;
     s->WT_indptr = t0.WT_indptr; s->WT_indices = t0.WT_indices; s->WT_data = t0.WT_data;
     s->W4_base = t0.W4_base; s->W4_w = t0.W4_w; s->WT_lo = t0.WT_lo; s->nnzWT = t0.nnzWT;
+    s->wt_xmax = t0.wt_xmax; s->wt_emax = t0.wt_emax;
     s->max_ngrid = ngrid;
     s->nnz = W_indptr[n];
     RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
@@ -1678,6 +1689,27 @@ static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int sc
 // the three stages in INTERNAL row order
 static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st,
                       int* bump = nullptr) {
+    // large batch, structured W^T whose workgroup ranges fit LDS: staged form
+    // (measured at C5, 129 vectors: see DESIGN.md)
+    constexpr int VB = 8;
+    const size_t lds = ((size_t)VB * s->wt_xmax + s->wt_emax) * sizeof(double);
+    if (s->WT_lo != nullptr && s->wt_xmax > 0 && lds <= 64 * 1024 &&
+        ((size_t)s->ngrid * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
+        getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
+        trace_once("W^T product: k_spmv_wt_staged");
+        static bool attr = false;
+        if (!attr) {
+            attr = true;
+            (void)hipFuncSetAttribute((const void*)k_spmv_wt_staged<VB>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        }
+        const unsigned gx = (s->ngrid + RL_THREADS - 1) / RL_THREADS;
+        RL_LAUNCH(k_spmv_wt_staged<VB>, dim3(gx, (nvec + VB - 1) / VB), dim3(RL_THREADS), lds, st,
+                  (const int*)s->WT_indptr, (const int*)s->WT_lo, (const double*)s->WT_data,
+                  s->ngrid, s->n, nvec, Xp, G, s->wt_xmax, bump);
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
     launch_spmv(s->WT_indptr, s->WT_indices, s->WT_data, s->ngrid, s->n, nvec, Xp, G, nullptr,
                 nullptr, st, 0, bump, s->ngrid > 0 ? s->nnzWT / s->ngrid : 0);
     RL_HIP(hipGetLastError());

@@ -870,3 +870,69 @@ def check_solver_workspace_reuse():
         os.environ.pop('RUNLMC_WS_CACHE_MB', None)
         if saved is not None:
             os.environ['RUNLMC_WS_CACHE_MB'] = saved
+
+
+def check_staged_wt_product():
+    """The LDS-staged W^T product of large batches (k_spmv_wt_staged), forced
+    on small ones: bit-identical to the CSR kernels (same summation order) for
+    uniform, clustered and gappy inputs, ragged outputs and a batch that is not
+    a multiple of the vector block; through apply_wt and through a solve."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch
+    rng = np.random.RandomState(17)
+    saved = os.environ.pop('RUNLMC_STAGED_WT', None)
+    try:
+        for kind in ('uniform', 'clustered', 'gappy'):
+            p = synth.make_problem(3, 2, 1, 400, eps=1.0)
+            p.noise = p.noise + 0.5
+            if kind != 'uniform':
+                Xs = []
+                for d in range(p.D):
+                    nd = 400 - 90 * d                        # ragged outputs
+                    if kind == 'clustered':
+                        x = np.clip(0.5 + 0.02 * rng.randn(nd), 0, 1)
+                        x[:5] = [0.0, 1.0, 0.25, 0.75, 0.1]
+                    else:
+                        x = np.concatenate([0.1 * rng.rand(nd // 2), 0.9 + 0.1 * rng.rand(nd - nd // 2)])
+                    Xs.append(x.reshape(-1, 1))
+                from runlmc_amd.approx.interpolation import autogrid, multi_interpolant
+                p.Xs = Xs
+                p.lens = [len(x) for x in Xs]
+                p.n = int(sum(p.lens))
+                p.Ys = [rng.rand(k) for k in p.lens]
+                p.y = np.hstack(p.Ys)
+                p.grid = autogrid(p.Xs, lo=None, hi=None, m=[400])[0]
+                p.grid_dists = p.grid - p.grid[0]
+                p.m = len(p.grid)
+                p.W = multi_interpolant(p.Xs, p.grid)
+                p.WT = p.W.transpose().tocsr()
+                p.WT.sort_indices()
+                p.WT.indices = p.WT.indices.astype(np.int32)
+                p.WT.indptr = p.WT.indptr.astype(np.int32)
+            fk = synth.functional_kernel(p)
+            ad = (0,)
+            V = rng.randn(11, p.n)
+
+            def results():
+                K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+                op = K.device_operator()
+                G = op.apply_wt(torch.from_numpy(V).to(op.device), 0).cpu().numpy()
+                os.environ['RUNLMC_NO_FUSE_WT'] = '1'
+                os.environ['RUNLMC_NO_FUSE_W'] = '1'
+                try:
+                    Xs_, it = solve_batch(op, torch.from_numpy(V[:3]).to(op.device), tol=1e-4,
+                                          maxiter=4)[:2]
+                finally:
+                    del os.environ['RUNLMC_NO_FUSE_WT'], os.environ['RUNLMC_NO_FUSE_W']
+                return G, Xs_.cpu().numpy()
+            os.environ.pop('RUNLMC_STAGED_WT', None)
+            G0, S0 = results()
+            _close(G0, (p.WT @ V.T).T, 1e-13)
+            os.environ['RUNLMC_STAGED_WT'] = '1'
+            G1, S1 = results()
+            assert np.array_equal(G1, G0), kind
+            assert np.array_equal(S1, S0), kind
+    finally:
+        os.environ.pop('RUNLMC_STAGED_WT', None)
+        if saved is not None:
+            os.environ['RUNLMC_STAGED_WT'] = saved

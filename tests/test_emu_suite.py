@@ -137,6 +137,10 @@ def test_solver_workspace_reuse():
     ps.check_solver_workspace_reuse()
 
 
+def test_staged_wt_product():
+    ps.check_staged_wt_product()
+
+
 def test_chunked_product():
     ps.check_chunked_product()
 
