@@ -535,6 +535,59 @@ k_spmv_wt_staged(const int* __restrict__ indptr, const int* __restrict__ lo,
 }
 
 // ---------------------------------------------------------------------------
+// k_spmv_w_staged<VB>: Y = W g + diag (.) X2 for LARGE batches when W is held
+// as base column + four weights per row with non-decreasing bases
+// (SkiTerm::W4_base / W4_w): the grid range of a workgroup's RL_THREADS data
+// rows is one contiguous piece of every grid vector, staged into LDS with
+// coalesced loads; base and weights of a row are independent loads.  Two
+// dependent levels of global loads (bases of the first and last row -> range)
+// instead of three (row pointers -> entries -> gathered values), no index
+// array, same summation order as k_spmv.
+//   grid (ceil(nrows / RL_THREADS), ceil(nvec / VB))    LDS: VB * xcap doubles
+// ---------------------------------------------------------------------------
+template <int VB>
+__global__ void __launch_bounds__(RL_THREADS)
+k_spmv_w_staged(const int* __restrict__ base, const double* __restrict__ w4, int nrows,
+                int ncols, int nvec, const double* __restrict__ G, double* __restrict__ Y,
+                const double* __restrict__ diag, const double* __restrict__ X2, int xcap) {
+    RL_SMEM(smem);
+    double* xs = reinterpret_cast<double*>(smem);          // [VB][xcap]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int r0 = blockIdx.x * nthr;
+    const int rl = (r0 + nthr < nrows ? r0 + nthr : nrows) - 1;
+    const int v0 = blockIdx.y * VB;
+    const int nv = nvec - v0 < VB ? nvec - v0 : VB;
+    const int c0 = base[r0], c1 = base[rl] + 4;
+    const int row = r0 + tid;
+    const int rowc = row <= rl ? row : rl;
+    const int b = base[rowc];
+    double w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = w4[(size_t)4 * rowc + e];
+    const double dg = diag != nullptr ? diag[rowc] : 0.0;
+    double x2[VB];
+#pragma unroll
+    for (int j = 0; j < VB; ++j)
+        x2[j] = diag != nullptr ? X2[(size_t)(v0 + (j < nv ? j : 0)) * nrows + rowc] : 0.0;
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+        const double* g = G + (size_t)(v0 + (j < nv ? j : 0)) * ncols + c0;
+        for (int i = tid; i < c1 - c0; i += nthr) xs[(size_t)j * xcap + i] = g[i];
+    }
+    __syncthreads();
+    if (row > rl) return;
+    const double* xr = xs + (b - c0);
+#pragma unroll
+    for (int j = 0; j < VB; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fma(w[e], xr[(size_t)j * xcap + e], acc);
+        if (diag != nullptr) acc = fma(dg, x2[j], acc);
+        if (j < nv) Y[(size_t)(v0 + j) * nrows + row] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row permutation of a batch of data-space vectors.
 //   gather : Y[v][i]       = X[v][perm[i]]
 //   scatter: Y[v][perm[i]] = X[v][i]

@@ -1344,6 +1344,7 @@ struct SkiTerm {
     // largest data range / entry count of any RL_THREADS consecutive grid rows
     // (k_spmv_wt_staged stages them in LDS); 0 = no structure
     int wt_xmax = 0, wt_emax = 0;
+    int w_xmax = 0;            // largest grid range of RL_THREADS consecutive data rows
 };
 
 // buffers of one rl_solve_batch call
@@ -1364,7 +1365,7 @@ struct rl_ski {
     rl_gridop* g = nullptr;
     int n = 0, ngrid = 0, nnz = 0, nnzWT = 0;
     int *W4_base = nullptr, *WT_lo = nullptr;     // interpolation structure (SkiTerm)
-    int wt_xmax = 0, wt_emax = 0;
+    int wt_xmax = 0, wt_emax = 0, w_xmax = 0;
     double* W4_w = nullptr;
     int *W_indptr = nullptr, *W_indices = nullptr;
     double* W_data = nullptr;
@@ -1516,6 +1517,9 @@ static int upload_term(SkiTerm* t, int n, int ngrid, const int* W_indptr, const 
             RL_TRY(upload_raw((void**)&t->W4_w, w4.data(), (size_t)4 * n * sizeof(double)));
             RL_TRY(upload_raw((void**)&t->WT_lo, lo.data(), (size_t)ngrid * sizeof(int)));
             WT_indptr = sp_ptr.data(); WT_indices = sp_idx.data(); WT_data = sp_val.data();
+            for (int r0 = 0; r0 < n; r0 += RL_THREADS)
+                t->w_xmax = std::max(t->w_xmax,
+                                     base[std::min(n, r0 + RL_THREADS) - 1] + 4 - base[r0]);
             for (int r0 = 0; r0 < ngrid; r0 += RL_THREADS) {
                 const int rl = std::min(ngrid, r0 + RL_THREADS) - 1;
                 const int c1 = lo[rl] + (sp_ptr[rl + 1] - sp_ptr[rl]);
@@ -1574,7 +1578,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     s->W_indptr = t0.W_indptr; s->W_indices = t0.W_indices; s->W_data = t0.W_data;
     s->WT_indptr = t0.WT_indptr; s->WT_indices = t0.WT_indices; s->WT_data = t0.WT_data;
     s->W4_base = t0.W4_base; s->W4_w = t0.W4_w; s->WT_lo = t0.WT_lo; s->nnzWT = t0.nnzWT;
-    s->wt_xmax = t0.wt_xmax; s->wt_emax = t0.wt_emax;
+    s->wt_xmax = t0.wt_xmax; s->wt_emax = t0.wt_emax; s->w_xmax = t0.w_xmax;
     s->max_ngrid = ngrid;
     s->nnz = W_indptr[n];
     RL_HIP(hipMalloc((void**)&s->noise_diag, (size_t)n * sizeof(double)));
@@ -1717,6 +1721,26 @@ static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStrea
 }
 static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const double* diag,
                      const double* X2p, hipStream_t st) {
+    // large batch, structured W: staged form (see ski_wt_int)
+    constexpr int VB = 8;
+    const size_t lds = (size_t)VB * s->w_xmax * sizeof(double);
+    if (s->W4_base != nullptr && s->w_xmax > 0 && lds <= 64 * 1024 &&
+        ((size_t)s->n * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
+        getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
+        trace_once("W product: k_spmv_w_staged");
+        static bool attr = false;
+        if (!attr) {
+            attr = true;
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged<VB>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        }
+        const unsigned gx = (s->n + RL_THREADS - 1) / RL_THREADS;
+        RL_LAUNCH(k_spmv_w_staged<VB>, dim3(gx, (nvec + VB - 1) / VB), dim3(RL_THREADS), lds, st,
+                  (const int*)s->W4_base, (const double*)s->W4_w, s->n, s->ngrid, nvec, G, Yp,
+                  diag, X2p, s->w_xmax);
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
     launch_spmv(s->W_indptr, s->W_indices, s->W_data, s->n, s->ngrid, nvec, G, Yp, diag, X2p,
                 st);
     RL_HIP(hipGetLastError());

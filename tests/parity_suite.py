@@ -873,8 +873,8 @@ def check_solver_workspace_reuse():
 
 
 def check_staged_wt_product():
-    """The LDS-staged W^T product of large batches (k_spmv_wt_staged), forced
-    on small ones: bit-identical to the CSR kernels (same summation order) for
+    """The LDS-staged W^T and W products of large batches (k_spmv_wt_staged,
+    k_spmv_w_staged), forced on small ones: bit-identical to the CSR kernels (same summation order) for
     uniform, clustered and gappy inputs, ragged outputs and a batch that is not
     a multiple of the vector block; through apply_wt and through a solve."""
     from runlmc_amd.util import synth
@@ -917,6 +917,7 @@ def check_staged_wt_product():
                 K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
                 op = K.device_operator()
                 G = op.apply_wt(torch.from_numpy(V).to(op.device), 0).cpu().numpy()
+                Yk = op.matmat_host(V)           # W^T, grid product, W + noise
                 os.environ['RUNLMC_NO_FUSE_WT'] = '1'
                 os.environ['RUNLMC_NO_FUSE_W'] = '1'
                 try:
@@ -924,14 +925,15 @@ def check_staged_wt_product():
                                           maxiter=4)[:2]
                 finally:
                     del os.environ['RUNLMC_NO_FUSE_WT'], os.environ['RUNLMC_NO_FUSE_W']
-                return G, Xs_.cpu().numpy()
+                return G, Xs_.cpu().numpy(), Yk
             os.environ.pop('RUNLMC_STAGED_WT', None)
-            G0, S0 = results()
+            G0, S0, Y0 = results()
             _close(G0, (p.WT @ V.T).T, 1e-13)
             os.environ['RUNLMC_STAGED_WT'] = '1'
-            G1, S1 = results()
+            G1, S1, Y1 = results()
             assert np.array_equal(G1, G0), kind
             assert np.array_equal(S1, S0), kind
+            assert np.array_equal(Y1, Y0), kind
     finally:
         os.environ.pop('RUNLMC_STAGED_WT', None)
         if saved is not None:
