@@ -53,10 +53,17 @@ def test_random_shapes_vs_oracle():
     print('fuzz: %d shapes, worst relative error %.2e' % (n_draws, worst))
 
 
-def test_random_ski_operators_and_solves():
+@pytest.mark.parametrize('staged', [False, True])
+def test_random_ski_operators_and_solves(staged, monkeypatch):
     """Random ragged multi-output problems through the package API: the SKI
     operator against the oracle's, then a batched solve whose reported
-    residuals are recomputed through the oracle operator."""
+    residuals are recomputed through the oracle operator.  `staged` forces the
+    LDS-staged W^T / W products of large batches onto these small ones, with
+    the fused small-system forms off so that the solver goes through them."""
+    if staged:
+        monkeypatch.setenv('RUNLMC_STAGED_WT', '1')
+        monkeypatch.setenv('RUNLMC_NO_FUSE_W', '1')
+        monkeypatch.setenv('RUNLMC_NO_FUSE_WT', '1')
     from runlmc_amd.approx.interpolation import autogrid, multi_interpolant
     from runlmc_amd.approx.iterative import Iterative
     from runlmc_amd.kern.stationary import RBF, Matern32
