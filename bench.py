@@ -294,6 +294,11 @@ def main():
                      'algorithmic_bytes_per_step': alg,
                      'device_ms_per_step': ev_ms},
     }
+    tr = out['roofline']['traffic']
+    if tr is not None and ev_ms > 0:
+        # rate at which the MEASURED bytes move (the two-level transform moves
+        # ~5x the algorithmic bytes: DESIGN.md section 5)
+        out['roofline']['traffic_GBps'] = tr / (ev_ms * 1e-3) / 1e9
 
     if not args.no_sweep and world == 1:
         # the configured batch (N+1 vectors) is latency-bound on a chip this
