@@ -1,71 +1,246 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Kronecker-Toeplitz MVMs/sec (+ NLL-and-gradient
-wall-clock) at a synthetic (D, Q, m) configuration of BASELINE.json.
+"""Headline benchmark: Kronecker-Toeplitz MVMs/sec + NLL-and-gradient
+wall-clock at the synthetic (D, Q, m) configurations of BASELINE.json.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5              # 1 GPU
+    python bench.py --gpus 1 --steps 20 --warmup 5              # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step is ONE batched grid product  Y = K_UU X,  K_UU = sum_q B_q (x) T_q, over
-the N+1 vectors a gradient step's solver iteration carries (y and the N
-Hutchinson probes this rank owns).  Inputs are resident in HBM before the timed
-region.  Ranks hold replicas of the operator and their own probe shard, with
-no collective in the product (weak scaling; value = all ranks' MVMs / time).
+Headline (`value`): C5 (D=10, Q=5, m=10^5 -> grid 100 004, N=128 probes).  A
+step is ONE batched grid product  Y = K_UU X,  K_UU = sum_q B_q (x) T_q,  over
+the N+1 = 129 vectors a gradient step's solver iteration carries (y and the
+Hutchinson probes this rank owns), inputs resident in HBM before the timed
+region.  Ranks hold replicas of the operator and their own probe shard with no
+collective in the product (weak scaling; value = all ranks' MVMs / max time).
+`value`, `ms_per_step` and `roofline.achieved` come from ONE clock: the wall
+clock around the K steps, bracketed by barrier + synchronize (the device-event
+time of the same region is printed beside it as a cross-check).
+
+Extra keys of the same JSON line: the full K~ = W K_UU W^T + eps product, the
+NLL+gradient step (eps = 0.1 as the reference, and the eps = 1 control of
+SURVEY 8d), the same set at C2 under "c2", and `cpu_baseline` -- the oracle
+timed on this host in a child process that never touches the GPU (single-core
+grid MVMs/sec; NLL+gradient with multiprocessing.Pool(cpu_count()) over the N+1
+solves as reference benchmarks/benchlib/bench.py:214-227 does).
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 os.environ.setdefault('OMP_NUM_THREADS', '1')   # reference bench.py:7
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from runlmc_amd.util import synth  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-
-# HBM-side bytes per step from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
-# separate runs; FETCH_SIZE of the 16-B/lane reads of the intermediates doubled
-# per the gfx950 correction of MI355X_MICROARCH.md; Infinity-Cache hits are
-# counted by these counters).  Keyed by (config, batch); source file alongside.
-MEASURED_TRAFFIC = {
-    # FETCH_SIZE + WRITE_SIZE of the three kernels per step; FETCH_SIZE of the
-    # 16-byte-per-lane reads of T doubled (gfx950 correction, MI355X_MICROARCH.md)
-    ('c2', 17): (29.7e6, 'profiles/r01/v5_c2_k17_pmc_summary.txt'),
-}
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02', 'traffic.json')
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--config', default='c2', choices=sorted(synth.CONFIGS))
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='c5', choices=['c1', 'c2', 'c5'])
     ap.add_argument('--batch', type=int, default=0,
                     help='vectors per step (default: probes per GPU + 1)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
     ap.add_argument('--no-nll', action='store_true', help='skip the NLL+grad timing')
     ap.add_argument('--no-sweep', action='store_true',
                     help='skip the saturating-batch timings (extra keys)')
-    ap.add_argument('--cpu-seconds', type=float, default=8.0)
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the second configuration (the "c2" key)')
+    ap.add_argument('--cpu-seconds', type=float, default=8.0,
+                    help='budget of each bounded CPU sample')
     # debugging aids for the multi-rank path on a one-GPU box
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
     ap.add_argument('--same-gpu', action='store_true',
                     help='every rank uses cuda:0 (only meaningful with gloo)')
+    # internal: the CPU-baseline child process (never imports torch)
+    ap.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------
+# CPU baseline: runs in a child process (no GPU runtime in it, so forking a
+# process pool is safe), imports oracle/ -- the only part of this file that does
+# ---------------------------------------------------------------------------
+_POOL_OP = None
+_POOL_CAP = 0
+
+
+def _pool_solve(rhs):
+    """One of the N+1 solves of the reference's pool (stochastic_deriv.py:39-52
+    -> Iterative.solve): SciPy-rule MINRES + the 100-iteration residual check,
+    optionally capped at _POOL_CAP iterations for the bounded C5 sample."""
+    from oracle.solver import minres_ps, _EarlyExit
+    op = _POOL_OP
+    t0 = time.perf_counter()
+    ctr = [0]
+
+    def cb(x):
+        ctr[0] += 1
+        if ctr[0] % 100 == 0 and np.linalg.norm(rhs - op.matvec(x)) < 1e-4:
+            raise _EarlyExit(x)
+        if _POOL_CAP and ctr[0] >= _POOL_CAP:
+            raise _EarlyExit(x)
+    try:
+        x = minres_ps(op.matvec, rhs, rtol=1e-10, maxiter=len(rhs), callback=cb)[0]
+    except _EarlyExit as e:
+        x = e.x
+    return x, ctr[0], time.perf_counter() - t0
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_child(spec_json):
+    """Child-process entry: times the oracle on the host cores."""
+    global _POOL_OP, _POOL_CAP
+    import multiprocessing as mp
+    from runlmc_amd.util import synth
+    from oracle import likelihood as olik
+    from oracle import operators as ops
+    from oracle.kernels import KernelSpec, RBFSpec
+    req = json.loads(spec_json)
+    out = {}
+    cores = os.cpu_count() or 1
+    for name, job in req['jobs'].items():
+        D, Q, R, m_data, n_probes = synth.CONFIGS[job['config']]
+        p = synth.make_problem(D, Q, R, m_data, eps=job.get('eps', 0.1))
+        spec = KernelSpec(p.D, [RBFSpec(g) for g in p.inv_lengthscales],
+                          list(p.coreg_vecs), list(p.coreg_diags), p.noise)
+        spec.set_input_dim(1)
+        res = {}
+        if job.get('mvm'):
+            # grid MVMs/sec on ONE core, in the 'sum' representation (what the
+            # reference benchmarks force) and the one gen_grid_kernel auto-selects
+            x = np.random.RandomState(0).randn(p.D * p.m)
+            rates = {}
+            for kt in ('sum', olik.choose_ktype(spec)):
+                if kt in rates:
+                    continue
+                op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens, ktype=kt)
+                op.grid_matvec(x)
+                op.grid_matvec(x)
+                count, t0 = 0, time.perf_counter()
+                while True:
+                    op.grid_matvec(x)
+                    count += 1
+                    el = time.perf_counter() - t0
+                    if el >= req['seconds'] / 2 or (count >= 2000 and el > 1.0):
+                        break
+                rates[kt] = count / el
+            best = max(rates, key=rates.get)
+            res['mvm'] = dict(value=rates[best], representation=best,
+                              all={k: round(v, 3) for k, v in rates.items()},
+                              seconds_per_representation=req['seconds'] / 2)
+        if job.get('nll'):
+            # NLL+gradient the reference's way: Pool(cpu_count()) over the N+1
+            # solves (bench.py:214-227), then the per-parameter gradient loops in
+            # the parent (likelihood.py:48-96)
+            np.random.seed(4321)
+            probes = np.random.randint(0, 2, (n_probes, p.n)) * 2 - 1
+            op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+            _POOL_OP = op
+            _POOL_CAP = int(job.get('iteration_cap', 0))
+            rhs = [p.y] + [r.astype(np.float64) for r in probes]
+            nproc = min(cores, len(rhs))
+            ctx = mp.get_context('fork')
+            t0 = time.perf_counter()
+            with ctx.Pool(processes=nproc) as pool:
+                sols = pool.map(_pool_solve, rhs, chunksize=1)
+            solve_wall = time.perf_counter() - t0
+            iters = np.array([s[1] for s in sols])
+            per_it = float(np.mean([s[2] / max(s[1], 1) for s in sols]))
+            alpha = sols[0][0]
+            inv_rs = np.array([s[0] for s in sols[1:]])
+            n_params = p.Q * p.R * p.D + p.Q * p.D + p.Q + p.D
+            info = dict(cores=cores, processes=nproc, rhs=len(rhs),
+                        iterations_mean=float(iters.mean()),
+                        solve_wall_s=solve_wall, per_iteration_s=per_it,
+                        params=n_params)
+            if not _POOL_CAP:
+                # the full gradient loops, timed
+                t1 = time.perf_counter()
+                olik.stochastic_gradients(spec, p.grid_dists, p.W, p.WT, p.lens, alpha,
+                                          probes, inv_rs)
+                info['grad_wall_s'] = time.perf_counter() - t1
+                info['seconds'] = solve_wall + info['grad_wall_s']
+                info['kind'] = 'timed in full'
+                info['sample'] = ('Pool(%d) over %d solves run to the reference stopping rule, '
+                                  'then all %d parameters x %d right-hand sides of dK products '
+                                  'in the parent' % (nproc, len(rhs), n_params, len(rhs)))
+            else:
+                # bounded sample: solves stopped after `cap` iterations and dK
+                # products timed on a subset; both scaled linearly (every MINRES
+                # iteration and every dK product costs the same)
+                T = ops.BTTBOracle(op.tops[0], (p.m,))
+                xg = np.random.RandomState(1).randn(p.n)
+                reps, t1 = 0, time.perf_counter()
+                while time.perf_counter() - t1 < req['seconds'] / 2 or reps < 2:
+                    p.W.dot(ops.kron_matvec(op.Bs[0], T, p.WT.dot(xg)))
+                    reps += 1
+                per_dk = (time.perf_counter() - t1) / reps
+                target = float(job['iterations_target'])
+                # (the measured wall already spans every wave of the pool)
+                solve_est = solve_wall * target / max(float(iters.mean()), 1.0)
+                grad_est = per_dk * (n_params - p.D) * len(rhs)
+                info.update(per_dK_product_s=per_dk, dK_products_timed=reps,
+                            iteration_cap=_POOL_CAP, iterations_target=target,
+                            solve_est_s=solve_est, grad_est_s=grad_est,
+                            seconds=solve_est + grad_est, kind='extrapolated from a bounded sample',
+                            sample=('Pool(%d) over %d solves, each stopped after %d MINRES '
+                                    'iterations (measured wall %.1f s) and scaled to the %.0f '
+                                    'iterations the device solve took; gradient loops: %d dK '
+                                    'products timed on one core, scaled to %d parameters x %d '
+                                    'right-hand sides (serial in the parent, as the reference)'
+                                    % (nproc, len(rhs), _POOL_CAP, solve_wall, target, reps,
+                                       n_params - p.D, len(rhs))))
+            res['nll_grad'] = info
+        out[name] = res
+    out['cpu_model'] = _cpu_model()
+    out['cores'] = cores
+    print('CPUJSON ' + json.dumps(out), flush=True)
+
+
+def run_cpu_child(jobs, seconds):
+    req = json.dumps(dict(jobs=jobs, seconds=seconds))
+    env = dict(os.environ, OMP_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', req],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith('CPUJSON '):
+            return json.loads(line[8:])
+    raise RuntimeError('CPU baseline child failed (rc %d): %s' % (r.returncode, r.stderr[-2000:]))
+
+
+# ---------------------------------------------------------------------------
+# GPU side
+# ---------------------------------------------------------------------------
 def dist_setup(args):
+    import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit(
+            'bench.py --gpus %d but WORLD_SIZE=%d: launch N ranks with\n  python -m '
+            'torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 '
+            '--master-port 29500 bench.py --gpus %d ...' % (args.gpus, world, args.gpus, args.gpus))
     local = 0 if args.same_gpu else int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -89,6 +264,7 @@ def barrier(world):
 def max_over_ranks(x, world, dev):
     if world == 1:
         return x
+    import torch
     import torch.distributed as dist
     on = dev if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([x], dtype=torch.float64, device=on)
@@ -96,11 +272,13 @@ def max_over_ranks(x, world, dev):
     return float(t[0])
 
 
-def time_grid_mvm(gridop, X, Y, steps, warmup, world):
-    """Events on the stream the library launches on (torch's current)."""
-    dev = X.device
+def time_steps(fn, steps, warmup, world, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on
+    both sides.  Returns (wall ms per step, device-event ms per step); events
+    sit on the stream the library launches on (torch's current stream)."""
+    import torch
     for _ in range(warmup):
-        gridop.mvm(X, out=Y)
+        fn()
     torch.cuda.synchronize(dev)
     barrier(world)
     torch.cuda.synchronize(dev)
@@ -109,118 +287,31 @@ def time_grid_mvm(gridop, X, Y, steps, warmup, world):
     t0 = time.perf_counter()
     e0.record()
     for _ in range(steps):
-        gridop.mvm(X, out=Y)
+        fn()
     e1.record()
     torch.cuda.synchronize(dev)
     barrier(world)
     torch.cuda.synchronize(dev)
     wall_ms = (time.perf_counter() - t0) * 1e3
-    ev_ms = e0.elapsed_time(e1)
-    return wall_ms / steps, ev_ms / steps
+    return wall_ms / steps, e0.elapsed_time(e1) / steps
 
 
-def cpu_baseline(p, tops, seconds):
-    """The oracle (NumPy restatement of the reference path) on ONE host core:
-    grid MVMs/sec in the 'sum' representation (what BASELINE.json's metric
-    names; reference benchmarks force it with ktype='sum') and in the
-    representation gen_grid_kernel would auto-select."""
-    from oracle import operators as ops
-    from oracle import likelihood as olik
-    from oracle.kernels import KernelSpec, RBFSpec
-    spec = KernelSpec(p.D, [RBFSpec(g) for g in p.inv_lengthscales],
-                      list(p.coreg_vecs), list(p.coreg_diags), p.noise)
-    spec.set_input_dim(1)
-    rng = np.random.RandomState(0)
-    x = rng.randn(p.D * p.m)
-    out = {}
-    for kt in ('sum', olik.choose_ktype(spec)):
-        if kt in out:
-            continue
-        op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens, ktype=kt)
-        op.grid_matvec(x)                       # warm-up
-        op.grid_matvec(x)
-        count, t0 = 0, time.perf_counter()
-        budget = seconds / 2
-        while True:
-            op.grid_matvec(x)
-            count += 1
-            el = time.perf_counter() - t0
-            if el >= budget or (count >= 2000 and el > 1.0):
-                break
-        out[kt] = count / el
-    best = max(out, key=out.get)
-    return dict(value=out[best], unit='MVM/s', cores=1, kind='port',
-                sample='%.0f s of single-vector grid MVMs per representation '
-                       '(oracle, NumPy pocketfft, OMP_NUM_THREADS=1); '
-                       'representation=%s; all=%s'
-                       % (seconds / 2, best,
-                          {k: round(v, 2) for k, v in out.items()}),
-                cpu_model=_cpu_model()), spec
-
-
-def _cpu_model():
+def measured_traffic(config, batch):
+    """HBM-side bytes per step of the grid product from this round's PMC
+    passes (tools/pmc.sh -> profiles/r02/traffic.json), or (None, None)."""
     try:
-        for line in open('/proc/cpuinfo'):
-            if line.startswith('model name'):
-                return line.split(':', 1)[1].strip()
-    except OSError:
-        pass
-    return 'unknown'
+        table = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    e = table.get('%s:%d' % (config, batch))
+    return (e['bytes_per_step'], e['source']) if e else (None, None)
 
 
-def cpu_nll_grad(p, spec, probes, iters_hint, seconds):
-    """Reference-path NLL+gradient wall-clock on the host, bounded: times a
-    few MINRES iterations and gradient MVMs of the oracle and scales by the
-    counts the full step needs when the full step would not fit the budget."""
-    from oracle import likelihood as olik
-    from oracle.solver import minres_ps
-    op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
-    n_rhs = len(probes) + 1
-    cores = os.cpu_count() or 1
-    # time MINRES iterations on y
-    its = 0
-    t0 = time.perf_counter()
-
-    class _Stop(Exception):
-        pass
-
-    def cb(_x):
-        nonlocal its
-        its += 1
-        if time.perf_counter() - t0 > seconds / 2 or its >= iters_hint:
-            raise _Stop()
-    try:
-        minres_ps(op.matvec, p.y, rtol=1e-10, maxiter=p.n, callback=cb)
-    except _Stop:
-        pass
-    per_it = (time.perf_counter() - t0) / max(its, 1)
-    # gradient side: P (N+1) single-term operator products (likelihood.py:48-96)
-    from oracle import operators as ops
-    T = ops.BTTBOracle(op.tops[0], (p.m,))
-    t1 = time.perf_counter()
-    reps = 0
-    xg = np.random.RandomState(1).randn(p.n)
-    while time.perf_counter() - t1 < seconds / 4 or reps < 2:
-        p.W.dot(ops.kron_matvec(op.Bs[0], T, p.WT.dot(xg)))
-        reps += 1
-    per_dk = (time.perf_counter() - t1) / reps
-    n_params = p.Q * p.R * p.D + p.Q * p.D + p.Q     # A_q, kappa_q, one RBF param each
-    solve_serial = per_it * iters_hint * n_rhs
-    grad_serial = per_dk * n_params * n_rhs
-    est = solve_serial / min(cores, n_rhs) + grad_serial
-    return dict(est_seconds=est, per_iteration_s=per_it, per_dK_mvm_s=per_dk,
-                iterations_assumed=int(iters_hint), rhs=n_rhs, params=n_params,
-                cores=cores,
-                sample='%d MINRES iterations on y + %d single-term dK products '
-                       'timed on one core; scaled to %d rhs x %d iterations '
-                       '(solves spread over min(cores, rhs) processes as the '
-                       'reference pool does) + %d params x %d rhs dK products'
-                       % (its, reps, n_rhs, iters_hint, n_params, n_rhs))
-
-
-def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=3):
+def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2):
     """One parameters_changed() equivalent on the device: operator update,
     alpha + probe solves, all four gradient families."""
+    import torch
+    from runlmc_amd.util import synth
     from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
     from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
     from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
@@ -230,7 +321,7 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=3):
                              device_index=torch.cuda.current_device())
     svc = StochasticDerivService(None, None, n_probes_global, 1e-4, group=group)
     best, info = None, None
-    for _ in range(repeats):
+    for _ in range(repeats + 1):          # first pass warms workspaces and graphs
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         gks[ad].update(fk, p.grid_dists)
@@ -240,107 +331,175 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=3):
              lik.kernel_gradients(), lik.noise_gradient())
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        if info is None:
+            info = {}
+            continue
         if best is None or el < best:
             best = el
             info = dict(iterations_mean=float(np.mean(lik.deriv.iterations)),
                         iterations_max=int(np.max(lik.deriv.iterations)),
                         residual_max=float(np.max(lik.deriv.residuals)),
+                        residual_median=float(np.median(lik.deriv.residuals)),
                         grad_norm=float(np.sqrt(sum(np.sum(np.square(x)) for x in
                                                     g[0] + g[1] + [np.array(g[2])] + [g[3]]))))
     info['seconds'] = best
     return info
 
 
-def main():
-    args = parse()
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: runlmc_amd has no CPU path')
-    rank, world, local = dist_setup(args)
-    dev = torch.device('cuda', torch.cuda.current_device())
-    D, Q, R, m_data, n_probes = synth.CONFIGS[args.config]
+def bench_config(name, args, rank, world, dev, steps, warmup, headline):
+    """All device measurements of one (D, Q, m) configuration."""
+    import torch
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import GridOp, SkiOp
+    D, Q, R, m_data, n_probes = synth.CONFIGS[name]
     p = synth.make_problem(D, Q, R, m_data)
-    from runlmc_amd._native import GridOp
     g = GridOp(D, p.m, Q, device_index=dev.index)
     tops = synth.tops(p)
     g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
 
     # weak scaling: every rank carries n_probes probes (+ y)
-    batch = args.batch or (n_probes + 1)
+    batch = (args.batch if headline else 0) or (n_probes + 1)
     gen = torch.Generator(device='cpu').manual_seed(1000 + rank)
     X = torch.randn(batch, D * p.m, dtype=torch.float64, generator=gen).to(dev)
     Y = torch.empty_like(X)
-    wall_ms, ev_ms = time_grid_mvm(g, X, Y, args.steps, args.warmup, world)
+    wall_ms, ev_ms = time_steps(lambda: g.mvm(X, out=Y), steps, warmup, world, dev)
     wall_ms = max_over_ranks(wall_ms, world, dev)
     ev_ms = max_over_ranks(ev_ms, world, dev)
     mvms = batch * world / (wall_ms * 1e-3)
     alg = synth.algorithmic_bytes_grid_mvm(D, Q, p.m, g.L, batch)
-    achieved = alg / (ev_ms * 1e-3) / 1e9
-
+    achieved = alg / (wall_ms * 1e-3) / 1e9
+    traffic, source = measured_traffic(name, batch)
     out = {
-        'metric': 'kronecker_toeplitz_mvms_per_sec',
-        'value': mvms, 'unit': 'MVM/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': wall_ms, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'value': mvms, 'ms_per_step': wall_ms,
         'config': {'workload': '%s synthetic D=%d Q=%d R=%d m=%d (grid %d, L=%d) '
-                               'N=%d probes/GPU, batch=%d vectors/step'
-                               % (args.config, D, Q, R, m_data, p.m, g.L, n_probes, batch),
+                               'N=%d probes/GPU, batch=%d vectors/step, K_UU product'
+                               % (name, D, Q, R, m_data, p.m, g.L, n_probes, batch),
                    'D': D, 'Q': Q, 'm': p.m, 'L': g.L, 'batch': batch,
                    'fft_split': [g.N1, g.N2], 'parallelism': 'probe-shard x%d' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': MEASURED_TRAFFIC.get((args.config, batch), (None, None))[0],
-                     'traffic_source': MEASURED_TRAFFIC.get((args.config, batch), (None, None))[1],
-                     'kernel': 'grid MVM = k2_cols_fwd + k2_rows_mix<%d> + k2_cols_inv' % D,
+                     'traffic': traffic, 'traffic_source': source,
+                     'kernel': 'grid MVM (column transforms + row transforms with the '
+                               'D x D mix + adjoint column transforms), D=%d' % D,
                      'algorithmic_bytes_per_step': alg,
-                     'device_ms_per_step': ev_ms},
+                     'clock': 'wall, same region as value',
+                     'device_event_ms_per_step': ev_ms},
     }
-    tr = out['roofline']['traffic']
-    if tr is not None and ev_ms > 0:
-        # rate at which the MEASURED bytes move (the two-level transform moves
-        # ~5x the algorithmic bytes: DESIGN.md section 5)
-        out['roofline']['traffic_GBps'] = tr / (ev_ms * 1e-3) / 1e9
+    if traffic is not None:
+        out['roofline']['traffic_GBps'] = traffic / (wall_ms * 1e-3) / 1e9
+
+    # the full operator  K~ = W K_UU W^T + eps  on the same batch (data space)
+    s = SkiOp(g, p.W, p.WT)
+    s.set_noise(p.noise, p.lens)
+    Xd = torch.randn(batch, p.n, dtype=torch.float64, generator=gen).to(dev)
+    Yd = torch.empty_like(Xd)
+    fsteps = max(3, steps // 2)
+    fwall, fev = time_steps(lambda: s.mvm(Xd, out=Yd), fsteps, 2, world, dev)
+    fwall = max_over_ranks(fwall, world, dev)
+    nnz = int(p.W.nnz)
+    full_alg = alg + 8 * 3 * p.n * batch + 2 * (nnz * 12 + (p.n + 1) * 4)
+    out['full_mvm'] = {'mvm_per_s': batch * world / (fwall * 1e-3), 'ms_per_step': fwall,
+                       'steps': fsteps, 'n': p.n,
+                       'roofline_frac': full_alg / (fwall * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       'algorithmic_bytes_per_step': full_alg,
+                       'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors' % batch}
+    del s, Xd, Yd
 
     if not args.no_sweep and world == 1:
-        # the configured batch (N+1 vectors) is latency-bound on a chip this
-        # size; larger batches show what the same kernels sustain
+        # the N+1-vector batch is what a solver round carries; larger batches
+        # show what the same kernels sustain
         sweep = {}
         for b in (64, 256, 1024, 4096):
-            if b * D * p.m * 8 * 2 > 4e9:
+            if b == batch or b * D * p.m * 8 * 2 > 4.2e9:
                 continue
             Xb = torch.randn(b, D * p.m, dtype=torch.float64, device=dev)
             Yb = torch.empty_like(Xb)
-            _, ms = time_grid_mvm(g, Xb, Yb, max(3, args.steps // 10), 2, 1)
+            w_ms, _ = time_steps(lambda: g.mvm(Xb, out=Yb), max(3, steps // 4), 2, 1, dev)
             ab = synth.algorithmic_bytes_grid_mvm(D, Q, p.m, g.L, b)
-            sweep[str(b)] = {'mvm_per_s': b / (ms * 1e-3),
-                             'roofline_frac': ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             'path': 'on-chip' if g.onchip[0] and b >= g.onchip[1]
-                             else 'three-kernel'}
+            sweep[str(b)] = {'mvm_per_s': b / (w_ms * 1e-3),
+                             'roofline_frac': ab / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del Xb, Yb
         out['batch_sweep'] = sweep
+    del X, Y
 
     if not args.no_nll:
-        import torch.distributed as dist
-        np.random.seed(4321)
-        # the config's N probes in total, dealt round-robin to the ranks
-        # (strong scaling of one optimiser step; alpha is solved on every rank)
-        total = n_probes
-        probes = np.random.randint(0, 2, (total, p.n)) * 2 - 1
-        info = gpu_nll_grad(p, probes, total)
-        info['seconds'] = max_over_ranks(info['seconds'], world, dev)
-        info['n_probes_global'] = total
-        info['scaling'] = 'strong'
-        info['probes_per_rank'] = -(-total // world)
-        out['nll_grad'] = info
+        for key, eps in (('nll_grad', 0.1), ('nll_grad_eps1', 1.0)):
+            pe = p if eps == 0.1 else synth.make_problem(D, Q, R, m_data, eps=eps)
+            np.random.seed(4321)
+            # the config's N probes in total, dealt round-robin to the ranks
+            # (strong scaling of one optimiser step)
+            probes = np.random.randint(0, 2, (n_probes, pe.n)) * 2 - 1
+            info = gpu_nll_grad(pe, probes, n_probes)
+            info['seconds'] = max_over_ranks(info['seconds'], world, dev)
+            info.update(n_probes_global=n_probes, scaling='strong', eps=eps,
+                        probes_per_rank=-(-n_probes // world))
+            out[key] = info
+    return out
+
+
+def main():
+    args = parse()
+    if args.cpu_child is not None:
+        cpu_child(args.cpu_child)
+        return
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: runlmc_amd has no CPU path')
+    rank, world, local = dist_setup(args)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    head = bench_config(args.config, args, rank, world, dev, args.steps, args.warmup, True)
+    out = {
+        'metric': 'kronecker_toeplitz_mvms_per_sec',
+        'value': head.pop('value'), 'unit': 'MVM/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': head.pop('ms_per_step'),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+    }
+    out.update(head)
+    other = 'c2' if args.config != 'c2' else None
+    if other and not args.no_extra and world == 1:
+        # the small synthetic configuration of BASELINE.json as an extra key
+        # (17 vectors per step: launch-latency-bound by construction)
+        out[other] = bench_config(other, args, rank, world, dev, max(args.steps, 100),
+                                  max(args.warmup, 10), False)
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        base, spec = cpu_baseline(p, tops, args.cpu_seconds)
-        out['cpu_baseline'] = base
-        out['speedup_vs_cpu_mvm'] = mvms / base['value']
+        jobs = {args.config: dict(config=args.config, mvm=True)}
         if 'nll_grad' in out:
-            hint = out['nll_grad']['iterations_mean']
-            cpu = cpu_nll_grad(p, spec, probes, max(int(round(hint)), 1),
-                               args.cpu_seconds)
-            out['cpu_baseline']['nll_grad'] = cpu
-            out['nll_grad']['speedup_vs_cpu_est'] = cpu['est_seconds'] / out['nll_grad']['seconds']
+            it = out['nll_grad']['iterations_mean']
+            small = args.config != 'c5'
+            jobs[args.config].update(
+                nll=True, **({} if small else
+                             dict(iteration_cap=60, iterations_target=it)))
+        if other in out:
+            jobs[other] = dict(config=other, mvm=True, nll='nll_grad' in out[other])
+        cpu = run_cpu_child(jobs, args.cpu_seconds)
+        mine = cpu[args.config]
+        out['cpu_baseline'] = dict(
+            value=mine['mvm']['value'], unit='MVM/s', cores=1, kind='port',
+            sample='%.0f s of single-vector grid MVMs per representation (oracle, NumPy '
+                   'pocketfft, OMP_NUM_THREADS=1, one core); representation=%s; all=%s'
+                   % (mine['mvm']['seconds_per_representation'], mine['mvm']['representation'],
+                      mine['mvm']['all']),
+            cpu_model=cpu['cpu_model'], host_cores=cpu['cores'])
+        out['speedup_vs_cpu_mvm'] = out['value'] / mine['mvm']['value']
+        if 'nll_grad' in mine:
+            out['cpu_baseline']['nll_grad'] = mine['nll_grad']
+            out['nll_grad']['speedup_vs_cpu'] = mine['nll_grad']['seconds'] / out['nll_grad']['seconds']
+            out['nll_grad']['cpu_kind'] = mine['nll_grad']['kind']
+        if other in cpu:
+            o = cpu[other]
+            out[other]['cpu_baseline'] = dict(
+                value=o['mvm']['value'], unit='MVM/s', cores=1, kind='port',
+                sample='as the headline; representation=%s; all=%s'
+                       % (o['mvm']['representation'], o['mvm']['all']))
+            out[other]['speedup_vs_cpu_mvm'] = out[other]['value'] / o['mvm']['value']
+            if 'nll_grad' in o:
+                out[other]['cpu_baseline']['nll_grad'] = o['nll_grad']
+                out[other]['nll_grad']['speedup_vs_cpu'] = \
+                    o['nll_grad']['seconds'] / out[other]['nll_grad']['seconds']
+                out[other]['nll_grad']['cpu_kind'] = o['nll_grad']['kind']
 
     if rank == 0:
         print(json.dumps(out))

@@ -112,11 +112,26 @@ class InterpolatedLLGP:
             raise ValueError('inputs differ in dimension')
         return dims.pop(), len(Ys)
 
+    @staticmethod
+    def _wrap(v, active_dims):
+        """Entries of lo / hi / m that belong to one active-dimension set
+        (interpolated_llgp.py:406-413): a scalar only for a single active
+        dimension, otherwise indexed by the set."""
+        if v is None:
+            return None
+        a = np.asarray(v, dtype=float)
+        if not a.shape:
+            if len(active_dims) != 1:
+                raise ValueError('scalar lo / hi / m needs a single active dimension, got %d'
+                                 % len(active_dims))
+            return a.reshape(1)
+        return a[list(active_dims)]
+
     def _generate_grids(self, lo, hi, m):
-        wrap = lambda v: None if v is None else np.atleast_1d(np.asarray(v, dtype=float))
         for ad in self._functional_kernel.active_dims:
             Xs = [X[:, list(ad)] for X in self.Xs]
-            self.grid_axes[ad] = autogrid(Xs, wrap(lo), wrap(hi), wrap(m))
+            wlo, whi, wm = (self._wrap(v, ad) for v in (lo, hi, m))
+            self.grid_axes[ad] = autogrid(Xs, wlo, whi, wm)
             axes = self.grid_axes[ad]
             # distance of every grid point to grid point 0, shaped like the
             # grid (interpolated_llgp.py:425-432)
