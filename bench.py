@@ -97,6 +97,31 @@ def _pool_solve(rhs):
     return x, ctr[0], time.perf_counter() - t0
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask and the cgroup CPU
+    quota, not os.cpu_count() (a container can see 256 CPUs and be allowed 12)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = float(txt[0])
+                per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def _cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -117,7 +142,7 @@ def cpu_child(spec_json):
     from oracle.kernels import KernelSpec, RBFSpec
     req = json.loads(spec_json)
     out = {}
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     for name, job in req['jobs'].items():
         D, Q, R, m_data, n_probes = synth.CONFIGS[job['config']]
         p = synth.make_problem(D, Q, R, m_data, eps=job.get('eps', 0.1))
@@ -156,9 +181,18 @@ def cpu_child(spec_json):
             probes = np.random.randint(0, 2, (n_probes, p.n)) * 2 - 1
             op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
             _POOL_OP = op
-            _POOL_CAP = int(job.get('iteration_cap', 0))
             rhs = [p.y] + [r.astype(np.float64) for r in probes]
             nproc = min(cores, len(rhs))
+            _POOL_CAP = 0
+            if job.get('bounded'):
+                # bounded sample: about 20 s of wall for the pool -- time two
+                # operator products here, then cap every solve accordingly
+                t0 = time.perf_counter()
+                op.matvec(rhs[0])
+                op.matvec(rhs[1])
+                t_mv = (time.perf_counter() - t0) / 2
+                waves = -(-len(rhs) // nproc)
+                _POOL_CAP = int(min(60, max(4, 20.0 / (waves * t_mv * 1.5))))
             ctx = mp.get_context('fork')
             t0 = time.perf_counter()
             with ctx.Pool(processes=nproc) as pool:
@@ -214,6 +248,7 @@ def cpu_child(spec_json):
         out[name] = res
     out['cpu_model'] = _cpu_model()
     out['cores'] = cores
+    out['cpu_count_reported'] = os.cpu_count()
     print('CPUJSON ' + json.dumps(out), flush=True)
 
 
@@ -471,7 +506,7 @@ def main():
             small = args.config != 'c5'
             jobs[args.config].update(
                 nll=True, **({} if small else
-                             dict(iteration_cap=60, iterations_target=it)))
+                             dict(bounded=True, iterations_target=it)))
         if other in out:
             jobs[other] = dict(config=other, mvm=True, nll='nll_grad' in out[other])
         cpu = run_cpu_child(jobs, args.cpu_seconds)
@@ -482,7 +517,8 @@ def main():
                    'pocketfft, OMP_NUM_THREADS=1, one core); representation=%s; all=%s'
                    % (mine['mvm']['seconds_per_representation'], mine['mvm']['representation'],
                       mine['mvm']['all']),
-            cpu_model=cpu['cpu_model'], host_cores=cpu['cores'])
+            cpu_model=cpu['cpu_model'], host_cores_usable=cpu['cores'],
+            host_cpu_count=cpu['cpu_count_reported'])
         out['speedup_vs_cpu_mvm'] = out['value'] / mine['mvm']['value']
         if 'nll_grad' in mine:
             out['cpu_baseline']['nll_grad'] = mine['nll_grad']

@@ -37,8 +37,31 @@ __device__ long long rl_timing_buf[256];
         if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
             rl_timing_buf[slot] = wall_clock64();                                \
     } while (0)
+// the same for a workgroup in the middle of a launch (steady state: the chip is
+// full and the memory system loaded), chosen by its x / y block index
+#define RL_STAMP_AT(slot, bx, by)                                                \
+    do {                                                                         \
+        if (blockIdx.x == (bx) && blockIdx.y == (by) && blockIdx.z == 0 && threadIdx.x == 0) \
+            rl_timing_buf[slot] = wall_clock64();                                \
+    } while (0)
+// census of concurrently resident workgroups of a launch (slot: current count,
+// slot + 1: the most seen): ENTER first thing in the kernel, LEAVE last
+#define RL_CENSUS_ENTER(slot)                                                    \
+    do {                                                                         \
+        if (threadIdx.x == 0) {                                                  \
+            const long long now = atomicAdd((unsigned long long*)&rl_timing_buf[slot], 1ull) + 1; \
+            atomicMax((unsigned long long*)&rl_timing_buf[(slot) + 1], (unsigned long long)now);   \
+        }                                                                        \
+    } while (0)
+#define RL_CENSUS_LEAVE(slot)                                                    \
+    do {                                                                         \
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&rl_timing_buf[slot], ~0ull); \
+    } while (0)
 #else
 #define RL_STAMP(slot) do { } while (0)
+#define RL_STAMP_AT(slot, bx, by) do { } while (0)
+#define RL_CENSUS_ENTER(slot) do { } while (0)
+#define RL_CENSUS_LEAVE(slot) do { } while (0)
 #endif
 
 struct __attribute__((aligned(16))) cplx {

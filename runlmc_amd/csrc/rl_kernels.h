@@ -235,6 +235,10 @@ struct MixParams {
     const double* facW;   // [nfac]
     const int* facQ;      // [nfac]
     const double* kappa;  // [Q][D]
+    // optional tables of the third-generation row kernel (rl_kernels3.h):
+    // dc [D][L], gs [nfac][L]; NULL = mix from spec / kappa / facW / facQ
+    const double* dc;
+    const double* gs;
 };
 
 // ---------------------------------------------------------------------------

@@ -45,6 +45,18 @@ __device__ __forceinline__ bool xcd_slot(const Tile2& tp, int tiles_per_pair, in
     return *pair < tp.pairs;
 }
 
+// Column-tile index of this workgroup.  Workgroups go to the eight XCDs round
+// robin by linear block id, so with the plain order the column tiles that share
+// a 128-byte line of x / y (a tile of C = 8 real columns is 64 bytes wide) land on
+// different XCDs and the line is fetched once per XCD.  When the tile count is a
+// multiple of 8, XCD k takes the contiguous tiles [k n/8, (k+1) n/8): neighbours
+// hit in that XCD's L2.  (Placement is the dispatcher's observed behaviour; only
+// speed depends on it.)
+__device__ __forceinline__ int xcd_column_tile() {
+    const int n = gridDim.x, b = blockIdx.x;
+    return (n & 7) == 0 && n >= 16 ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
+
 // middle passes (everything but first and last), forward / adjoint
 __device__ __forceinline__ void middle_forward(cplx* tile, const FftPlan& plan, int cols, int ld,
                                                const cplx* tw, int tid, int nthr,
@@ -82,7 +94,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
-    int ct = blockIdx.x, b = blockIdx.y, pair = blockIdx.z;
+    int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
     if (tp.xcd) {
         int t;
         if (!xcd_slot(tp, tp.tilesC * D, &pair, &t)) return;
@@ -228,13 +240,33 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
         for (int i = 0; i < RB; ++i) v[i] = tile[(size_t)(g + i) * C + c];
         SmallDft<RB, false>::run(v);
         const int n2 = c0 + c;
+        if (twl.lo != nullptr) {
+            // inter-step twiddle W_L^{freq1[g + k] n2}.  The last pass puts
+            // frequency f0 + k (N1 / RB) at position g + k, so the RB factors are
+            // W_L^{f0 n2} * (W_L^{(N1 / RB) n2})^k: five table look-ups (base,
+            // step^1,2,4,8) and at most three multiplications per power instead
+            // of RB look-ups of three dependent loads each
+            const int M = N1 / RB;
+            const cplx wb = twiddle_L(twl, freq1[g] * n2);
+            cplx sk[RB];
+            sk[1] = twiddle_L(twl, M * n2);
+            sk[2] = twiddle_L(twl, 2 * M * n2);
+            sk[4] = twiddle_L(twl, 4 * M * n2);
+            sk[3] = c_mul(sk[2], sk[1]);
+            sk[5] = c_mul(sk[4], sk[1]);
+            sk[6] = c_mul(sk[4], sk[2]);
+            sk[7] = c_mul(sk[4], sk[3]);
+            if (RB == 16) {
+                sk[RB / 2] = twiddle_L(twl, (RB / 2) * M * n2);
 #pragma unroll
-        for (int k = 0; k < RB; ++k) {
-            const int r = g + k;
-            cplx z = v[k];
-            if (twl.lo != nullptr) z = c_mul(z, twiddle_L(twl, freq1[r] * n2));
-            out[(size_t)r * N2 + n2] = z;
+                for (int k = RB / 2 + 1; k < RB; ++k) sk[k] = c_mul(sk[RB / 2], sk[k - RB / 2]);
+            }
+            v[0] = c_mul(v[0], wb);
+#pragma unroll
+            for (int k = 1; k < RB; ++k) v[k] = c_mul(v[k], c_mul(wb, sk[k]));
         }
+#pragma unroll
+        for (int k = 0; k < RB; ++k) out[(size_t)(g + k) * N2 + n2] = v[k];
     }
     RL_STAMP(13);
 }
@@ -251,7 +283,7 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
-    int ct = blockIdx.x, b = blockIdx.y, pair = blockIdx.z;
+    int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
     if (tp.xcd) {
         int t;
         if (!xcd_slot(tp, tp.tilesC * D, &pair, &t)) return;

@@ -12,6 +12,7 @@
 
 #include "rl_kernels.h"
 #include "rl_kernels2.h"
+#include "rl_kernels3.h"
 #include "rl_kernels4.h"
 
 // ---------------------------------------------------------------------------
@@ -99,6 +100,26 @@ static FftPlan make_plan(int n) {
         rem /= r;
     }
     return p;
+}
+
+// Row plans of the third-generation row kernel (rl_kernels3.h): N2 = RA * RB * 2
+// with the last radix-2 pass done by the mix threads.  Returns false when the
+// length has no such instantiation.
+static bool make_plan_rows3(int n, FftPlan* p) {
+    int ra, rb;
+    switch (n) {
+        case 128: ra = 8; rb = 8; break;
+        case 256: ra = 16; rb = 8; break;
+        case 512: ra = 16; rb = 16; break;
+        default: return false;
+    }
+    p->n = n;
+    p->npass = 3;
+    for (int i = 0; i < RL_MAX_PASSES; ++i) p->radix[i] = 1;
+    p->radix[0] = ra;
+    p->radix[1] = rb;
+    p->radix[2] = 2;
+    return true;
 }
 
 // code of the fused (register first/last pass) instantiation that runs a
@@ -214,6 +235,10 @@ struct rl_gridop {
     int rowsS = 0;   // rows per k_rows_spec workgroup
     int code1 = 0, code2 = 0;   // fused_code(N1), fused_code(N2); both != 0 -> v2 kernels
     bool v2 = false;
+    bool rows3 = false;         // row kernel = k3_rows_mix (plan2 = {RA, RB, 2})
+    double* mixtab = nullptr;   // dev [D + nfac][L]: dc rows then gs rows (k_mix_tables)
+    size_t mixtab_rows = 0;     // rows allocated
+    bool mixtab_ok = false;     // tables match the current parameters
     int max_tops = 0;
     FftPlan plan1, plan2;
     cplx *tw1 = nullptr, *tw2 = nullptr, *twlo = nullptr, *twhi = nullptr;
@@ -236,11 +261,12 @@ struct rl_gridop {
     // a second chunk of intermediates and a side stream: consecutive chunks of a
     // large batched product run on two streams, so that one chunk's kernels fill
     // the compute units another chunk's tail leaves idle
-    cplx* T2 = nullptr;
+    cplx* T2[3] = {nullptr, nullptr, nullptr};     // workspaces of the side streams
     size_t T2_pairs = 0;
+    int nside = 0;              // side streams prepared (product runs on 1 + nside streams)
     cplx* Tcur = nullptr;       // workspace of the chunk being launched
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     size_t chunk_pairs = 1;
     size_t xcd_pairs = 0;   // pairs per XCD-affine chunk (0: affinity off)
     // single-tile product (k1_product): grids short enough that all D transforms
@@ -298,6 +324,17 @@ static void set_lds_attr_rows() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
 }
+template <int D>
+static void set_lds_attr_rows3() {
+#if !defined(RL_EMU)
+    (void)hipFuncSetAttribute((const void*)k3_rows_mix<D, 8, 8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k3_rows_mix<D, 16, 8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k3_rows_mix<D, 16, 16>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+}
 template <int RA, int RB>
 static void set_lds_attr_cols2() {
 #if !defined(RL_EMU)
@@ -330,6 +367,12 @@ static void set_lds_attrs() {
     set_lds_attr_rows<10>(); set_lds_attr_rows<11>(); set_lds_attr_rows<12>();
     set_lds_attr_rows<13>(); set_lds_attr_rows<14>(); set_lds_attr_rows<15>();
     set_lds_attr_rows<16>();
+    set_lds_attr_rows3<1>();  set_lds_attr_rows3<2>();  set_lds_attr_rows3<3>();
+    set_lds_attr_rows3<4>();  set_lds_attr_rows3<5>();  set_lds_attr_rows3<6>();
+    set_lds_attr_rows3<7>();  set_lds_attr_rows3<8>();  set_lds_attr_rows3<9>();
+    set_lds_attr_rows3<10>(); set_lds_attr_rows3<11>(); set_lds_attr_rows3<12>();
+    set_lds_attr_rows3<13>(); set_lds_attr_rows3<14>(); set_lds_attr_rows3<15>();
+    set_lds_attr_rows3<16>();
 #endif
 }
 
@@ -667,7 +710,15 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     g->plan2 = make_plan(g->N2);
     g->code1 = fused_code(g->plan1);
     g->code2 = fused_code(g->plan2);
-    const bool rows_ok = g->code2 == 808 || g->code2 == 816 || g->code2 == 1616;
+    bool rows_ok = g->code2 == 808 || g->code2 == 816 || g->code2 == 1616;
+    // third-generation row kernel wherever its lengths apply and its unpadded
+    // tile of one row fits (the spectra are built with the same plan below)
+    if (g->code1 != 0 && getenv("RUNLMC_NO_K3") == nullptr &&
+        (size_t)g->N2 * D * sizeof(cplx) <= kLdsHard && make_plan_rows3(g->N2, &g->plan2)) {
+        g->rows3 = true;
+        g->code2 = g->plan2.radix[0] * 100 + g->plan2.radix[1];
+        rows_ok = true;
+    }
     g->v2 = g->code1 != 0 && rows_ok && getenv("RUNLMC_FORCE_V1") == nullptr;
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
@@ -737,12 +788,14 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->spec4, g->tw4A, g->tw4B, g->tw4lo, g->tw4hi, g->untw4, g->freq4A,
-                    g->pos4, g->T2, g->twL, g->spec1, g->S5};
+                    g->pos4, g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->S5, g->mixtab};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
-    if (g->aux) (void)hipStreamDestroy(g->aux);
+    for (int i = 0; i < 3; ++i) {
+        if (g->ev_join[i]) (void)hipEventDestroy(g->ev_join[i]);
+        if (g->aux[i]) (void)hipStreamDestroy(g->aux[i]);
+    }
     delete g;
     return RL_OK;
 }
@@ -787,12 +840,12 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     RL_LAUNCH(k_rows_spec, gridS, dim3(RL_THREADS), lds_rows(g->N2, g->rowsS), stream, g->T,
               g->spec, ntop, g->N1, g->N2, g->rowsS, g->plan2, g->tw2);
     if (g->v1p) {
-        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         RL_TRY(launch1p(g, 1, (unsigned)npairs, stream, g->tops, nullptr, ntop, 1, none,
                         g->spec1));
     }
     if (g->v4 && (g->v4_min < (1 << 30) || g->v5)) {     // only when a path that reads them is on
-        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         RL_TRY(launch4(1, g->ep4, dim3(ntop), dim3(g->thr4), g->lds4, stream, g->tops, nullptr,
                        ntop, g->geo, 1, g->p4, none, g->spec4));
     }
@@ -823,6 +876,24 @@ static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::ve
     }
     RL_HIP(hipMemcpy(g->kappa, kap.data(), kap.size() * sizeof(double), hipMemcpyHostToDevice));
     g->nfac = nfac;
+    // mix tables of the third-generation row kernel (dc: D rows, gs: nfac rows)
+    g->mixtab_ok = false;
+    if (g->rows3 && nfac <= RL_MIXF && getenv("RUNLMC_NO_MIXTAB") == nullptr) {
+        const size_t rows = (size_t)g->D + nfac;
+        if (rows > g->mixtab_rows) {
+            if (g->mixtab) RL_HIP(hipFree(g->mixtab));
+            g->mixtab = nullptr;
+            g->mixtab_rows = 0;
+            RL_HIP(hipMalloc((void**)&g->mixtab, rows * (size_t)g->L * sizeof(double)));
+            g->mixtab_rows = rows;
+        }
+        MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa, nullptr, nullptr};
+        RL_LAUNCH(k_mix_tables, dim3((g->L + 255) / 256, (unsigned)rows), dim3(256), 0,
+                  (hipStream_t) nullptr, mp, g->D, g->L, g->mixtab,
+                  g->mixtab + (size_t)g->D * g->L);
+        RL_HIP(hipGetLastError());
+        g->mixtab_ok = true;
+    }
     return RL_OK;
 }
 
@@ -1011,6 +1082,43 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
             tp->thrC = std::max(64, std::min(RL_THREADS, ((items + 63) / 64) * 64));
         }
     }
+    if (g->rows3) {
+        // unpadded tile of R rows x D outputs; enough rows that pass A hands every
+        // thread of a 256-thread workgroup a butterfly, at most 80 KiB (two
+        // workgroups per CU); more rows only while the launch stays large
+        const int sa = g->N2 / g->plan2.radix[0], nbf = g->N2 / g->plan2.radix[1];
+        auto lds3 = [&](int r) { return (size_t)g->N2 * r * g->D * sizeof(cplx); };
+        R = 1;
+        while (g->N1 % (R * 2) == 0 && R * g->D * sa < RL_THREADS && lds3(2 * R) <= 80 * 1024)
+            R *= 2;
+        while (g->N1 % (R * 2) == 0 && lds3(2 * R) <= 40 * 1024 &&
+               (size_t)(g->N1 / (2 * R)) * pairs >= 2048)
+            R *= 2;
+        if (getenv("RUNLMC_NO_SMALL_TILES") == nullptr)
+            while (R > 1 && (size_t)(g->N1 / R) * pairs < 512) R /= 2;
+        if (const char* e = getenv("RUNLMC_TILE_R")) {
+            const int r = atoi(e);
+            if (r >= 1 && g->N1 % r == 0 && lds3(r) <= kLdsHard) R = r;
+        }
+        tp->R = R;
+        tp->colsMagic = div_magic((unsigned)(R * g->D));
+        // workgroup size: the multiple of 64 that needs the fewest rounds over the
+        // three phases, the smallest such (C5: 10 x 32 butterflies -> 320 threads);
+        // when LDS admits several workgroups per CU, small enough that they also
+        // fit the ~12 waves per CU the kernel's registers allow
+        const int items[3] = {R * g->D * sa, R * g->D * nbf, R * g->N2};
+        const int weight[3] = {4, 4, 1};      // passes A and B run twice; a mix item is light
+        const int wgs = (int)std::min<size_t>(8, (160 * 1024) / lds3(R));
+        const int tmax = wgs >= 2 ? std::max(256, (12 / wgs) * 64) : RL_THREADS3;
+        long bestCost = -1;
+        int bestT = 64;
+        for (int t = 64; t <= tmax; t += 64) {
+            long cost = 0;
+            for (int k = 0; k < 3; ++k) cost += (long)weight[k] * ((items[k] + t - 1) / t);
+            if (bestCost < 0 || cost < bestCost) { bestCost = cost; bestT = t; }
+        }
+        tp->thrR = bestT;
+    }
     // experiment knobs (tile sweeps on the GPU box)
     if (const char* e = getenv("RUNLMC_TILE_C")) {
         const int c = atoi(e);
@@ -1021,7 +1129,7 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
             tp->logC = ilog2(C);
         }
     }
-    if (const char* e = getenv("RUNLMC_TILE_R")) {
+    if (const char* e = g->rows3 ? nullptr : getenv("RUNLMC_TILE_R")) {
         const int r = atoi(e);
         if (r >= 1 && g->N1 % r == 0 && lds(r) <= kLdsHard) {
             R = r;
@@ -1069,9 +1177,42 @@ static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_
     RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->Tcur, tp, g->plan2,
               g->tw2, g->freq1, g->twl, mp, bump);
 }
+// third-generation row kernel: tile = R rows x D outputs, unpadded
+template <int D, int RA, int RB>
+static void launch3_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
+                         const MixParams& mp, int* bump) {
+    dim3 grid(g->N1 / tp.R, (unsigned)pairs);
+    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
+    const size_t lds = (size_t)g->N2 * tp.R * D * sizeof(cplx);
+#if !defined(RL_EMU)
+    {
+        static bool told = false;
+        if (!told && getenv("RUNLMC_TRACE") != nullptr) {
+            told = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, (const void*)k3_rows_mix<D, RA, RB>, tp.thrR, lds);
+            fprintf(stderr, "[runlmc] k3_rows_mix<%d,%d,%d>: R=%d threads=%d lds=%zu grid=%u x %u, "
+                    "occupancy query: %d workgroups per CU\n", D, RA, RB, tp.R, tp.thrR, lds,
+                    grid.x, grid.y, nb);
+        }
+    }
+#endif
+    RL_LAUNCH((k3_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->Tcur, tp, g->tw2,
+              g->freq1, g->twl, mp, bump);
+}
 template <int D>
 static void launch2_rows_code(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                               const MixParams& mp, int* bump) {
+    if (g->rows3) {
+        trace_once("row kernel: k3_rows_mix");
+        switch (g->code2) {
+            case 808: launch3_rows<D, 8, 8>(g, tp, pairs, st, mp, bump); break;
+            case 1608: launch3_rows<D, 16, 8>(g, tp, pairs, st, mp, bump); break;
+            default: launch3_rows<D, 16, 16>(g, tp, pairs, st, mp, bump); break;
+        }
+        return;
+    }
     switch (g->code2) {
         case 808: launch2_rows<D, 8, 8>(g, tp, pairs, st, mp, bump); break;
         case 816: launch2_rows<D, 8, 16>(g, tp, pairs, st, mp, bump); break;
@@ -1147,22 +1288,37 @@ static int mvm_chunk_v1(rl_gridop* g, const MixParams& mp, const double* Xc, dou
 }
 
 // second chunk of intermediates + side stream of the two-stream batched product
+// streams a chunked product runs on (RUNLMC_STREAMS, 1..4; default 2)
+static int product_streams() {
+    static const int n = [] {
+        const char* e = getenv("RUNLMC_STREAMS");
+        return e ? std::min(4, std::max(1, atoi(e))) : 2;
+    }();
+    return n;
+}
 static int prepare_two_streams(rl_gridop* g, size_t chunk) {
-    if (g->T2_pairs < chunk) {
-        if (g->T2) RL_HIP(hipFree(g->T2));
-        g->T2 = nullptr;
+    const int want = product_streams() - 1;
+    if (g->T2_pairs < chunk || g->nside < want) {
+        for (int i = 0; i < 3; ++i) {
+            if (g->T2[i]) RL_HIP(hipFree(g->T2[i]));
+            g->T2[i] = nullptr;
+        }
         g->T2_pairs = 0;
-        RL_HIP(hipMalloc((void**)&g->T2, chunk * g->D * (size_t)g->L * sizeof(cplx)));
+        for (int i = 0; i < want; ++i)
+            RL_HIP(hipMalloc((void**)&g->T2[i], chunk * g->D * (size_t)g->L * sizeof(cplx)));
         g->T2_pairs = chunk;
     }
-    if (!g->aux) {
-        RL_HIP(hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking));
-        RL_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-        RL_HIP(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
-    }
+    if (!g->ev_fork) RL_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < want; ++i)
+        if (!g->aux[i]) {
+            RL_HIP(hipStreamCreateWithFlags(&g->aux[i], hipStreamNonBlocking));
+            RL_HIP(hipEventCreateWithFlags(&g->ev_join[i], hipEventDisableTiming));
+        }
+    g->nside = want;
     return RL_OK;
 }
 static bool wants_two_streams(const rl_gridop* g) {
+    if (product_streams() < 2) return false;
     const char* two_env = getenv("RUNLMC_TWO_STREAMS");
     return two_env ? atoi(two_env) != 0
                    : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
@@ -1252,9 +1408,10 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         // inside a capture nothing may be allocated: the solver prepares the
         // second workspace beforehand (prepare_two_streams) or stays on one
         if (!capturing) RL_TRY(prepare_two_streams(g, chunk));
-        if (g->T2_pairs >= chunk && g->aux != nullptr) {
+        if (g->T2_pairs >= chunk && g->nside > 0) {
             RL_HIP(hipEventRecord(g->ev_fork, stream));
-            RL_HIP(hipStreamWaitEvent(g->aux, g->ev_fork, 0));
+            for (int i = 0; i < g->nside; ++i)
+                RL_HIP(hipStreamWaitEvent(g->aux[i], g->ev_fork, 0));
             two = true;
         }
     }
@@ -1269,9 +1426,9 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
             hipStream_t cst = stream;
             cplx* tb = g->T;
             if (two) {
-                cst = parity ? g->aux : stream;
-                tb = parity ? g->T2 : g->T;
-                parity ^= 1;
+                cst = parity ? g->aux[parity - 1] : stream;
+                tb = parity ? g->T2[parity - 1] : g->T;
+                parity = (parity + 1) % (g->nside + 1);
             }
             RL_TRY(mvm_chunk_v2(g, mp, Xc, Yc, nv, pairs, cst, nullptr, nullptr, tb));
             continue;
@@ -1279,8 +1436,10 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         RL_TRY(mvm_chunk_v1(g, mp, Xc, Yc, nv, pairs, stream));
     }
     if (two) {
-        RL_HIP(hipEventRecord(g->ev_join, g->aux));
-        RL_HIP(hipStreamWaitEvent(stream, g->ev_join, 0));
+        for (int i = 0; i < g->nside; ++i) {
+            RL_HIP(hipEventRecord(g->ev_join[i], g->aux[i]));
+            RL_HIP(hipStreamWaitEvent(stream, g->ev_join[i], 0));
+        }
     }
     RL_HIP(hipGetLastError());
     return RL_OK;
@@ -1288,7 +1447,9 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
 
 extern "C" int rl_gridop_mvm(rl_gridop* g, const double* X, double* Y, int nvec, void* stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
-    MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa};
+    MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa,
+                 g->mixtab_ok ? g->mixtab : nullptr,
+                 g->mixtab_ok ? g->mixtab + (size_t)g->D * g->L : nullptr};
     return mvm_with_mix(g, mp, X, Y, nvec, (hipStream_t)stream);
 }
 
@@ -1296,7 +1457,8 @@ extern "C" int rl_gridop_mvm_top(rl_gridop* g, int q, const double* X, double* Y
                                  void* stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
     if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_mvm_top: q out of range");
-    MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones};
+    MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones, nullptr,
+                 nullptr};
     return mvm_with_mix(g, mp, X, Y, nvec, (hipStream_t)stream);
 }
 
@@ -1981,7 +2143,9 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         gs.n = n;
         gs.nnz = s->nnzWT;
         gs.lo = s->WT_lo;
-        MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa};
+        MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa,
+                     g->mixtab_ok ? g->mixtab : nullptr,
+                     g->mixtab_ok ? g->mixtab + (size_t)g->D * g->L : nullptr};
         if (g->v2)
             RL_TRY(mvm_chunk_v2(g, mp, nullptr, s->G2, nrhs, ((size_t)nrhs + 1) / 2, st, &gs,
                                 mb.giter));

@@ -9,8 +9,8 @@ SIZE here, never by an environment knob.  C2 = D=4, Q=3, m=5000, 16 probes + y.
 
 Reference semantics: runlmc/linalg/bttb.py:144-148, kronecker.py:39-46,
 approx/ski.py:13-16, approx/iterative.py:23-62.  Tolerances: products 1e-11
-relative to max|y| (fp64 FFT roundoff, SURVEY 8c states 1e-10); converged
-MINRES iterates 1e-6 relative (well-conditioned systems).
+relative to max|y| (fp64 FFT roundoff, SURVEY 8c states 1e-10); MINRES iterates
+see CAP below.
 """
 import numpy as np
 import pytest
@@ -19,11 +19,20 @@ import torch
 from oracle import operators as ops
 from oracle import likelihood as olik
 from oracle.kernels import KernelSpec, RBFSpec
-from oracle.solver import iterative_solve
+from oracle.solver import iterative_solve, minres_ps
 
 pytestmark = pytest.mark.gpu
 
 REL = 1e-11
+# Fixed-count MINRES comparisons.  K~ = (fast-decaying RBF spectrum) + noise is
+# numerically rank-revealing: after ~10 Lanczos steps the next vector is
+# determined by roundoff (beta_k at the noise floor), so from there on two
+# correct implementations agree only to the accuracy of the iterate itself
+# (measured on the emulator at C5: 8e-13 after 8 iterations, O(1) after 16).
+# At C2 the floor is reached sooner: 1.2e-9 after 8 iterations on the GPU.
+# The recurrences are therefore compared after CAP iterations at 1e-8 and the
+# converged iterates at the size of the last updates.
+CAP = 6
 
 
 @pytest.fixture(scope='module')
@@ -122,14 +131,25 @@ def test_c5_minres_converged_vs_oracle(native):
     dop = K.device_operator()
     rng = np.random.RandomState(11)
     B = np.vstack([p.y] + [rng.randint(0, 2, p.n) * 2.0 - 1 for _ in range(npr)])
-    X, it, rs, st = solve_batch(dop, torch.from_numpy(B).to(dop.device), tol=1e-4)[:4]
+    Bd = torch.from_numpy(B).to(dop.device)
+    oop = olik.LMCOperatorOracle(_spec(p), p.grid_dists, p.W, p.WT, p.lens)
+    # (a) the same NUMBER of iterations on both sides: iterate parity proper
+    Xc, itc = solve_batch(dop, Bd, tol=1e-4, maxiter=CAP)[:2]
+    Xc = Xc.cpu().numpy()
+    assert np.all(np.array(itc) == CAP)
+    for v in (0, 77):
+        xo, info = minres_ps(oop.matvec, B[v], rtol=1e-10, maxiter=CAP)[:2]
+        assert _rel(Xc[v], xo) < 1e-8, v
+    # (b) run to the reference's stopping rule: same exit, same count (the
+    # rtol = 1e-10 test is crossed at the roundoff floor, so the count may move
+    # by a few iterations and the iterates by the size of the last updates)
+    X, it, rs, st = solve_batch(dop, Bd, tol=1e-4)[:4]
     X = X.cpu().numpy()
     rs, it = np.array(rs), np.array(it)
-    oop = olik.LMCOperatorOracle(_spec(p), p.grid_dists, p.W, p.WT, p.lens)
     for v in (0, 77):
         xo, ito, erro, ok = iterative_solve(oop.matvec, B[v], tol=1e-4)
         assert abs(int(it[v]) - ito) <= max(3, ito // 10), (v, it[v], ito)
-        assert _rel(X[v], xo) < 1e-6, v
+        assert _rel(X[v], xo) < 2e-4, v
         # the reported residual is the true one, through the ORACLE's operator,
         # and as small as the reference's own
         true = np.linalg.norm(B[v] - oop.matvec(X[v]))
@@ -141,7 +161,7 @@ def test_c5_minres_converged_vs_oracle(native):
 def test_c2_converged_alpha_vs_oracle(native):
     """The same at C2 (D=4, Q=3, m=5000, 16 probes + y): converged device
     solves (17 systems: the fused small-system rounds) against the oracle's
-    MINRES iterate at 1e-6."""
+    MINRES iterate (1e-8 after CAP iterations, 2e-4 at the reference's exit)."""
     from runlmc_amd.util import synth
     from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
     from runlmc_amd._native import solve_batch
@@ -154,14 +174,21 @@ def test_c2_converged_alpha_vs_oracle(native):
     dop = K.device_operator()
     rng = np.random.RandomState(12)
     B = np.vstack([p.y] + [rng.randint(0, 2, p.n) * 2.0 - 1 for _ in range(npr)])
-    X, it, rs, st = solve_batch(dop, torch.from_numpy(B).to(dop.device), tol=1e-4)[:4]
+    Bd = torch.from_numpy(B).to(dop.device)
+    oop = olik.LMCOperatorOracle(_spec(p), p.grid_dists, p.W, p.WT, p.lens)
+    Xc, itc = solve_batch(dop, Bd, tol=1e-4, maxiter=CAP)[:2]
+    Xc = Xc.cpu().numpy()
+    assert np.all(np.array(itc) == CAP)
+    for v in (0, 1, 16):
+        xo = minres_ps(oop.matvec, B[v], rtol=1e-10, maxiter=CAP)[0]
+        assert _rel(Xc[v], xo) < 1e-8, v
+    X, it, rs, st = solve_batch(dop, Bd, tol=1e-4)[:4]
     X = X.cpu().numpy()
     rs = np.array(rs)
-    oop = olik.LMCOperatorOracle(_spec(p), p.grid_dists, p.W, p.WT, p.lens)
     for v in (0, 1, 16):
         xo, ito, erro, ok = iterative_solve(oop.matvec, B[v], tol=1e-4)
         assert abs(int(it[v]) - ito) <= max(3, ito // 10), (v, it[v], ito)
-        assert _rel(X[v], xo) < 1e-6, v
+        assert _rel(X[v], xo) < 2e-4, v
         assert rs[v] <= max(1e-4, 1.5 * erro)
 
 
