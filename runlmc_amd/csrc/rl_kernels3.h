@@ -274,6 +274,9 @@ k3_rows_mix(cplx* __restrict__ T, Tile2 tp, const cplx* __restrict__ tw2,
     // final radix-2 pass + mix + its adjoint.  The mix is REAL, so real and
     // imaginary parts are separate work items (adjacent lanes): half the
     // registers per thread and twice the parallelism of a complex item.
+#if defined(RL_TIMING) && !defined(RL_EMU)
+    if (rl_timing_buf[120] != 2)
+#endif
     for (int w = tid; w < R * H * 2; w += nthr) {
         const int part = w & 1, it = w >> 1;
         const int gp = it % H, rr = it / H;
@@ -287,6 +290,9 @@ k3_rows_mix(cplx* __restrict__ T, Tile2 tp, const cplx* __restrict__ tw2,
             s[b] = a0 + a1;
             t[b] = a0 - a1;
         }
+#if defined(RL_TIMING) && !defined(RL_EMU)
+        if (rl_timing_buf[120] != 1)
+#endif
         mix_real2<D>(s, t, mp, L, o);
 #pragma unroll
         for (int b = 0; b < D; ++b) {

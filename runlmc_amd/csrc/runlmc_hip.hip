@@ -749,7 +749,11 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     // intermediates of one chunk: large enough that a launch's tail does not
     // matter, small enough to sit in the 256 MiB Infinity Cache (measured: C2,
     // 1024 vectors 2.17 / 2.31 / 2.50 / 2.24 M MVM/s at 64 / 96 / 192 / 384 MB)
-    size_t chunk_mb = 192;
+    // (re-measured with two streams at C5, 33 MB per pair: 2.93 / 2.97 / 3.10 / 3.08 ms
+    // per 129-vector product at 64 / 96 / 128 / 192 MB -- the working set of both
+    // streams then stays inside the Infinity Cache, which serves re-reads at
+    // ~7 TB/s against ~5.5 from HBM, tools/mall_probe.py)
+    size_t chunk_mb = (size_t)D * L * sizeof(cplx) >= ((size_t)8 << 20) ? 64 : 192;
     if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
     // XCD affinity (experiment knob, OFF by default: measured slower on MI355X --
@@ -2461,6 +2465,12 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
 
 #if defined(RL_TIMING) && !defined(RL_EMU)
 // experiment builds: the phase stamps of the last launches (see rl_device.h)
+extern "C" int rl_debug_poke(int slot, long long value) {
+    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rl_timing_buf), &value, sizeof(long long),
+                             (size_t)slot * sizeof(long long)));
+    return RL_OK;
+}
 extern "C" int rl_debug_timing(long long* out, int count) {
     RL_HIP(hipDeviceSynchronize());
     RL_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rl_timing_buf),

@@ -15,10 +15,14 @@ g = GridOp(D, p.m, Q)
 g.set_lmc(synth.tops(p), list(p.coreg_vecs), list(p.coreg_diags))
 X = torch.randn(nvec, D * p.m, dtype=torch.float64, device=g.device)
 Y = torch.empty_like(X)
+lib = _lib.get_library().cdll
+if os.environ.get('K3_DBG'):
+    lib.rl_debug_poke.argtypes = [ctypes.c_int, ctypes.c_longlong]
+    g.mvm(X, out=Y)
+    assert lib.rl_debug_poke(120, int(os.environ['K3_DBG'])) == 0
 for _ in range(3):
     g.mvm(X, out=Y)
 torch.cuda.synchronize()
-lib = _lib.get_library().cdll
 buf = (ctypes.c_longlong * 128)()
 lib.rl_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.rl_debug_timing(buf, 128) == 0
