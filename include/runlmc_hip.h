@@ -60,15 +60,6 @@ int rl_gridop_create_2d(int device, int D, int m1, int m2, int max_tops, rl_grid
 int rl_gridop_destroy(rl_gridop* g);
 /* L = N1*N2 and tile parameters actually chosen (any pointer may be NULL). */
 int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int* rowsB);
-/* The on-chip product path (whole product of one vector inside one workgroup,
- * no intermediates in HBM): *available != 0 when the grid is short enough for
- * it; it is taken for batches of at least *min_batch vectors
- * (RUNLMC_V4_MIN overrides, RUNLMC_NO_V4 disables).  L/4 = Na x Nb is the
- * in-LDS split, slots the frequency pairs per thread, threads the workgroup
- * size (any pointer may be NULL).                                             */
-int rl_gridop_onchip_info(const rl_gridop* g, int* available, int* min_batch, int* Na, int* Nb,
-                          int* slots, int* threads);
-
 /* Parameters of the LMC kernel, in the reference's own factored form
  * B_q = A_q^T A_q + diag(kappa_q) (runlmc/lmc/functional_kernel.py:280-287):
  *   tops        host [Q][m]   first rows k_q(grid distances)

@@ -32,7 +32,6 @@ _SIGNATURES = {
     'rl_gridop_create_2d': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
     'rl_gridop_destroy': [_vp],
     'rl_gridop_info': [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p],
-    'rl_gridop_onchip_info': [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p],
     'rl_gridop_set_lmc': [_vp, _i, _vp, _vp, _vp, _vp],
     'rl_gridop_set_dense': [_vp, _i, _vp, _vp],
     'rl_gridop_mvm': [_vp, _vp, _vp, _i, _vp],

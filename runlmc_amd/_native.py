@@ -58,10 +58,6 @@ class GridOp:
         info = [ctypes.c_int() for _ in range(5)]
         self.lib.call('rl_gridop_info', self._h, *[ctypes.byref(i) for i in info])
         self.L, self.N1, self.N2, self.colsA, self.rowsB = [i.value for i in info]
-        oc = [ctypes.c_int() for _ in range(6)]
-        self.lib.call('rl_gridop_onchip_info', self._h, *[ctypes.byref(i) for i in oc])
-        #: the on-chip product path: (available, min_batch, Na, Nb, slots, threads)
-        self.onchip = tuple(i.value for i in oc)
         self.Q = 0
 
     def __del__(self):

@@ -23,27 +23,8 @@ struct Tile2 {
     int C, logC;        // columns per k2_cols_* workgroup (power of two)
     int R;              // rows per k2_rows_mix workgroup (power of two)
     unsigned colsMagic; // fast_div magic of R * D
-    // XCD-affine launch: 1-D grid; block id -> (XCD = id % 8, slot = id / 8);
-    // all workgroups that touch one vector pair's intermediates run on one XCD
-    // so that T is re-read from that XCD's L2 by the next kernel.  Placement is
-    // the dispatcher's observed round-robin; only speed depends on it.
-    int xcd;            // 0: plain 3-D / 2-D grids
-    int pairs;          // pairs in this launch (xcd mode)
-    int tilesC;         // column tiles per (pair, output)
-    int tilesR;         // row tiles per pair
     int thrC, thrR;     // workgroup sizes of the column / row kernels
 };
-
-// (pair, tile-within-pair) of this workgroup; false if it is launch padding
-__device__ __forceinline__ bool xcd_slot(const Tile2& tp, int tiles_per_pair, int* pair,
-                                         int* tile) {
-    const int id = blockIdx.x;
-    const int slot = id >> 3;
-    const int q = slot / tiles_per_pair;
-    *tile = slot - q * tiles_per_pair;
-    *pair = (id & 7) + 8 * q;
-    return *pair < tp.pairs;
-}
 
 // Column-tile index of this workgroup.  Workgroups go to the eight XCDs round
 // robin by linear block id, so with the plain order the column tiles that share
@@ -94,13 +75,7 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
-    int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
-    if (tp.xcd) {
-        int t;
-        if (!xcd_slot(tp, tp.tilesC * D, &pair, &t)) return;
-        b = t / tp.tilesC;
-        ct = t - b * tp.tilesC;
-    }
+    const int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
     const int c0 = ct * C;
     const int L = N1 * N2;
     const int m = geo.m;
@@ -283,13 +258,7 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
-    int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
-    if (tp.xcd) {
-        int t;
-        if (!xcd_slot(tp, tp.tilesC * D, &pair, &t)) return;
-        b = t / tp.tilesC;
-        ct = t - b * tp.tilesC;
-    }
+    const int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
     const int c0 = ct * C;
     const size_t L = (size_t)N1 * N2;
     const cplx* in = T + ((size_t)pair * D + b) * L;
@@ -396,8 +365,7 @@ k2_rows_mix(cplx* __restrict__ T, Tile2 tp, FftPlan plan2, const cplx* __restric
     const int N1 = tp.N1, N2 = tp.N2, R = tp.R;
     const int cols = R * D;
     const int ld = cols | 1;
-    int rt = blockIdx.x, pair = blockIdx.y;
-    if (tp.xcd && !xcd_slot(tp, tp.tilesR, &pair, &rt)) return;
+    const int rt = blockIdx.x, pair = blockIdx.y;
     const int r0 = rt * R;
     const size_t L = (size_t)N1 * N2;
     cplx* base = T + (size_t)pair * D * L;

@@ -227,8 +227,7 @@ k3_rows_mix(cplx* __restrict__ T, Tile2 tp, const cplx* __restrict__ tw2,
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, R = tp.R;
     const int cols = R * D;
-    int rt = blockIdx.x, pair = blockIdx.y;
-    if (tp.xcd && !xcd_slot(tp, tp.tilesR, &pair, &rt)) return;
+    const int rt = blockIdx.x, pair = blockIdx.y;
     const int r0 = rt * R;
     const size_t L = (size_t)N1 * N2;
     cplx* base = T + (size_t)pair * D * L;

@@ -13,7 +13,6 @@
 #include "rl_kernels.h"
 #include "rl_kernels2.h"
 #include "rl_kernels3.h"
-#include "rl_kernels4.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -268,7 +267,6 @@ struct rl_gridop {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     size_t chunk_pairs = 1;
-    size_t xcd_pairs = 0;   // pairs per XCD-affine chunk (0: affinity off)
     // single-tile product (k1_product): grids short enough that all D transforms
     // of a pair fit one LDS tile
     bool v1p = false;
@@ -278,20 +276,6 @@ struct rl_gridop {
     size_t lds1 = 0;
     int thr1 = 256;
     int v1p_min = 64;          // vectors from which the single-tile product is used
-    // on-chip product (rl_kernels4.h): available for short 1-D grids, used for
-    // batches of at least v4_min vectors
-    bool v4 = false;
-    Plan4 p4;
-    int ep4 = 0, thr4 = 0, v4_min = 0, cus4 = 1;
-    size_t lds4 = 0;
-    double* spec4 = nullptr;   // dev [max_tops][2H + 1] (rl_kernels4.h)
-    // two-kernel form of the same scheme for small batches (k5_forward / k5_inverse)
-    bool v5 = false;
-    int v5_max = 0;            // largest batch it is used for
-    cplx* S5 = nullptr;        // half spectra in flight [nvec][2][D][2 EP][thr4]
-    size_t S5_cap = 0;         // vectors
-    cplx *tw4A = nullptr, *tw4B = nullptr, *tw4lo = nullptr, *tw4hi = nullptr, *untw4 = nullptr;
-    int *freq4A = nullptr, *pos4 = nullptr;
 };
 
 static size_t lds_cols(const rl_gridop* g) {
@@ -379,115 +363,6 @@ static void set_lds_attrs() {
 
 static unsigned div_magic(unsigned d);
 
-// ---------------------------------------------------------------------------
-// on-chip product plan (rl_kernels4.h): N = L / 2 = Na x Nb inside LDS
-// ---------------------------------------------------------------------------
-template <int D, int EP>
-static void set_lds_attr4() {
-#if !defined(RL_EMU)
-    (void)hipFuncSetAttribute((const void*)k4_product<D, EP>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#endif
-}
-
-// the (D, EP) instantiations: 8 * D * EP VGPRs hold the half spectra
-#define RL_V4_MAX_DEP 12
-#define RL_V4_MAX_D 6
-#define RL_V4_MAX_EP 3
-#define RL_V4_FOR_EP(M, d)                                                     \
-    if constexpr (d <= RL_V4_MAX_D) { M(d, 1) }                                \
-    if constexpr (d <= RL_V4_MAX_D && d * 2 <= RL_V4_MAX_DEP) { M(d, 2) }      \
-    if constexpr (d <= RL_V4_MAX_D && d * 3 <= RL_V4_MAX_DEP) { M(d, 3) }
-
-template <int D>
-static int launch4_d(int ep, dim3 grid, dim3 block, size_t lds, hipStream_t st, const double* X,
-                     double* Y, int nvec, const Geom& geo, int mode, const Plan4& pl,
-                     const MixParams& mp, double* spec_out) {
-#define RL_M(d, e)                                                                       \
-    if (ep == e) {                                                                       \
-        set_lds_attr4<d, e>();                                                           \
-        RL_LAUNCH((k4_product<d, e>), grid, block, lds, st, X, Y, nvec, geo, mode, pl,   \
-                  mp, spec_out);                                                         \
-        return RL_OK;                                                                    \
-    }
-    RL_V4_FOR_EP(RL_M, D)
-#undef RL_M
-    return fail(RL_ELIMIT, "on-chip product: no instantiation");
-}
-
-static int launch4(int D, int ep, dim3 grid, dim3 block, size_t lds, hipStream_t st,
-                   const double* X, double* Y, int nvec, const Geom& geo, int mode,
-                   const Plan4& pl, const MixParams& mp, double* spec_out) {
-    switch (D) {
-#define RL_CASE(d) \
-    case d: return launch4_d<d>(ep, grid, block, lds, st, X, Y, nvec, geo, mode, pl, mp, spec_out);
-        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6) RL_CASE(7)
-        RL_CASE(8) RL_CASE(9) RL_CASE(10) RL_CASE(11) RL_CASE(12) RL_CASE(13)
-        RL_CASE(14) RL_CASE(15) RL_CASE(16)
-#undef RL_CASE
-        default: return fail(RL_ELIMIT, "unsupported D");
-    }
-}
-
-template <int D>
-static int launch5_d(rl_gridop* g, hipStream_t st, const double* X, double* Y, int nvec,
-                     const MixParams& mp) {
-    const dim3 block(g->thr4);
-#define RL_M(d, e)                                                                          \
-    if (g->ep4 == e) {                                                                      \
-        static bool attr = false;                                                           \
-        if (!attr) {                                                                        \
-            attr = true;                                                                    \
-            (void)hipFuncSetAttribute((const void*)k5_forward<e>,                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            (void)hipFuncSetAttribute((const void*)k5_inverse<d, e>,                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        }                                                                                   \
-        RL_LAUNCH((k5_forward<e>), dim3(d, nvec, 2), block, g->lds4, st, X, (int)d, g->geo, \
-                  g->p4, g->S5);                                                            \
-        RL_LAUNCH((k5_inverse<d, e>), dim3(d, nvec), block, g->lds4, st,                    \
-                  (const cplx*)g->S5, Y, g->geo, g->p4, mp);                                \
-        return RL_OK;                                                                       \
-    }
-    RL_V4_FOR_EP(RL_M, D)
-#undef RL_M
-    return fail(RL_ELIMIT, "two-kernel on-chip product: no instantiation");
-}
-
-static int launch5(rl_gridop* g, hipStream_t st, const double* X, double* Y, int nvec,
-                   const MixParams& mp) {
-    switch (g->D) {
-#define RL_CASE(d) case d: return launch5_d<d>(g, st, X, Y, nvec, mp);
-        RL_CASE(1) RL_CASE(2) RL_CASE(3) RL_CASE(4) RL_CASE(5) RL_CASE(6)
-#undef RL_CASE
-        default: return fail(RL_ELIMIT, "unsupported D");
-    }
-}
-
-// radix schedule for the on-chip product: odd factors first, then the power of
-// two in as few passes of radix <= 8 as possible, no radix 2 unless forced
-static FftPlan make_plan4(int n) {
-    FftPlan p;
-    p.n = n;
-    p.npass = 0;
-    for (int i = 0; i < RL_MAX_PASSES; ++i) p.radix[i] = 1;
-    int rem = n;
-    for (int odd : {3, 5})
-        while (rem % odd == 0 && p.npass < 2) {
-            p.radix[p.npass++] = odd;
-            rem /= odd;
-        }
-    const int l = ilog2(rem);
-    if (l == 1) {
-        p.radix[p.npass++] = 2;
-    } else if (l > 1) {
-        const int np = (l + 2) / 3;
-        int extra = 3 * np - l;          // passes that are radix 4 instead of 8
-        for (int i = 0; i < np; ++i) p.radix[p.npass++] = (i >= np - extra) ? 4 : 8;
-    }
-    return p;
-}
-
 // single-tile product (k1_product<D>)
 template <int D>
 static void launch1p_d(rl_gridop* g, unsigned pairs, hipStream_t st, const double* X, double* Y,
@@ -515,100 +390,6 @@ static int launch1p(rl_gridop* g, int D, unsigned pairs, hipStream_t st, const d
 #undef RL_CASE
         default: return fail(RL_ELIMIT, "unsupported D");
     }
-}
-
-static int plan4_create(rl_gridop* g) {
-    g->v4 = false;
-    if (g->geo.m1 != 0 || (g->L & 7) || g->D > RL_V4_MAX_D || getenv("RUNLMC_NO_V4"))
-        return RL_OK;
-    const int H = g->L / 4, pairs = H / 2 + 1;
-    if (H < 32) return RL_OK;
-    // smallest workgroup whose threads can hold the half spectra
-    int thr = 64, ep = 0;
-    for (; thr <= RL_THREADS4; thr *= 2) {
-        ep = (pairs + thr - 1) / thr;
-        if (ep <= RL_V4_MAX_EP && g->D * ep <= RL_V4_MAX_DEP) break;
-    }
-    if (thr > RL_THREADS4) return RL_OK;
-    // split with the cheapest pass schedule: sum over passes of
-    // (rounds of butterflies per thread) x (cost of one butterfly)
-    auto bf_cost = [](int r) {
-        switch (r) { case 2: return 10; case 3: return 30; case 4: return 34; case 5: return 74;
-                     case 8: return 106; default: return 260; }
-    };
-    int bestNb = 0;
-    long bestCost = 0;
-    for (int nb = 4; nb <= 512 && nb * 2 <= H; nb *= 2) {
-        if (H % nb) break;
-        const int na = H / nb;
-        if ((size_t)na * (nb | 1) * sizeof(cplx) > kLdsHard) continue;
-        const FftPlan pa = make_plan4(na), pb = make_plan4(nb);
-        long cost = 0;
-        for (int s = 0; s < pa.npass; ++s)
-            cost += (long)(((na / pa.radix[s]) * nb + thr - 1) / thr) * bf_cost(pa.radix[s]) + 40;
-        for (int s = 0; s < pb.npass; ++s)
-            cost += (long)(((nb / pb.radix[s]) * na + thr - 1) / thr) * bf_cost(pb.radix[s]) + 40;
-        if (bestNb == 0 || cost < bestCost) { bestNb = nb; bestCost = cost; }
-    }
-    if (!bestNb) return RL_OK;
-    Plan4& pl = g->p4;
-    pl.N = H;
-    pl.Nb = bestNb;
-    pl.Na = H / bestNb;
-    pl.ld = pl.Nb | 1;
-    pl.planA = make_plan4(pl.Na);
-    pl.planB = make_plan4(pl.Nb);
-    pl.magicNa = div_magic((unsigned)pl.Na);
-    pl.magicNb = div_magic((unsigned)pl.Nb);
-    const std::vector<int> fa = position_to_freq(pl.planA), fb = position_to_freq(pl.planB);
-    std::vector<int> inva(pl.Na), invb(pl.Nb), pos(H);
-    for (int r = 0; r < pl.Na; ++r) inva[fa[r]] = r;
-    for (int c = 0; c < pl.Nb; ++c) invb[fb[c]] = c;
-    for (int k = 0; k < H; ++k) pos[k] = inva[k % pl.Na] * pl.ld + invb[k / pl.Na];
-    int rc;
-    if ((rc = upload(&g->tw4A, unity_table(pl.Na, 1, pl.Na))) != RL_OK) return rc;
-    if ((rc = upload(&g->tw4B, unity_table(pl.Nb, 1, pl.Nb))) != RL_OK) return rc;
-    const int shift = ilog2(H) / 2;
-    pl.nlo = 1 << shift;
-    pl.nhi = (int)(((long)H + (1L << shift) - 1) >> shift);
-    if ((rc = upload(&g->tw4lo, unity_table(pl.nlo, 1, H))) != RL_OK) return rc;
-    if ((rc = upload(&g->tw4hi, unity_table(pl.nhi, 1L << shift, H))) != RL_OK) return rc;
-    if ((rc = upload(&g->untw4, unity_table(H + 1, 1, g->L))) != RL_OK) return rc;
-    if ((rc = upload(&g->freq4A, fa)) != RL_OK) return rc;
-    if ((rc = upload(&g->pos4, pos)) != RL_OK) return rc;
-    RL_HIP(hipMalloc((void**)&g->spec4, (size_t)g->max_tops * (2 * H + 1) * sizeof(double)));
-    pl.twA = g->tw4A;
-    pl.twB = g->tw4B;
-    pl.freqA = g->freq4A;
-    pl.twN.lo = g->tw4lo;
-    pl.twN.hi = g->tw4hi;
-    pl.twN.shift = shift;
-    pl.twN.mask = (1 << shift) - 1;
-    pl.pos = g->pos4;
-    pl.wl = g->untw4;
-    g->ep4 = ep;
-    g->thr4 = thr;
-    g->lds4 = plan4_lds_bytes(pl);
-    if (g->lds4 > kLdsHard) return RL_OK;
-    {
-        hipDeviceProp_t prop;
-        RL_HIP(hipGetDeviceProperties(&prop, g->device));
-        g->cus4 = std::max(1, prop.multiProcessorCount);
-    }
-    // OFF unless asked for (RUNLMC_V4_MIN=<batch>): measured on MI355X at C2 it
-    // sustains 1.5 M MVM/s against 2.5 M for the three-kernel path -- it issues
-    // 124 k VALU wave-instructions per vector (real-input untangling, two
-    // phases, radix <= 8) against 60 k, at two waves per SIMD
-    g->v4_min = 1 << 30;
-    if (const char* e = getenv("RUNLMC_V4_MIN")) g->v4_min = std::max(1, atoi(e));
-    g->v4 = true;
-    // two-kernel small-batch form: opt-in (RUNLMC_V5_MAX=<largest batch>)
-    g->v5 = false;
-    if (const char* e = getenv("RUNLMC_V5_MAX")) {
-        g->v5_max = atoi(e);
-        g->v5 = g->v5_max > 0;
-    }
-    return RL_OK;
 }
 
 #define RL_MAX_D 16
@@ -756,19 +537,6 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     size_t chunk_mb = (size_t)D * L * sizeof(cplx) >= ((size_t)8 << 20) ? 64 : 192;
     if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
-    // XCD affinity (experiment knob, OFF by default: measured slower on MI355X --
-    // 1.30 vs 1.65 M MVM/s at C2, batch 1024 -- because the small chunks it
-    // needs cost more than the L2 re-reads save): a pair's intermediates
-    // (D*L*16 B) would have to sit in one XCD's 4 MiB L2
-    {
-        double l2_mb = 0.0;
-        if (const char* e = getenv("RUNLMC_XCD_L2_MB")) l2_mb = atof(e);
-        const size_t per_pair = (size_t)D * L * sizeof(cplx);
-        const size_t ppx = (size_t)(l2_mb * 1048576.0) / per_pair;
-        g->xcd_pairs = ppx >= 1 ? 8 * ppx : 0;
-    }
-
-    if ((rc = plan4_create(g)) != RL_OK) return rc;
     // single-tile product for short grids
     if (m1 == 0 && L <= 2048 && getenv("RUNLMC_NO_V1P") == nullptr) {
         const size_t lds = ((size_t)L * (D | 1) + L) * sizeof(cplx);
@@ -791,8 +559,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     (void)hipSetDevice(g->device);
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
-                    g->spec4, g->tw4A, g->tw4B, g->tw4lo, g->tw4hi, g->untw4, g->freq4A,
-                    g->pos4, g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->S5, g->mixtab};
+                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -812,18 +579,6 @@ extern "C" int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int*
     if (N2) *N2 = g->N2;
     if (colsA) *colsA = g->colsA;
     if (rowsB) *rowsB = g->rowsB;
-    return RL_OK;
-}
-
-extern "C" int rl_gridop_onchip_info(const rl_gridop* g, int* available, int* min_batch, int* Na,
-                                     int* Nb, int* slots, int* threads) {
-    if (!g) return fail(RL_EINVAL, "gridop is NULL");
-    if (available) *available = g->v4 ? 1 : 0;
-    if (min_batch) *min_batch = g->v4_min;
-    if (Na) *Na = g->v4 ? g->p4.Na : 0;
-    if (Nb) *Nb = g->v4 ? g->p4.Nb : 0;
-    if (slots) *slots = g->ep4;
-    if (threads) *threads = g->thr4;
     return RL_OK;
 }
 
@@ -847,11 +602,6 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
         MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         RL_TRY(launch1p(g, 1, (unsigned)npairs, stream, g->tops, nullptr, ntop, 1, none,
                         g->spec1));
-    }
-    if (g->v4 && (g->v4_min < (1 << 30) || g->v5)) {     // only when a path that reads them is on
-        MixParams none{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        RL_TRY(launch4(1, g->ep4, dim3(ntop), dim3(g->thr4), g->lds4, stream, g->tops, nullptr,
-                       ntop, g->geo, 1, g->p4, none, g->spec4));
     }
     RL_HIP(hipGetLastError());
     return RL_OK;
@@ -1143,17 +893,12 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
     }
     if (const char* e = getenv("RUNLMC_THR_C")) tp->thrC = std::min(RL_THREADS2, std::max(64, atoi(e)));
     if (const char* e = getenv("RUNLMC_THR_R")) tp->thrR = std::min(RL_THREADS2, std::max(64, atoi(e)));
-    tp->pairs = (int)pairs;
-    tp->tilesC = g->N2 / C;
-    tp->tilesR = g->N1 / R;
-    tp->xcd = (g->xcd_pairs > 0 && pairs >= 16) ? 1 : 0;
 }
 
 template <int RA, int RB>
 static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                              const double* X, int nv, int D, int mode, const Gather& gs) {
     dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
-    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * D));
     if (gs.indptr != nullptr)
         RL_LAUNCH((k2_cols_fwd<RA, RB, true>), grid, dim3(tp.thrC),
                   (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->Tcur, tp,
@@ -1168,7 +913,6 @@ static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
                              double* Y, int nv) {
     const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
     dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
-    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesC * g->D));
     RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
               st, g->Tcur, Y, nv, g->D, g->geo, tp, g->plan1, g->tw1);
 }
@@ -1176,7 +920,6 @@ template <int D, int RA, int RB>
 static void launch2_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                          const MixParams& mp, int* bump) {
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
-    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
     const size_t lds = (size_t)g->N2 * ((tp.R * D) | 1) * sizeof(cplx);
     RL_LAUNCH((k2_rows_mix<D, RA, RB>), grid, dim3(tp.thrR), lds, st, g->Tcur, tp, g->plan2,
               g->tw2, g->freq1, g->twl, mp, bump);
@@ -1186,7 +929,6 @@ template <int D, int RA, int RB>
 static void launch3_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                          const MixParams& mp, int* bump) {
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
-    if (tp.xcd) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * tp.tilesR));
     const size_t lds = (size_t)g->N2 * tp.R * D * sizeof(cplx);
 #if !defined(RL_EMU)
     {
@@ -1351,51 +1093,8 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
         RL_HIP(hipGetLastError());
         return RL_OK;
     }
-    if (g->v4 && g->v5 && nvec <= g->v5_max) {
-        // small batch: one workgroup per (vector, output) transform, two kernels
-        bool ok = g->S5_cap >= (size_t)nvec;
-        if (!ok) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            const bool capturing = stream != nullptr &&
-                                   hipStreamIsCapturing(stream, &cs) == hipSuccess &&
-                                   cs != hipStreamCaptureStatusNone;
-            if (!capturing) {       // (nothing may be allocated inside a capture)
-                if (g->S5) RL_HIP(hipFree(g->S5));
-                g->S5 = nullptr;
-                g->S5_cap = 0;
-                const size_t cap = std::max<size_t>((size_t)nvec, 32);
-                RL_HIP(hipMalloc((void**)&g->S5, cap * 2 * g->D * 2 * g->ep4 * g->thr4 *
-                                                     sizeof(cplx)));
-                g->S5_cap = cap;
-                ok = true;
-            }
-        }
-        if (ok) {
-            trace_once("grid product: k5_forward + k5_inverse (on chip, two kernels)");
-            MixParams mp4 = mp;
-            mp4.spec = g->spec4 + (size_t)((mp.spec - g->spec) / g->L) * (2 * g->p4.N + 1);
-            RL_TRY(launch5(g, stream, X, Y, nvec, mp4));
-            RL_HIP(hipGetLastError());
-            return RL_OK;
-        }
-    }
-    if (g->v4 && nvec >= g->v4_min) {
-        // the whole product on chip, one workgroup per vector
-        trace_once("grid product: k4_product (on chip)");
-        MixParams mp4 = mp;
-        mp4.spec = g->spec4 + (size_t)((mp.spec - g->spec) / g->L) * (2 * g->p4.N + 1);
-        // persistent workgroups: as many as can be resident, each walks vectors
-        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(kLdsHard / g->lds4,
-                                                                    2048 / (4 * g->thr4)));
-        const unsigned nwg = (unsigned)std::min<size_t>((size_t)nvec, per_cu * g->cus4);
-        RL_TRY(launch4(g->D, g->ep4, dim3(nwg), dim3(g->thr4), g->lds4, stream, X, Y, nvec,
-                       g->geo, 0, g->p4, mp4, nullptr));
-        RL_HIP(hipGetLastError());
-        return RL_OK;
-    }
     const size_t total_pairs = ((size_t)nvec + 1) / 2;
     size_t chunk = std::min(total_pairs, g->chunk_pairs);
-    if (g->v2 && g->xcd_pairs > 0 && total_pairs >= 16) chunk = std::min(chunk, g->xcd_pairs);
     RL_TRY(ensure_workspace(g, chunk));
     const size_t vec_len = (size_t)g->D * g->m;
     // two streams for a product of several chunks
@@ -2305,7 +2004,6 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         const bool short_rows = (size_t)s->nnzWT <= (size_t)8 * s->ngrid;
         const bool fuse_wt = fuse_w && short_rows && s->g->Q >= 1 &&
                              ((size_t)nrhs + 1) / 2 <= s->g->chunk_pairs &&
-                             !(s->g->v4 && nrhs >= s->g->v4_min) &&
                              getenv("RUNLMC_NO_FUSE_WT") == nullptr;
         mb.fuse_wt = fuse_wt ? 1 : 0;
         mb.W_indices = s->W_indices;

@@ -145,167 +145,3 @@ def grid_mvm_model(tops, facA, facW, facQ, kappa, X, L, N1, N2,
             if p + 1 < nvec:
                 Y[p + 1, a] = y[:m].imag
     return Y
-
-
-# ---------------------------------------------------------------------------
-# On-chip scheme (k4_product): ONE real vector per workgroup, the length-L real
-# transform done as an N = L/2 point complex transform of z[n] = x[2n] + i x[2n+1]
-# (itself split Na x Nb inside LDS), untangled pairwise (k, N-k) into the
-# half spectrum k = 0..N, mixed, re-tangled and transformed back.
-# ---------------------------------------------------------------------------
-def onchip_positions(Na, Nb, planA, planB):
-    """pos[k] = (row, col) of frequency k of the N-point transform after
-    four_step_forward(., Na, Nb): k = kA(row) + Na * kB(col)."""
-    fa = position_to_freq(Na, planA)
-    fb = position_to_freq(Nb, planB)
-    inva = np.argsort(fa)
-    invb = np.argsort(fb)
-    k = np.arange(Na * Nb)
-    return inva[k % Na], invb[k // Na]
-
-
-def onchip_untangle(S, Na, Nb, planA, planB, L):
-    """S: scrambled N-point spectrum (Na, Nb) of the packed sequence.  Returns
-    (c, X2lo, X2hi): for every pair slot c in [0, N/2], twice the real
-    sequence's spectrum at k = c and at k = N - c."""
-    N = Na * Nb
-    r, cpos = onchip_positions(Na, Nb, planA, planB)
-    c = np.arange(N // 2 + 1)
-    A = S[r[c], cpos[c]]
-    B = S[r[(N - c) % N], cpos[(N - c) % N]]
-    w = np.exp(-2j * np.pi * c / L)
-    P = A + np.conj(B)
-    Qd = 1j * w * (A - np.conj(B))
-    return c, P - Qd, np.conj(P + Qd)
-
-
-def onchip_retangle(Ulo, Uhi, Na, Nb, planA, planB, L):
-    """Inverse of the untangle for a Hermitian product spectrum: values at
-    k = c (Ulo) and k = N - c (Uhi) -> scrambled N-point array (Na, Nb)."""
-    N = Na * Nb
-    r, cpos = onchip_positions(Na, Nb, planA, planB)
-    c = np.arange(N // 2 + 1)
-    w = np.exp(-2j * np.pi * c / L)
-    P = Ulo + np.conj(Uhi)
-    Qd = 1j * np.conj(w) * (Ulo - np.conj(Uhi))
-    S = np.zeros((Na, Nb), dtype=np.complex128)
-    S[r[c], cpos[c]] = P + Qd
-    S[r[(N - c) % N], cpos[(N - c) % N]] = np.conj(P - Qd)
-    return S
-
-
-def onchip_grid_mvm_model(tops, facA, facW, facQ, kappa, X, L, Na, Nb, planA, planB):
-    """K_UU X for X (nvec, D, m), one real vector at a time (see above)."""
-    nvec, D, m = X.shape
-    Q = len(tops)
-    N = L // 2
-    assert Na * Nb == N
-
-    def half_spectrum2(x_real_L):
-        z = x_real_L[0::2] + 1j * x_real_L[1::2]
-        S = four_step_forward(z, Na, Nb, planA, planB)
-        return onchip_untangle(S, Na, Nb, planA, planB, L)
-
-    # spectra at k = c and k = N - c, scaled so that the unnormalised adjoint
-    # returns the product: t_hat / (2 L)
-    slo = np.zeros((Q, N // 2 + 1))
-    shi = np.zeros((Q, N // 2 + 1))
-    for q in range(Q):
-        _, lo, hi = half_spectrum2(circulant_column(tops[q], L))
-        assert np.abs(lo.imag).max() < 1e-9 * (1 + np.abs(lo).max())
-        slo[q], shi[q] = lo.real / (4 * L), hi.real / (4 * L)
-    Y = np.zeros_like(X)
-    for v in range(nvec):
-        Xlo = np.zeros((D, N // 2 + 1), dtype=np.complex128)
-        Xhi = np.zeros_like(Xlo)
-        for b in range(D):
-            xp = np.zeros(L)
-            xp[:m] = X[v, b]
-            _, Xlo[b], Xhi[b] = half_spectrum2(xp)
-        out = []
-        for Z, s in ((Xlo, slo), (Xhi, shi)):
-            Yh = np.einsum('qd,qk->dk', kappa, s) * Z
-            for f in range(len(facW)):
-                t = np.einsum('b,bk->k', facA[f], Z) * (facW[f] * s[facQ[f]])
-                Yh += facA[f][:, None] * t[None]
-            out.append(Yh)
-        for a in range(D):
-            S = onchip_retangle(out[0][a], out[1][a], Na, Nb, planA, planB, L)
-            z = four_step_adjoint(S, Na, Nb, planA, planB)
-            y = np.zeros(L)
-            y[0::2], y[1::2] = z.real, z.imag
-            Y[v, a] = y[:m]
-    return Y
-
-
-# ---------------------------------------------------------------------------
-# Two-phase on-chip scheme (what k4_product actually runs): the length-L real
-# transform of a sequence whose second half is zero padding, split by parity of
-# the frequency.  With N = L/2, H = N/2:
-#   even k = 2k':  the length-N real transform of x[0:N]  -> H-point complex
-#                  transform of x[2n] + i x[2n+1] + pairwise untangle
-#   odd  k = 4j+1: the H-point complex transform of (x[n] - i x[n+H]) W_L^n
-#                  (k = 4j+3 are the conjugates of mirrored ones: never formed)
-# Each phase keeps D * H complex values on chip; the result is the sum.
-# ---------------------------------------------------------------------------
-def twophase_grid_mvm_model(tops, facA, facW, facQ, kappa, X, L, Ha, Hb, planA, planB):
-    nvec, D, m = X.shape
-    Q = len(tops)
-    N = L // 2
-    H = N // 2
-    assert Ha * Hb == H and m <= N
-    n = np.arange(H)
-    wL = np.exp(-2j * np.pi * n / L)
-
-    def mix(Z, s):                       # Z (D, K) complex, s (Q, K) real
-        Yh = np.einsum('qd,qk->dk', kappa, s) * Z
-        for f in range(len(facW)):
-            t = np.einsum('b,bk->k', facA[f], Z) * (facW[f] * s[facQ[f]])
-            Yh += facA[f][:, None] * t[None]
-        return Yh
-
-    def even_forward(u):                 # u real (N,) -> 2 E[c], 2 E[H - c]
-        z = u[0::2] + 1j * u[1::2]
-        S = four_step_forward(z, Ha, Hb, planA, planB)
-        return onchip_untangle(S, Ha, Hb, planA, planB, N)
-
-    def odd_forward(u):                  # u real (N,) -> scrambled (Ha, Hb): O[2j]
-        z = (u[:H] - 1j * u[H:]) * wL
-        return four_step_forward(z, Ha, Hb, planA, planB)
-
-    se_lo = np.zeros((Q, H // 2 + 1))
-    se_hi = np.zeros_like(se_lo)
-    so = np.zeros((Q, Ha, Hb))
-    for q in range(Q):
-        c = circulant_column(tops[q], L)
-        _, lo, hi = even_forward(c[:N] + c[N:])
-        se_lo[q], se_hi[q] = lo.real / (4 * L), hi.real / (4 * L)
-        S = odd_forward(c[:N] - c[N:])
-        assert np.abs(S.imag).max() < 1e-9 * (1 + np.abs(S).max())
-        so[q] = S.real * (2.0 / L)
-    Y = np.zeros_like(X)
-    for v in range(nvec):
-        xp = np.zeros((D, N))
-        xp[:, :m] = X[v]
-        # phase E
-        lo = np.zeros((D, H // 2 + 1), dtype=np.complex128)
-        hi = np.zeros_like(lo)
-        for b in range(D):
-            _, lo[b], hi[b] = even_forward(xp[b])
-        ylo, yhi = mix(lo, se_lo), mix(hi, se_hi)
-        for a in range(D):
-            S = onchip_retangle(ylo[a], yhi[a], Ha, Hb, planA, planB, N)
-            z = four_step_adjoint(S, Ha, Hb, planA, planB)
-            y = np.zeros(N)
-            y[0::2], y[1::2] = z.real, z.imag
-            Y[v, a] = y[:m]
-        # phase O
-        So = np.zeros((D, Ha, Hb), dtype=np.complex128)
-        for b in range(D):
-            So[b] = odd_forward(xp[b])
-        Yo = mix(So.reshape(D, -1), so.reshape(Q, -1)).reshape(D, Ha, Hb)
-        for a in range(D):
-            h = np.conj(wL) * four_step_adjoint(Yo[a], Ha, Hb, planA, planB)
-            y = np.concatenate([h.real, -h.imag])
-            Y[v, a] += y[:m]
-    return Y

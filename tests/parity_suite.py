@@ -625,61 +625,6 @@ def check_ragged_and_empty_outputs():
     assert lik.noise_gradient()[1] == 0.0        # no data, no gradient
 
 
-def check_onchip_product(big=True, knob='RUNLMC_V4_MIN', value='1'):
-    """The on-chip product path (one workgroup per vector, rl_kernels4.h),
-    forced for every batch size, against the oracle: full mix, dense-B entry,
-    single top row, and agreement with the three-kernel path.  With
-    knob='RUNLMC_V5_MAX' the two-kernel small-batch form of the same scheme
-    (k5_forward / k5_inverse)."""
-    from runlmc_amd._native import GridOp
-    cases = [(1, 1, 40, 1), (3, 2, 50, 3), (2, 2, 104, 5), (4, 3, 300, 4), (4, 6, 504, 3),
-             (2, 2, 777, 4), (6, 1, 238, 2), (5, 2, 1000, 3), (3, 2, 700, 3), (6, 2, 1100, 2)]
-    if big:
-        cases += [(4, 3, 5004, 3), (2, 2, 5120, 2)]
-    old = os.environ.get(knob)
-    os.environ[knob] = value
-    try:
-        for D, Q, m, nvec in cases:
-            rng = np.random.RandomState(D * 1000 + Q * 100 + m)
-            tops = np.array([np.exp(-(0.02 + 0.1 * q) * np.arange(m) ** (1 + 0.3 * (q % 2)))
-                             for q in range(Q)])
-            A = [rng.randn(1 + q % 2, D) for q in range(Q)]
-            kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
-            g = GridOp(D, m, Q)
-            assert g.onchip[0] == 1, (D, Q, m, g.onchip)
-            if knob == 'RUNLMC_V4_MIN':
-                assert g.onchip[1] == 1, (D, Q, m, g.onchip)
-            g.set_lmc(tops, A, kap)
-            X = rng.randn(nvec, D * m)
-            Y = g.matmat_host(X)
-            Bs = ops.coreg_mats(A, kap)
-            toeps = [ops.BTTBOracle(t) for t in tops]
-            ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X])
-            _close(Y, ref, 1e-11)
-            g.set_dense(tops, np.array(Bs))
-            _close(g.matmat_host(X), ref, 1e-11)
-            Y1 = g.matmat_host(X[:1], top=Q - 1)
-            ref1 = np.array([toeps[Q - 1].matvec(r) for r in X[0].reshape(D, m)]).ravel()
-            _close(Y1[0], ref1, 1e-11)
-            os.environ['RUNLMC_NO_V4'] = '1'
-            try:
-                g2 = GridOp(D, m, Q)
-            finally:
-                del os.environ['RUNLMC_NO_V4']
-            assert g2.onchip[0] == 0
-            g2.set_lmc(tops, A, kap)
-            _close(g2.matmat_host(X), Y, 1e-12)
-        # outside its envelope (too many outputs for the register-resident
-        # spectra) the operator silently stays on the three-kernel path
-        g = GridOp(7, 3000, 1)
-        assert g.onchip[0] == 0
-    finally:
-        if old is None:
-            del os.environ[knob]
-        else:
-            os.environ[knob] = old
-
-
 def check_solver_fusions():
     """The batched MINRES variants agree: two-kernel rounds with the W product
     inside P and the W^T product inside the first grid kernel (a grid long

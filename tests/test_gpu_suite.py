@@ -92,14 +92,6 @@ def test_ragged_and_empty_outputs():
     ps.check_ragged_and_empty_outputs()
 
 
-def test_onchip_product():
-    ps.check_onchip_product()
-
-
-def test_onchip_two_kernel_product():
-    ps.check_onchip_product(knob='RUNLMC_V5_MAX', value='1000000')
-
-
 def test_solver_fusions():
     ps.check_solver_fusions()
 
