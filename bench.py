@@ -271,11 +271,6 @@ def dist_setup(args):
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if args.gpus != world:
-        raise SystemExit(
-            'bench.py --gpus %d but WORLD_SIZE=%d: launch N ranks with\n  python -m '
-            'torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 '
-            '--master-port 29500 bench.py --gpus %d ...' % (args.gpus, world, args.gpus, args.gpus))
     local = 0 if args.same_gpu else int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -376,7 +371,10 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2):
                         residual_max=float(np.max(lik.deriv.residuals)),
                         residual_median=float(np.median(lik.deriv.residuals)),
                         grad_norm=float(np.sqrt(sum(np.sum(np.square(x)) for x in
-                                                    g[0] + g[1] + [np.array(g[2])] + [g[3]]))))
+                                                    g[0] + g[1] + [np.array(g[2])] + [g[3]]))),
+                        # a few entries, so that runs can be compared with each other
+                        grad_sample=[float(v) for v in np.concatenate(
+                            [np.ravel(g[3]), np.ravel(g[1][0]), np.ravel(g[0][0])])[:12]])
     info['seconds'] = best
     return info
 
@@ -477,6 +475,14 @@ def main():
     if args.cpu_child is not None:
         cpu_child(args.cpu_child)
         return
+    # (before anything touches the GPU) one rank per GPU: --gpus N needs N ranks
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world_env:
+        raise SystemExit(
+            'bench.py --gpus %d but WORLD_SIZE=%d: launch N ranks with\n  python -m '
+            'torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 '
+            '--master-port 29500 bench.py --gpus %d ...'
+            % (args.gpus, world_env, args.gpus, args.gpus))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: runlmc_amd has no CPU path')

@@ -88,7 +88,10 @@ int rl_gridop_spectrum_host(rl_gridop* g, int q, double* out);
  * SumMatrix assembled by gen_grid_kernel (lmc/grid_kernel.py:70-74).
  *   W   CSR n x (D*m)  (host; int32 indices; reference
  *       approx/interpolation.py:119-176), WT its transpose in CSR.
- * The handle keeps a pointer to `g` (not owned).                              */
+ * The handle keeps a pointer to `g` (not owned): every product and solve uses
+ * it, so destroy the SKI handle BEFORE its grid operator(s).  (rl_ski_destroy
+ * itself does not touch `g`, so the other order only leaks nothing and crashes
+ * nothing -- but no other call on the handle is valid once `g` is gone.)     */
 int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int* W_indices,
                   const double* W_data, const int* WT_indptr, const int* WT_indices,
                   const double* WT_data, rl_ski** out);

@@ -67,29 +67,31 @@ class Iterative:
     def solve_sharded(K, B, minres=True, tol=1e-4, group=None):
         """A block of right-hand sides split over the ranks of `group` (every
         rank holds a replica of the operator; rows rank, rank + world, ... are
-        solved locally, no communication during the solve), results gathered
-        on every rank with one all-reduce of the zero-padded block -- SURVEY
-        section 8e, BASELINE config 4 (block of 8 right-hand sides over 1-4
-        GPUs).  B: (k, n) array.  Returns (X, iterations, residuals), all (k, .)."""
-        from ..util.dist import shard_rows, all_reduce_sum_
+        solved locally, no communication during the solve), results put together
+        on every rank with ONE all-gather (each rank sends its own rows once) --
+        SURVEY section 8e, BASELINE config 4 (block of 8 right-hand sides over
+        1-4 GPUs).  B: (k, n) array.  Returns (X, iterations, residuals), all (k, .)."""
+        from ..util.dist import shard_rows, rank_world, all_gather_rows
         ski = _device_operator(K)
         B = np.atleast_2d(as_f64(B))
         k, n = B.shape
         if n != K.shape[0]:
             raise ValueError('right-hand side has length {}, operator is {}'
                              .format(n, K.shape))
+        rank, world = rank_world(group)
         mine = shard_rows(k, group)
-        X = torch.zeros((k, n), dtype=torch.float64, device=ski.device)
-        stats = torch.zeros((k, 2), dtype=torch.float64, device=ski.device)
+        # solution rows with their iteration count and residual in two extra columns
+        local = torch.zeros((len(mine), n + 2), dtype=torch.float64, device=ski.device)
         if mine:
             Bl = torch.from_numpy(B[mine]).to(ski.device)
             Xl, iters, resid, _ = Iterative.solve_device(K, Bl, minres, tol)
-            idx = torch.tensor(mine, device=ski.device)
-            X[idx] = Xl
-            stats[idx, 0] = torch.from_numpy(np.asarray(iters, dtype=np.float64)).to(ski.device)
-            stats[idx, 1] = torch.from_numpy(np.asarray(resid, dtype=np.float64)).to(ski.device)
-        flat = torch.cat([X.reshape(-1), stats.reshape(-1)])
-        all_reduce_sum_(flat, group)
-        X = flat[:k * n].reshape(k, n).cpu().numpy()
-        stats = flat[k * n:].reshape(k, 2).cpu().numpy()
-        return X, stats[:, 0].astype(np.int64), stats[:, 1]
+            local[:, :n] = Xl
+            local[:, n] = torch.from_numpy(np.asarray(iters, dtype=np.float64)).to(ski.device)
+            local[:, n + 1] = torch.from_numpy(np.asarray(resid, dtype=np.float64)).to(ski.device)
+        counts = [len(range(r, k, world)) for r in range(world)]
+        full = all_gather_rows(local, counts, group).cpu().numpy()
+        # rank r's rows are r, r + world, ...: undo the interleave
+        order = np.concatenate([np.arange(r, k, world) for r in range(world)]).astype(np.int64)
+        out = np.empty_like(full)
+        out[order] = full
+        return out[:, :n], out[:, n].astype(np.int64), out[:, n + 1]

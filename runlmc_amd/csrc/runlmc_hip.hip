@@ -59,6 +59,18 @@ static void trace_once(const char* what) {
     fprintf(stderr, "[runlmc] %s\n", what);
 }
 
+// One-time per DEVICE work (the > 64 KiB dynamic-LDS opt-ins are function
+// attributes of the code object loaded on each device): true the first time a
+// call site sees the current device.  `seen` is the call site's own bit mask.
+static bool first_on_device(unsigned long long* seen) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*seen & bit) return false;
+    *seen |= bit;
+    return true;
+}
+
 static int ilog2(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -333,9 +345,8 @@ static void set_lds_attr_cols2() {
 
 static void set_lds_attrs() {
 #if !defined(RL_EMU)
-    static bool done = false;
-    if (done) return;
-    done = true;
+    static unsigned long long seen = 0;
+    if (!first_on_device(&seen)) return;
     (void)hipFuncSetAttribute((const void*)k_cols_fwd,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_cols_inv,
@@ -368,9 +379,8 @@ template <int D>
 static void launch1p_d(rl_gridop* g, unsigned pairs, hipStream_t st, const double* X, double* Y,
                        int nvec, int mode, const MixParams& mp, double* spec_out) {
 #if !defined(RL_EMU)
-    static bool attr = false;
-    if (!attr) {
-        attr = true;
+    static unsigned long long seen = 0;
+    if (first_on_device(&seen)) {
         (void)hipFuncSetAttribute((const void*)k1_product<D>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -607,11 +617,24 @@ static int build_spectra(rl_gridop* g, int ntop, hipStream_t stream) {
     return RL_OK;
 }
 
-static int set_common(rl_gridop* g, int Q, const double* tops) {
+// A setter validates EVERYTHING and builds its factors on the host before it
+// touches the handle (set_check), then commits: tops + spectra (set_common) and
+// factors + mix tables (set_factors).  A device failure half way leaves the
+// handle without parameters (Q = 0), so that later products fail loudly
+// instead of mixing new spectra with old factors.
+static int set_check(rl_gridop* g, int Q, const double* tops) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
     if (Q < 1 || Q > g->max_tops)
         return fail(RL_EINVAL, "rl_gridop_set: Q outside [1, max_tops]");
     if (!tops) return fail(RL_EINVAL, "rl_gridop_set: tops is NULL");
+    return RL_OK;
+}
+static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector<double>& A,
+                      const std::vector<double>& W, const std::vector<int>& Qi,
+                      const std::vector<double>& kap);
+
+static int set_common(rl_gridop* g, int Q, const double* tops) {
+    RL_TRY(set_check(g, Q, tops));
     RL_HIP(hipSetDevice(g->device));
     RL_HIP(hipMemcpy(g->tops, tops, (size_t)Q * g->m * sizeof(double), hipMemcpyHostToDevice));
     RL_TRY(build_spectra(g, Q, nullptr));
@@ -651,9 +674,20 @@ static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::ve
     return RL_OK;
 }
 
+static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector<double>& A,
+                      const std::vector<double>& W, const std::vector<int>& Qi,
+                      const std::vector<double>& kap) {
+    if ((int)W.size() > g->max_fac)
+        return fail(RL_ELIMIT, "rl_gridop_set: total rank exceeds max_tops*D");
+    int rc = set_common(g, Q, tops);
+    if (rc == RL_OK) rc = set_factors(g, A, W, Qi, kap);
+    if (rc != RL_OK) g->Q = 0;          // no half-updated operator
+    return rc;
+}
+
 extern "C" int rl_gridop_set_lmc(rl_gridop* g, int Q, const double* tops, const int* ranks,
                                  const double* coreg_vecs, const double* coreg_diags) {
-    RL_TRY(set_common(g, Q, tops));
+    RL_TRY(set_check(g, Q, tops));
     if (!ranks || !coreg_diags) return fail(RL_EINVAL, "rl_gridop_set_lmc: NULL argument");
     const int D = g->D;
     std::vector<double> A, W, kap(coreg_diags, coreg_diags + (size_t)Q * D);
@@ -690,7 +724,7 @@ extern "C" int rl_gridop_set_lmc(rl_gridop* g, int Q, const double* tops, const 
             Qi.push_back(q);
         }
     }
-    return set_factors(g, A, W, Qi, kap);
+    return set_commit(g, Q, tops, A, W, Qi, kap);
 }
 
 // cyclic Jacobi eigen-decomposition of a small symmetric matrix (row-major,
@@ -735,7 +769,7 @@ static void jacobi_eig(std::vector<double>& a, int n, std::vector<double>& w,
 }
 
 extern "C" int rl_gridop_set_dense(rl_gridop* g, int Q, const double* tops, const double* B) {
-    RL_TRY(set_common(g, Q, tops));
+    RL_TRY(set_check(g, Q, tops));
     if (!B) return fail(RL_EINVAL, "rl_gridop_set_dense: B is NULL");
     const int D = g->D;
     std::vector<double> A, W, kap((size_t)Q * D, 0.0);
@@ -761,7 +795,7 @@ extern "C" int rl_gridop_set_dense(rl_gridop* g, int Q, const double* tops, cons
             Qi.push_back(q);
         }
     }
-    return set_factors(g, A, W, Qi, kap);
+    return set_commit(g, Q, tops, A, W, Qi, kap);
 }
 
 template <int D>
@@ -1225,6 +1259,11 @@ struct SolverWork {
 };
 
 struct rl_ski {
+    // Lanczos coefficients of a solve: kept between calls (a hipMalloc / hipFree
+    // pair per solve costs ~200 us, as much as four C2 solver rounds)
+    double* lanczos_buf = nullptr;
+    size_t lanczos_bytes = 0;
+    int device = 0;     // copy of g->device: the grid operator may be gone at destroy time
     std::vector<SkiTerm> extra;   // terms beyond the first (rl_ski_add_term)
     int max_ngrid = 0;
     rl_gridop* g = nullptr;
@@ -1420,6 +1459,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     rl_ski* s = new rl_ski;
     HandleGuard<rl_ski, rl_ski_destroy> guard(s);
     s->g = g;
+    s->device = g->device;
     s->n = n;
     s->ngrid = ngrid;
     // sort the data points by the first grid point they touch
@@ -1483,7 +1523,7 @@ static void free_work(SolverWork& w);
 
 extern "C" int rl_ski_destroy(rl_ski* s) {
     if (!s) return RL_OK;
-    (void)hipSetDevice(s->g->device);
+    (void)hipSetDevice(s->device);
     for (SkiTerm& t : s->extra) {
         void* tp[] = {t.W_indptr, t.W_indices, t.W_data, t.WT_indptr, t.WT_indices, t.WT_data,
                       t.W4_base, t.W4_w, t.WT_lo};
@@ -1494,7 +1534,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     if (s->ws_valid) free_work(s->ws);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
-                    s->W4_base, s->W4_w, s->WT_lo};
+                    s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -1566,9 +1606,8 @@ static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStrea
         ((size_t)s->ngrid * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
         getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
         trace_once("W^T product: k_spmv_wt_staged");
-        static bool attr = false;
-        if (!attr) {
-            attr = true;
+        static unsigned long long seen = 0;
+        if (first_on_device(&seen)) {
             (void)hipFuncSetAttribute((const void*)k_spmv_wt_staged<VB>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         }
@@ -1593,9 +1632,8 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
         ((size_t)s->n * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
         getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
         trace_once("W product: k_spmv_w_staged");
-        static bool attr = false;
-        if (!attr) {
-            attr = true;
+        static unsigned long long seen = 0;
+        if (first_on_device(&seen)) {
             (void)hipFuncSetAttribute((const void*)k_spmv_w_staged<VB>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         }
@@ -1718,7 +1756,6 @@ static void free_work(SolverWork& w) {
     if (w.I) (void)hipFree(w.I);
     if (w.count) (void)hipFree(w.count);
     if (w.resid) (void)hipFree(w.resid);
-    if (w.lanczos) (void)hipFree(w.lanczos);
     w.I = nullptr; w.count = nullptr; w.resid = nullptr; w.lanczos = nullptr;
 }
 
@@ -1740,7 +1777,7 @@ struct SolverWorkGuard {
     ~SolverWorkGuard() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
-        if (w->lanczos) { (void)hipFree(w->lanczos); w->lanczos = nullptr; }
+        w->lanczos = nullptr;       // owned by the handle (rl_ski::lanczos_buf)
         size_t nv = 0;
         for (double* p : w->vec) nv += p != nullptr;
         const size_t bytes = nv * s->ws_vec_cap * sizeof(double);
@@ -2016,7 +2053,14 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         mb.ngrid = s->ngrid;
         if (lanczos_out != nullptr) {
             const size_t bytes = (size_t)nrhs * lanczos_cap * 2 * sizeof(double);
-            RL_HIP(hipMalloc((void**)&w.lanczos, bytes));
+            if (s->lanczos_bytes < bytes) {
+                if (s->lanczos_buf) RL_HIP(hipFree(s->lanczos_buf));
+                s->lanczos_buf = nullptr;
+                s->lanczos_bytes = 0;
+                RL_HIP(hipMalloc((void**)&s->lanczos_buf, bytes));
+                s->lanczos_bytes = bytes;
+            }
+            w.lanczos = s->lanczos_buf;
             RL_HIP(hipMemsetAsync(w.lanczos, 0, bytes, st));
             mb.lanczos = w.lanczos;
             mb.lanczos_cap = lanczos_cap;
@@ -2074,7 +2118,14 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         mb.lanczos_cap = 0;
         if (lanczos_out != nullptr) {
             const size_t bytes = (size_t)nrhs * lanczos_cap * 2 * sizeof(double);
-            RL_HIP(hipMalloc((void**)&w.lanczos, bytes));
+            if (s->lanczos_bytes < bytes) {
+                if (s->lanczos_buf) RL_HIP(hipFree(s->lanczos_buf));
+                s->lanczos_buf = nullptr;
+                s->lanczos_bytes = 0;
+                RL_HIP(hipMalloc((void**)&s->lanczos_buf, bytes));
+                s->lanczos_bytes = bytes;
+            }
+            w.lanczos = s->lanczos_buf;
             RL_HIP(hipMemsetAsync(w.lanczos, 0, bytes, st));
             mb.lanczos = w.lanczos;
             mb.lanczos_cap = lanczos_cap;

@@ -114,14 +114,26 @@ class ApproxLMCLikelihood(LMCLikelihood):
         lib, dev = skiop.lib, skiop.device
         term_of = getattr(self.K, 'term_of', None) or {ad: 0 for ad in fk.active_dims}
         nloc = dv.rs_dev.shape[0]
-        U = torch.cat([dv.alpha_dev[None, :], dv.inv_rs_dev], dim=0).contiguous()
-        V = torch.cat([dv.alpha_dev[None, :], dv.rs_dev], dim=0).contiguous()
+        # alpha rides in a transform pair of its own (last of an odd batch, or
+        # next to a zero row), as in the solves: its Gram terms then carry the
+        # same bits on every rank, whatever probes the rank holds
+        arow = dv.alpha_dev[None, :]
+        if nloc % 2 == 0:
+            U = torch.cat([dv.inv_rs_dev, arow], dim=0).contiguous()
+            V = torch.cat([dv.rs_dev, arow], dim=0).contiguous()
+            ia, probe_rows = nloc, slice(0, nloc)
+        else:
+            zero = torch.zeros_like(arow)
+            U = torch.cat([arow, zero, dv.inv_rs_dev], dim=0).contiguous()
+            V = torch.cat([arow, zero, dv.rs_dev], dim=0).contiguous()
+            ia, probe_rows = 0, slice(2, 2 + nloc)
+        nrow = U.shape[0]
 
         # per active-dimension set (= per grid = per term of the operator): the
         # top rows k_q and dk_q/dtheta of its kernels, one batched Toeplitz
         # product and one D x D Gram per top row
         owner = []            # (q, None) for k_q, (q, p) for dk_q/dtheta_p
-        blocks = []           # P tensors (ntops_t, nloc + 1, D, D)
+        blocks = []           # P tensors (ntops_t, nrow, D, D)
         for ad, qs in fk.active_dims.items():
             term = term_of[ad]
             grid = skiop.grids[term]
@@ -138,7 +150,7 @@ class ApproxLMCLikelihood(LMCLikelihood):
             gop.set_lmc(np.stack(tops_t), [None] * nt, [np.zeros(D)] * nt)
             Ut = skiop.apply_wt(U, term)
             Vt = skiop.apply_wt(V, term)
-            P = torch.empty((nt, nloc + 1, D, D), dtype=torch.float64, device=dev)
+            P = torch.empty((nt, nrow, D, D), dtype=torch.float64, device=dev)
             TV = torch.empty_like(Vt)
             for t in range(nt):
                 gop.mvm(Vt, out=TV, top=t)
@@ -149,17 +161,17 @@ class ApproxLMCLikelihood(LMCLikelihood):
         ntops = P.shape[0]
         offsets = torch.from_numpy(
             np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int32)).to(dev)
-        seg = segment_dots(lib, U, V, offsets, D)          # (nloc + 1, D)
+        seg = segment_dots(lib, U, V, offsets, D)          # (nrow, D)
 
         # alpha terms are identical on every rank; probe sums are reduced
-        probe = torch.cat([P[:, 1:].sum(dim=1).reshape(-1),
-                           seg[1:].sum(dim=0).reshape(-1)])
+        probe = torch.cat([P[:, probe_rows].sum(dim=1).reshape(-1),
+                           seg[probe_rows].sum(dim=0).reshape(-1)])
         all_reduce_sum_(probe, dv._group)
         N = dv._n_it
         Psum = probe[:ntops * D * D].reshape(ntops, D, D)
         ssum = probe[ntops * D * D:]
-        Gall = (0.5 * (P[:, 0] - Psum / N)).cpu().numpy()
-        noise = (0.5 * (seg[0] - ssum / N)).cpu().numpy()
+        Gall = (0.5 * (P[:, ia] - Psum / N)).cpu().numpy()
+        noise = (0.5 * (seg[ia] - ssum / N)).cpu().numpy()
         G = [None] * Q
         Gd = [[None] * len(self.materialized_grads[q]) for q in range(Q)]
         for t, (q, p_) in enumerate(owner):

@@ -11,7 +11,7 @@ import torch
 
 from .derivative import Derivative
 from ..approx.iterative import Iterative
-from ..util.dist import rank_world, shard_rows, all_reduce_sum_, broadcast_
+from ..util.dist import rank_world, shard_rows, all_reduce_sum_
 
 
 class StochasticDerivService:
@@ -42,11 +42,26 @@ class StochasticDerivService:
             raise ValueError('probes must have shape {}'.format((self._n_it, n)))
         mine = shard_rows(self._n_it, self._group)
         dev = K.device
-        rhs = np.vstack([np.asarray(y, dtype=np.float64)[None, :],
-                         rs[mine].astype(np.float64)])
-        B = torch.from_numpy(rhs).to(dev)
-        X, iters, resid, istop, lanczos = Iterative.solve_device(
-            K, B, minres=True, tol=self._tol, lanczos_cap=self.LANCZOS_CAP)
+        # Two right-hand sides share one complex transform, so a vector's
+        # roundoff depends on its batch neighbour.  y is therefore given a
+        # transform of its own on EVERY rank -- last in an odd batch, or next to
+        # a zero vector -- and alpha comes out bit-identical everywhere: the
+        # ranks assemble identical gradients without any broadcast.
+        yrow = np.asarray(y, dtype=np.float64)[None, :]
+        probes = rs[mine].astype(np.float64)
+        if len(mine) % 2 == 0:
+            rhs = np.vstack([probes, yrow])                       # y alone in the last pair
+            order = [len(mine)] + list(range(len(mine)))
+        else:
+            rhs = np.vstack([yrow, np.zeros_like(yrow), probes])  # y paired with zeros
+            order = [0] + list(range(2, 2 + len(mine)))
+        Bfull = torch.from_numpy(rhs).to(dev)
+        Xf, iters, resid, istop, lanczos = Iterative.solve_device(
+            K, Bfull, minres=True, tol=self._tol, lanczos_cap=self.LANCZOS_CAP)
+        idx = torch.tensor(order, device=dev)
+        X, B = Xf[idx], Bfull[idx]
+        iters, resid, istop = (np.asarray(a)[order] for a in (iters, resid, istop))
+        lanczos = lanczos[order]
         rank, world = rank_world(self._group)
         if self.metrics is not None:
             # mean over the N+1 systems; alpha (solved everywhere) counted once
@@ -57,10 +72,6 @@ class StochasticDerivService:
             self.metrics.iterations.append(float(stats[0]) / (self._n_it + 1))
             self.metrics.solv_error.append(float(stats[1]) / (self._n_it + 1))
         alpha = X[0].clone()
-        # two right-hand sides share one complex transform, so alpha's
-        # roundoff depends on the probe it was packed with; make every rank
-        # use rank 0's alpha so gradients are bit-identical across ranks
-        broadcast_(alpha, 0, self._group)
         return StochasticDeriv(alpha, B[1:], X[1:], self._n_it, group=self._group,
                                iterations=iters, residuals=resid, istop=istop,
                                lanczos=lanczos)

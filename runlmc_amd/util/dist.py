@@ -4,10 +4,11 @@
 The reference's only parallel axis is the N+1 independent solves mapped over a
 process pool (runlmc/lmc/stochastic_deriv.py:39-52).  Here the N probes are
 dealt round-robin to the ranks, every rank holds a replica of the operator and
-solves for alpha itself (rank 0's alpha is then broadcast, n doubles, so that
-all ranks assemble bit-identical gradients), and ONE all-reduce of the summed
+solves for alpha itself -- in a transform pair of its own, so that every rank
+gets the same bits without a broadcast -- and ONE all-reduce of the summed
 gradient partials (a few KB) closes the step.  There is no collective inside
-the solve."""
+the solve.  A plain block of right-hand sides is split the same way and put
+together again with one all-gather."""
 import torch
 import torch.distributed as dist
 
@@ -58,3 +59,25 @@ def all_reduce_sum_(flat, group=None):
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def all_gather_rows(local, counts, group=None):
+    """Concatenation over ranks of (rows_r, width) float64 blocks, rank order;
+    `counts[r]` = rows of rank r (known to everyone).  One all_gather of
+    equal-sized buffers (each rank pads its block to max(counts) rows): a rank
+    sends its own rows once instead of reducing a world-sized zero-padded
+    block.  Returns a (sum(counts), width) tensor on `local`'s device."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return local
+    width = local.shape[1]
+    most = max(counts)
+    backend = dist.get_backend(group)
+    on_host = backend == 'gloo' and local.device.type != 'cpu'
+    send = torch.zeros((most, width), dtype=local.dtype,
+                       device='cpu' if on_host else local.device)
+    send[:local.shape[0]] = local.cpu() if on_host else local
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    out = torch.cat([recv[r][:counts[r]] for r in range(world)], dim=0)
+    return out.to(local.device)

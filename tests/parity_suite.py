@@ -131,6 +131,31 @@ def check_operator_errors():
         Toeplitz(np.ones(4)).matvec(np.ones(5))
 
 
+def check_failed_setter_leaves_operator():
+    """A setter that rejects its arguments leaves the handle as it was: the next
+    product is still the OLD operator (C ABI: rl_gridop_set_lmc / set_dense
+    validate and factor on the host before they touch the device state)."""
+    import pytest
+    from runlmc_amd._native import GridOp
+    from runlmc_amd._lib import NativeError
+    rng = np.random.RandomState(4)
+    D, Q, m = 3, 2, 40
+    tops = np.array([np.exp(-0.1 * (q + 1) * np.arange(m)) for q in range(Q)])
+    A = [rng.randn(1, D) for _ in range(Q)]
+    kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+    g = GridOp(D, m, Q)
+    g.set_lmc(tops, A, kap)
+    X = rng.randn(2, D * m)
+    Y0 = g.matmat_host(X)
+    bad = np.array([np.eye(D), np.triu(np.ones((D, D)))])        # second B is not symmetric
+    with pytest.raises((ValueError, NativeError)):
+        g.set_dense(2.0 * tops, bad)
+    _close(g.matmat_host(X), Y0, 1e-14)
+    Bs = ops.coreg_mats(A, kap)
+    toeps = [ops.BTTBOracle(t_) for t_ in tops]
+    _close(Y0, np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X]))
+
+
 def check_kronecker_and_sum():
     lin = _lin()
     for i in range(int(lin['kron_count'])):

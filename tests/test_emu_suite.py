@@ -29,6 +29,10 @@ def test_operator_errors():
     ps.check_operator_errors()
 
 
+def test_failed_setter_leaves_operator():
+    ps.check_failed_setter_leaves_operator()
+
+
 def test_kronecker_and_sum():
     ps.check_kronecker_and_sum()
 

@@ -40,7 +40,7 @@ def _grads(world_group=None):
                           [np.ravel(g) for g in lik.coreg_diags_gradients()] +
                           [np.ravel(g) for g in lik.kernel_gradients()] +
                           [lik.noise_gradient()])
-    return flat, lik.deriv.rs_dev.shape[0]
+    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy()
 
 
 def _worker(rank, world, port, q):
@@ -49,8 +49,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from runlmc_amd import _lib, build
     _lib.use_library(build.EMU_LIB)
-    flat, nloc = _grads()
-    q.put((rank, flat, nloc))
+    flat, nloc, alpha = _grads()
+    q.put((rank, flat, nloc, alpha))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,7 +59,7 @@ def test_two_rank_probe_sharding():
     from runlmc_amd import _lib, build
     _lib.use_library(build.build_emu())
     try:
-        ref, nall = _grads()
+        ref, nall, alpha_ref = _grads()
     finally:
         _lib.use_library(None)
     ctx = mp.get_context('spawn')
@@ -75,8 +75,14 @@ def test_two_rank_probe_sharding():
     got.sort(key=lambda t: t[0])
     assert got[0][2] + got[1][2] == nall          # every probe owned once
     assert got[0][2] == (nall + 1) // 2
-    # both ranks end with the same, full gradient
-    np.testing.assert_allclose(got[0][1], got[1][1], rtol=0, atol=1e-11 * np.abs(ref).max())
+    # alpha is solved on every rank in a transform pair of its own (one rank
+    # holds an odd, the other an even number of probes: both batch layouts):
+    # the SAME BITS everywhere, with no broadcast -- and the same as one rank's
+    assert np.array_equal(got[0][3], got[1][3])
+    assert np.array_equal(got[0][3], alpha_ref)
+    # both ranks end with the same, full gradient (identical alpha terms,
+    # identical all-reduced probe sums)
+    assert np.array_equal(got[0][1], got[1][1])
     # batching changes which vectors share a transform -> solver-level noise
     scale = np.abs(ref).max()
     assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
