@@ -450,6 +450,23 @@ def gen_fit_data():
         arrs['ty%d' % i] = te['ATMP'].values.astype(float)
     _save('fit_weather.npz', **arrs)
 
+    # the synthetic two-input workload of benchmarks/synth/synth.py: five outputs
+    # sampled from a Q = 2 SLFM + independent RBF kernel on the unit square
+    # (data/synth/mkdata.py wrote xss.npy / yss.npy); the last output's
+    # upper-right quadrant is the held-out set (standard_tester.py:151-167)
+    d = os.path.join(REF, 'data', 'synth')
+    xss = list(np.load(os.path.join(d, 'xss.npy')))
+    yss = list(np.load(os.path.join(d, 'yss.npy')))
+    sel = np.all(xss[-1] >= 0.5, axis=1)
+    arrs = {'names': np.array(['out%d' % i for i in range(len(xss))])}
+    for i in range(len(xss)):
+        last = i == len(xss) - 1
+        arrs['x%d' % i] = xss[i][~sel] if last else xss[i]
+        arrs['y%d' % i] = yss[i][~sel] if last else yss[i]
+        arrs['tx%d' % i] = xss[i][sel] if last else np.zeros((0, 2))
+        arrs['ty%d' % i] = yss[i][sel] if last else np.zeros(0)
+    _save('fit_synth.npz', **arrs)
+
 
 def _normalise(yss):
     # runlmc/util/normalizer.py:19-34 via models/multigp.py:63-69
