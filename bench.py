@@ -54,6 +54,8 @@ def parse():
     ap.add_argument('--no-nll', action='store_true', help='skip the NLL+grad timing')
     ap.add_argument('--no-sweep', action='store_true',
                     help='skip the saturating-batch timings (extra keys)')
+    ap.add_argument('--no-full', action='store_true',
+                    help='skip the full-operator (W K_UU W^T + eps) timing')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the second configuration (the "c2" key)')
     ap.add_argument('--cpu-seconds', type=float, default=8.0,
@@ -379,6 +381,26 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2):
     return info
 
 
+def time_full_operator(g, p, batch, gen, steps, world, dev, alg):
+    """K~ = W K_UU W^T + eps on `batch` data-space vectors."""
+    import torch
+    from runlmc_amd._native import SkiOp
+    s = SkiOp(g, p.W, p.WT)
+    s.set_noise(p.noise, p.lens)
+    Xd = torch.randn(batch, p.n, dtype=torch.float64, generator=gen).to(dev)
+    Yd = torch.empty_like(Xd)
+    fsteps = max(3, steps // 2)
+    fwall, fev = time_steps(lambda: s.mvm(Xd, out=Yd), fsteps, 2, world, dev)
+    fwall = max_over_ranks(fwall, world, dev)
+    nnz = int(p.W.nnz)
+    full_alg = alg + 8 * 3 * p.n * batch + 2 * (nnz * 12 + (p.n + 1) * 4)
+    return {'mvm_per_s': batch * world / (fwall * 1e-3), 'ms_per_step': fwall,
+            'steps': fsteps, 'n': p.n,
+            'roofline_frac': full_alg / (fwall * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'algorithmic_bytes_per_step': full_alg,
+            'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors' % batch}
+
+
 def bench_config(name, args, rank, world, dev, steps, warmup, headline):
     """All device measurements of one (D, Q, m) configuration."""
     import torch
@@ -421,22 +443,8 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
     if traffic is not None:
         out['roofline']['traffic_GBps'] = traffic / (wall_ms * 1e-3) / 1e9
 
-    # the full operator  K~ = W K_UU W^T + eps  on the same batch (data space)
-    s = SkiOp(g, p.W, p.WT)
-    s.set_noise(p.noise, p.lens)
-    Xd = torch.randn(batch, p.n, dtype=torch.float64, generator=gen).to(dev)
-    Yd = torch.empty_like(Xd)
-    fsteps = max(3, steps // 2)
-    fwall, fev = time_steps(lambda: s.mvm(Xd, out=Yd), fsteps, 2, world, dev)
-    fwall = max_over_ranks(fwall, world, dev)
-    nnz = int(p.W.nnz)
-    full_alg = alg + 8 * 3 * p.n * batch + 2 * (nnz * 12 + (p.n + 1) * 4)
-    out['full_mvm'] = {'mvm_per_s': batch * world / (fwall * 1e-3), 'ms_per_step': fwall,
-                       'steps': fsteps, 'n': p.n,
-                       'roofline_frac': full_alg / (fwall * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       'algorithmic_bytes_per_step': full_alg,
-                       'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors' % batch}
-    del s, Xd, Yd
+    if not args.no_full:
+        out['full_mvm'] = time_full_operator(g, p, batch, gen, steps, world, dev, alg)
 
     if not args.no_sweep and world == 1:
         # the N+1-vector batch is what a solver round carries; larger batches

@@ -653,7 +653,10 @@ static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::ve
     }
     RL_HIP(hipMemcpy(g->kappa, kap.data(), kap.size() * sizeof(double), hipMemcpyHostToDevice));
     g->nfac = nfac;
-    // mix tables of the third-generation row kernel (dc: D rows, gs: nfac rows)
+    // mix tables of the third-generation row kernel (dc: D rows, gs: nfac rows).
+    // (Measured against a mix that reads only the Q spectra and forms dc / gs in
+    // registers -- a third of the table bytes, 100 more multiply-adds and 20 more
+    // scalar loads per point: 3.79 vs 2.96 ms per C5 product.  Removed.)
     g->mixtab_ok = false;
     if (g->rows3 && nfac <= RL_MIXF && getenv("RUNLMC_NO_MIXTAB") == nullptr) {
         const size_t rows = (size_t)g->D + nfac;
@@ -891,13 +894,17 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
         tp->R = R;
         tp->colsMagic = div_magic((unsigned)(R * g->D));
         // workgroup size: the multiple of 64 that needs the fewest rounds over the
-        // three phases, the smallest such (C5: 10 x 32 butterflies -> 320 threads);
-        // when LDS admits several workgroups per CU, small enough that they also
-        // fit the ~12 waves per CU the kernel's registers allow
+        // three phases, the smallest such; when LDS admits several workgroups per
+        // CU, small enough that they also fit the waves the kernel's registers
+        // allow (C5: 512 threads -- the 2 x 512 split re/im mix items in ONE round,
+        // the 320 butterflies of the radix-16 passes on five of the eight waves;
+        // measured 2.81 vs 2.95 ms per 129-vector product against 320 threads)
         const int items[3] = {R * g->D * sa, R * g->D * nbf, R * g->N2};
         const int weight[3] = {4, 4, 1};      // passes A and B run twice; a mix item is light
+        // (the kernel is built for 128 VGPRs while D <= 12: 16 waves per CU)
         const int wgs = (int)std::min<size_t>(8, (160 * 1024) / lds3(R));
-        const int tmax = wgs >= 2 ? std::max(256, (12 / wgs) * 64) : RL_THREADS3;
+        const int waves = g->D <= 12 ? 16 : 8;
+        const int tmax = wgs >= 2 ? std::max(256, (waves / wgs) * 64) : RL_THREADS3;
         long bestCost = -1;
         int bestT = 64;
         for (int t = 64; t <= tmax; t += 64) {
@@ -1590,7 +1597,9 @@ static int ski_reserve_perm(rl_ski* s, int nvec) {
 // caller order <-> internal (sorted) order
 static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int scatter,
                          hipStream_t st) {
-    dim3 grid((s->n + RL_THREADS - 1) / RL_THREADS, nvec);
+    // (row-block count padded to a multiple of 8 for the XCD-aware order; the
+    // kernel masks rows past n)
+    dim3 grid((((s->n + RL_THREADS - 1) / RL_THREADS) + 7) / 8 * 8, nvec);
     RL_LAUNCH(k_permute_rows, grid, dim3(RL_THREADS), 0, st, X, Y, (const int*)s->perm, s->n,
               scatter);
 }

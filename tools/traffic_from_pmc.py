@@ -1,0 +1,46 @@
+"""HBM-side bytes per bench step of the grid product from rocprofv3 PMC passes
+(tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs) -> profiles/r02/traffic.json.
+
+    python tools/traffic_from_pmc.py <pmc dir> <config> <batch> <steps incl. warm-up> <source label>
+
+Counter handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are kilobytes at the L2's fabric side (Infinity-Cache hits included);
+on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads,
+so it is doubled for the kernels whose reads are the complex intermediates (row
+kernel, adjoint column kernel); the forward column kernel reads 8-byte reals and
+is left as reported.  WRITE_SIZE is used as reported (uncalibrated)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root, config, batch, steps, label = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+tot = defaultdict(lambda: defaultdict(float))
+for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get('Kernel_Name', '').split('(')[0].replace('void ', '')
+            tot[name][row['Counter_Name']] += float(row['Counter_Value'])
+bytes_total, detail = 0.0, {}
+for name, c in tot.items():
+    if not (name.startswith('k2_') or name.startswith('k3_') or name.startswith('k1_product')):
+        continue
+    double = not name.startswith('k2_cols_fwd')
+    rd = c.get('FETCH_SIZE', 0.0) * 1024 * (2 if double else 1)
+    wr = c.get('WRITE_SIZE', 0.0) * 1024
+    detail[name] = {'read_bytes_per_step': rd / steps, 'write_bytes_per_step': wr / steps,
+                    'fetch_doubled': double}
+    bytes_total += rd + wr
+out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'profiles', 'r02', 'traffic.json')
+try:
+    table = json.load(open(out_path))
+except (OSError, ValueError):
+    table = {}
+table['%s:%d' % (config, batch)] = {'bytes_per_step': bytes_total / steps, 'source': label,
+                                    'kernels': detail}
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+json.dump(table, open(out_path, 'w'), indent=1, sort_keys=True)
+print(config, batch, 'bytes per step %.4g' % (bytes_total / steps))
