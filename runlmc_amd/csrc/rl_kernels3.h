@@ -227,7 +227,18 @@ k3_rows_mix(cplx* __restrict__ T, Tile2 tp, const cplx* __restrict__ tw2,
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, R = tp.R;
     const int cols = R * D;
-    const int rt = blockIdx.x, pair = blockIdx.y;
+    // (row tile, pair) of this workgroup.  The mix tables of a row are the same
+    // for every pair, so the tiles that share a row should meet in one XCD's L2:
+    // with a tile count that is a multiple of 8, XCD k (linear block id mod 8,
+    // the dispatcher's observed placement) takes the row tiles k, k + 8, ... and
+    // runs the pairs of each one after another.  Otherwise: plain 2-D order.
+    int rt = blockIdx.x, pair = blockIdx.y;
+    if ((gridDim.x & 7) == 0 && gridDim.y > 1) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = b & 7, slot = b >> 3;
+        rt = (slot / (int)gridDim.y) * 8 + xcd;
+        pair = slot % (int)gridDim.y;
+    }
     const int r0 = rt * R;
     const size_t L = (size_t)N1 * N2;
     cplx* base = T + (size_t)pair * D * L;
