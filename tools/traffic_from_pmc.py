@@ -18,7 +18,14 @@ from collections import defaultdict
 
 root, config, batch, steps, label = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 tot = defaultdict(lambda: defaultdict(float))
-for path in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+# one file per counter pass (pass0, pass1, ...): the newest, should a directory
+# hold the output of more than one run
+paths = []
+for pdir in sorted(glob.glob(os.path.join(root, 'pass*'))):
+    cand = glob.glob(os.path.join(pdir, '**', '*counter_collection.csv'), recursive=True)
+    if cand:
+        paths.append(max(cand, key=os.path.getmtime))
+for path in paths:
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get('Kernel_Name', '').split('(')[0].replace('void ', '')
