@@ -709,6 +709,47 @@ def check_solver_fusions():
         _close(res["fused"][0][v], xo, 2e-5)
 
 
+def check_row_kernel_shapes(shapes=None):
+    """The third-generation row kernel (k3_rows_mix) at each of its plans --
+    N2 = 128 (8.8.2), 256 (16.8.2), 512 (16.16.2) -- with odd column factors,
+    several D (the 128-VGPR build up to D = 12, the wider one above), odd and
+    even batches, LMC and dense-B parameters (with and without the dc / gs mix
+    tables: more factors than the tables hold fall back to the spectra), and the
+    single-top product; all against the oracle's 'sum' representation."""
+    from runlmc_amd._native import GridOp
+    shapes = shapes or [(4, 3, 5004, 5), (3, 2, 20001, 3), (2, 2, 30000, 3), (2, 1, 70000, 2)]
+    saved = os.environ.pop('RUNLMC_POW2_ONLY', None)
+    try:
+        for i, (D, Q, m, k) in enumerate(shapes):
+            rng = np.random.RandomState(100 + i)
+            tops = np.array([np.exp(-(0.02 + 0.1 * q) * np.arange(m) ** (1 + 0.3 * (q % 2)))
+                             for q in range(Q)])
+            A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+            kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+            for pow2 in (False, True):
+                if pow2:
+                    os.environ['RUNLMC_POW2_ONLY'] = '1'
+                else:
+                    os.environ.pop('RUNLMC_POW2_ONLY', None)
+                g = GridOp(D, m, Q)
+                if g.N2 not in (128, 256, 512):
+                    continue
+                X = rng.randn(k, D * m)
+                Bs = ops.coreg_mats(A, kap)
+                toeps = [ops.BTTBOracle(t) for t in tops]
+                ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X])
+                g.set_lmc(tops, A, kap)
+                _close(g.matmat_host(X), ref)
+                g.set_dense(tops, np.array(Bs))            # up to Q * D factors
+                _close(g.matmat_host(X), ref)
+                one = g.matmat_host(X[:1], top=Q - 1)[0]
+                _close(one, np.concatenate([toeps[Q - 1].matvec(r) for r in X[0].reshape(D, m)]))
+    finally:
+        os.environ.pop('RUNLMC_POW2_ONLY', None)
+        if saved is not None:
+            os.environ['RUNLMC_POW2_ONLY'] = saved
+
+
 def check_chunked_product():
     """A batched grid product split into several chunks of intermediates, on one
     stream and on two (RUNLMC_CHUNK_MB / RUNLMC_TWO_STREAMS), against the

@@ -147,3 +147,7 @@ def test_single_tile_product():
 
 def test_rank_above_outputs():
     ps.check_rank_above_outputs()
+
+
+def test_row_kernel_shapes():
+    ps.check_row_kernel_shapes()
