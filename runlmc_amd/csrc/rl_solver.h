@@ -1078,6 +1078,50 @@ k_cross_dots(const double* __restrict__ U, const double* __restrict__ V, int D, 
     if (threadIdx.x == 0) out[((size_t)v * D + a) * D + b] = acc;
 }
 
+// The same with a 4 x 8 block of (a, b) pairs per workgroup: every loaded value
+// feeds 8 (or 4) multiply-adds, and a row of U / V is read D/8 (D/4) times
+// instead of D times (the one-pair-per-workgroup form above re-reads both
+// operands D times: 20.8 GB per top row at C5).
+//   grid (ceil(D / 4) * ceil(D / 8), nvec)
+#define RL_XD_A 4
+#define RL_XD_B 8
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_cross_dots_tiled(const double* __restrict__ U, const double* __restrict__ V, int D, int m,
+                   double* __restrict__ out) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int nbb = (D + RL_XD_B - 1) / RL_XD_B;
+    const int a0 = (blockIdx.x / nbb) * RL_XD_A, b0 = (blockIdx.x % nbb) * RL_XD_B;
+    const int v = blockIdx.y;
+    const double* u = U + (size_t)v * D * m;
+    const double* w = V + (size_t)v * D * m;
+    double acc[RL_XD_A][RL_XD_B];
+#pragma unroll
+    for (int a = 0; a < RL_XD_A; ++a)
+#pragma unroll
+        for (int b = 0; b < RL_XD_B; ++b) acc[a][b] = 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        double ua[RL_XD_A], wb[RL_XD_B];
+        // (rows past D are read from the last valid row and never stored)
+#pragma unroll
+        for (int a = 0; a < RL_XD_A; ++a) ua[a] = u[(size_t)(a0 + a < D ? a0 + a : D - 1) * m + i];
+#pragma unroll
+        for (int b = 0; b < RL_XD_B; ++b) wb[b] = w[(size_t)(b0 + b < D ? b0 + b : D - 1) * m + i];
+#pragma unroll
+        for (int a = 0; a < RL_XD_A; ++a)
+#pragma unroll
+            for (int b = 0; b < RL_XD_B; ++b) acc[a][b] = fma(ua[a], wb[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < RL_XD_A; ++a)
+#pragma unroll
+        for (int b = 0; b < RL_XD_B; ++b) {
+            const double s = block_reduce_sum(acc[a][b], red);
+            if (threadIdx.x == 0 && a0 + a < D && b0 + b < D)
+                out[((size_t)v * D + a0 + a) * D + b0 + b] = s;
+        }
+}
+
 // out[v][d] = sum_{i in segment d} U[v][i] * V[v][i];  segments given by
 // offsets[D+1] (per-output slices of a data-space vector)   grid (D, nvec)
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)

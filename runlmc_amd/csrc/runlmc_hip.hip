@@ -2245,8 +2245,14 @@ extern "C" int rl_cross_dots(const double* U, const double* V, int nvec, int D, 
     if (!U || !V || !out) return fail(RL_EINVAL, "rl_cross_dots: NULL argument");
     if (nvec < 0 || D < 1 || m < 1) return fail(RL_EINVAL, "rl_cross_dots: bad sizes");
     if (nvec == 0) return RL_OK;
-    RL_LAUNCH(k_cross_dots, dim3(D * D, nvec), dim3(RL_SOLVER_THREADS),
-              RL_SOLVER_THREADS * sizeof(double), (hipStream_t)stream, U, V, D, m, out);
+    if (D >= 4 && m >= 1024) {
+        const unsigned nb = ((D + RL_XD_A - 1) / RL_XD_A) * ((D + RL_XD_B - 1) / RL_XD_B);
+        RL_LAUNCH(k_cross_dots_tiled, dim3(nb, nvec), dim3(RL_SOLVER_THREADS),
+                  RL_SOLVER_THREADS * sizeof(double), (hipStream_t)stream, U, V, D, m, out);
+    } else {
+        RL_LAUNCH(k_cross_dots, dim3(D * D, nvec), dim3(RL_SOLVER_THREADS),
+                  RL_SOLVER_THREADS * sizeof(double), (hipStream_t)stream, U, V, D, m, out);
+    }
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

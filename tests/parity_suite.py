@@ -750,6 +750,22 @@ def check_row_kernel_shapes(shapes=None):
             os.environ['RUNLMC_POW2_ONLY'] = saved
 
 
+def check_cross_dots():
+    """D x D Gram matrices of the batched gradient (rl_cross_dots): the tiled
+    kernel (D >= 4, m >= 1024) and the one-pair-per-workgroup kernel against
+    NumPy, including D that is not a multiple of the 4 x 8 tile."""
+    from runlmc_amd import _lib
+    from runlmc_amd._native import cross_dots
+    lib = _lib.get_library()
+    dev = lib.torch_device(0)
+    rng = np.random.RandomState(8)
+    for D, m, k in ((5, 1500, 3), (10, 1024, 2), (13, 2100, 2), (3, 4000, 2), (4, 300, 3), (16, 1100, 1)):
+        U, V = rng.randn(k, D * m), rng.randn(k, D * m)
+        P = cross_dots(lib, torch.from_numpy(U).to(dev), torch.from_numpy(V).to(dev), D, m)
+        ref = np.einsum('vai,vbi->vab', U.reshape(k, D, m), V.reshape(k, D, m))
+        _close(P.cpu().numpy(), ref, 1e-12)
+
+
 def check_chunked_product():
     """A batched grid product split into several chunks of intermediates, on one
     stream and on two (RUNLMC_CHUNK_MB / RUNLMC_TWO_STREAMS), against the

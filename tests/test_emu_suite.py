@@ -151,3 +151,7 @@ def test_rank_above_outputs():
 
 def test_row_kernel_shapes():
     ps.check_row_kernel_shapes()
+
+
+def test_cross_dots():
+    ps.check_cross_dots()

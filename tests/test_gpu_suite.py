@@ -128,3 +128,7 @@ def test_row_kernel_shapes():
     ps.check_row_kernel_shapes([(4, 3, 5004, 5), (3, 2, 20001, 3), (2, 2, 30000, 3),
                                 (2, 1, 70000, 2), (16, 2, 66000, 3), (13, 2, 40000, 2),
                                 (12, 3, 26000, 4), (9, 1, 12000, 5), (1, 1, 9000, 7)])
+
+
+def test_cross_dots():
+    ps.check_cross_dots()
