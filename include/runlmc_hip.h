@@ -60,6 +60,21 @@ int rl_gridop_create_2d(int device, int D, int m1, int m2, int max_tops, rl_grid
 int rl_gridop_destroy(rl_gridop* g);
 /* L = N1*N2 and tile parameters actually chosen (any pointer may be NULL). */
 int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int* rowsB);
+/* Which form of the product the CURRENT parameters run in (valid after a
+ * rl_gridop_set_* call; any pointer may be NULL):
+ *   *rank          0: transform (FFT) kernels only;  r > 0: every top row is,
+ *                  to 2e-13 of its products, Phi C_q Phi^T with Phi the r
+ *                  orthonormal polynomials on the grid, and batches of at
+ *                  least *min_elements = nvec*D*m elements run as
+ *                  project -> r x r map -> expand (csrc/rl_lowrank.h) -- the
+ *                  same operator of bttb.py:144-148, verified per top row
+ *                  against the transform kernels inside the set call.
+ *   RUNLMC_NO_LOWRANK=1 keeps every handle on the transform kernels.        */
+int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements);
+/* Moves that batch gate for this handle (0: every batch; < 0: back to the
+ * default, 2^23 elements or RUNLMC_LR_MIN).  Below the gate the polynomial
+ * form is slower than the transform kernels (too few workgroups).           */
+int rl_gridop_set_form_gate(rl_gridop* g, long long min_elements);
 /* Parameters of the LMC kernel, in the reference's own factored form
  * B_q = A_q^T A_q + diag(kappa_q) (runlmc/lmc/functional_kernel.py:280-287):
  *   tops        host [Q][m]   first rows k_q(grid distances)

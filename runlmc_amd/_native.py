@@ -74,6 +74,19 @@ class GridOp:
     def width(self):
         return self.D * self.m
 
+    def form(self):
+        """(rank, min_elements): rank r > 0 when the current parameters run
+        batches of >= min_elements elements in the polynomial-subspace form
+        (csrc/rl_lowrank.h), 0 when on the transform kernels only."""
+        r, n = ctypes.c_int(), ctypes.c_longlong()
+        self.lib.call('rl_gridop_form', self._h, ctypes.byref(r), ctypes.byref(n))
+        return r.value, n.value
+
+    def set_form_gate(self, min_elements):
+        """Smallest batch (nvec*D*m elements) run in the polynomial form;
+        0 = every batch, negative = the library default."""
+        self.lib.call('rl_gridop_set_form_gate', self._h, int(min_elements))
+
     def _tops(self, tops):
         tops = as_f64(tops)
         if tops.ndim != 2 or tops.shape[1] != self.m:

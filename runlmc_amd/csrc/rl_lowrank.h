@@ -1,0 +1,228 @@
+// Polynomial-subspace form of the grid product for SMOOTH kernels.
+//
+// A Toeplitz block T_q[i][j] = k_q(|x_i - x_j|) of a kernel that is smooth over
+// the whole grid (an RBF or periodic kernel whose length scale is not small
+// against the grid's extent -- the reference's synthetic benchmarks draw
+// inverse length scales from logspace(0, 1, Q) on the unit interval) is
+// numerically of very low rank on that grid: with Phi (m x r) the orthonormal
+// polynomials of degree < r on the grid points,
+//
+//     T_q = Phi C_q Phi^T   to roundoff,   C_q = Phi^T T_q Phi   (r x r),
+//
+// r = 24 for every block of BASELINE's C2 and C5 (measured: 1e-14 relative).
+// Then  K_UU X = Phi [ sum_q B_q (x) C_q ] Phi^T X :  one pass over X, a tiny
+// dense map on r coefficients per output, one pass over Y -- the ALGORITHMIC
+// traffic of the product (read x, write y) and r multiply-adds per element each
+// way, instead of four passes over zero-padded complex intermediates.
+//
+// The form is used only when it is as exact as the transform path: for every
+// top row the host verifies, on random vectors and against the FFT kernels of
+// this same handle, that the two products agree to RL_LR_TOL of the result's
+// largest entry; otherwise -- Matern kernels, short length scales, 2-D grids --
+// the handle stays on the FFT path (rl_kernels2/3.h).  Reference semantics
+// either way: runlmc/linalg/bttb.py:144-148, kronecker.py:39-46.
+#pragma once
+#include "rl_device.h"
+
+#define RL_LR_RMAX 48          // basis functions generated per handle
+#define RL_LR_T 32             // grid points per lane and projection chunk (chunk = 64 T)
+#define RL_LR_G 4              // ... requested G lane-steps ahead of their use
+#define RL_LR_RB 2             // rows per wave of the projection
+#define RL_LR_WAVES 4          // waves per projection workgroup
+#define RL_LR_ROWS (RL_LR_RB * RL_LR_WAVES)   // rows per projection workgroup
+#define RL_LR_TOL 2e-13        // accepted |y_fft - y_lr| / max|y_fft| at set time
+
+// The basis is never read from memory by the two streaming kernels: a lane
+// evaluates the UNNORMALISED polynomials of its grid point by the three-term
+// recurrence  q_0 = 1, q_{j+1} = s q_j - beta_j q_{j-1}  (Phi_j = nu_j q_j; beta,
+// nu from the host's long-double recurrence; the normalisation nu is applied to
+// the r coefficients in k_lr_mix).  Evaluated in fp64 the recurrence reproduces
+// the long-double basis to 1e-14 of its largest entry (degree 48, m = 5e3 .. 1e5).
+__device__ __forceinline__ double lr_point(int n, int m) {
+    return m > 1 ? fma(2.0 / (double)(m - 1), (double)n, -1.0) : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// k_lr_project<R>: part[chunk][row][j] = sum_{n in chunk} q_j(n) X[row][n],
+// rows = the nrows contiguous length-m blocks of X (vector-major, output-minor).
+//   grid (nchunks, ceil(nrows / RL_LR_ROWS))   block 64 * RL_LR_WAVES
+// Lanes run along the grid (every load is 512 contiguous bytes of one row), a
+// wave owns RL_LR_RB rows and keeps their RB x R running sums in registers over
+// the RL_LR_T points of each lane; the 64 lanes are summed once per chunk
+// through LDS.  x values are requested RL_LR_G lane-steps before their use.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(64 * RL_LR_WAVES)
+k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __restrict__ beta,
+             double* __restrict__ part) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);       // [WAVES][R][65]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.y * RL_LR_ROWS + wave * RL_LR_RB;
+    const int n_begin = blockIdx.x * (64 * RL_LR_T);
+    const double* xrow[RL_LR_RB];
+#pragma unroll
+    for (int r = 0; r < RL_LR_RB; ++r)
+        xrow[r] = X + (size_t)(row0 + r < nrows ? row0 + r : nrows - 1) * m;
+    double acc[RL_LR_RB][R];
+#pragma unroll
+    for (int r = 0; r < RL_LR_RB; ++r)
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc[r][j] = 0.0;
+    constexpr int NG = RL_LR_T / RL_LR_G;
+    double xa[RL_LR_G][RL_LR_RB], xb[RL_LR_G][RL_LR_RB];
+    // unconditional loads from clamped points; points past the end count as zero
+    auto request = [&](double (*xs)[RL_LR_RB], int g) {
+#pragma unroll
+        for (int k = 0; k < RL_LR_G; ++k) {
+            const int n = n_begin + lane + 64 * (g * RL_LR_G + k);
+            const int nc = n < m ? n : m - 1;
+#pragma unroll
+            for (int r = 0; r < RL_LR_RB; ++r) xs[k][r] = xrow[r][nc];
+        }
+    };
+    auto consume = [&](double (*xs)[RL_LR_RB], int g) {
+#pragma unroll
+        for (int k = 0; k < RL_LR_G; ++k) {
+            const int n = n_begin + lane + 64 * (g * RL_LR_G + k);
+            const double s = lr_point(n, m);
+            const double live = n < m ? 1.0 : 0.0;
+            double x[RL_LR_RB];
+#pragma unroll
+            for (int r = 0; r < RL_LR_RB; ++r) x[r] = xs[k][r] * live;
+            double qm = 0.0, q = 1.0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+#pragma unroll
+                for (int r = 0; r < RL_LR_RB; ++r) acc[r][j] = fma(q, x[r], acc[r][j]);
+                const double qn = fma(s, q, -beta[j] * qm);
+                qm = q;
+                q = qn;
+            }
+        }
+    };
+    static_assert(NG % 2 == 0, "ping-pong over pairs of groups");
+    request(xa, 0);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+        request(xb, g + 1);
+        consume(xa, g);
+        request(xa, g + 2 < NG ? g + 2 : g);      // (the last one is a repeat, unused)
+        consume(xb, g + 1);
+    }
+    // sum over the 64 lanes, one row at a time: [wave][j][lane] in LDS, then one
+    // thread per (wave, j)
+#pragma unroll
+    for (int r = 0; r < RL_LR_RB; ++r) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) red[(wave * R + j) * 65 + lane] = acc[r][j];
+        __syncthreads();
+        for (int e = tid; e < RL_LR_WAVES * R; e += 64 * RL_LR_WAVES) {
+            const int w = e / R, j = e - w * R;
+            const double* src = red + (size_t)e * 65;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int l = 0; l < 64; l += 4) {
+                s0 += src[l];
+                s1 += src[l + 1];
+                s2 += src[l + 2];
+                s3 += src[l + 3];
+            }
+            const int row = blockIdx.y * RL_LR_ROWS + w * RL_LR_RB + r;
+            if (row < nrows)
+                part[((size_t)blockIdx.x * nrows + row) * R + j] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_lr_mix: per vector, sum the projection's partial results over the chunks and
+// apply the dense coefficient map
+//     Zhat[a][i] = nu_i sum_q sum_b B_q[a][b] sum_j C_q[i][j] (nu_j Z[b][j])
+// (nu: the basis normalisation, see lr_point above).
+//   grid (nvec)   block 256   LDS: Z [D][r] + W [Q][D][r]
+//   Cq [Q][r][r], Bq [Q][D][D] (single-top products pass Q = 1, B = identity)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, int Q,
+         const double* __restrict__ Cq, const double* __restrict__ Bq,
+         const double* __restrict__ nu, double* __restrict__ Zhat) {
+    RL_SMEM(smem);
+    double* Z = reinterpret_cast<double*>(smem);          // [D][r]
+    double* W = Z + D * r;                                 // [Q][D][r]
+    const int v = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int nrows = nvec * D;
+    for (int e = tid; e < D * r; e += nthr) {
+        // chunks summed in a fixed order (eight interleaved running sums, so that
+        // eight loads are in flight; the same order on every run and every rank)
+        const double* src = part + (size_t)v * D * r + e;
+        const size_t stride = (size_t)nrows * r;
+        double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int c = 0;
+        for (; c + 8 <= nchunks; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(c + u) * stride];
+        }
+        for (; c < nchunks; ++c) s8[0] += src[(size_t)c * stride];
+        Z[e] = nu[e % r] * (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
+    }
+    __syncthreads();
+    for (int e = tid; e < Q * D * r; e += nthr) {
+        const int q = e / (D * r), rem = e - q * D * r;
+        const int b = rem / r, i = rem - b * r;
+        const double* c = Cq + ((size_t)q * r + i) * r;
+        const double* z = Z + b * r;
+        double s = 0.0;
+        for (int j = 0; j < r; ++j) s = fma(c[j], z[j], s);
+        W[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < D * r; e += nthr) {
+        const int a = e / r, i = e - a * r;
+        double s = 0.0;
+        for (int q = 0; q < Q; ++q) {
+            const double* bq = Bq + ((size_t)q * D + a) * D;
+            for (int b = 0; b < D; ++b) s = fma(bq[b], W[(q * D + b) * r + i], s);
+        }
+        Zhat[((size_t)v * D + a) * r + i] = nu[i] * s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_lr_expand<R>: Y[row][n] = sum_j q_j(n) Zhat[row][j]  (Zhat carries nu).
+//   grid (ceil(m / 256), ceil(nrows / rows_per_block))   block 256
+// A thread owns one grid point: its R basis values (recurrence, once) stay in
+// registers for all the rows of the block, the coefficients of a row are the
+// same for every lane.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(256)
+k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __restrict__ beta,
+            int rows_per_block, double* __restrict__ Y) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row0 = blockIdx.y * rows_per_block;
+    const int row1 = row0 + rows_per_block < nrows ? row0 + rows_per_block : nrows;
+    const double s = lr_point(n < m ? n : m - 1, m);
+    double p[R];
+    {
+        double qm = 0.0, q = 1.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            p[j] = q;
+            const double qn = fma(s, q, -beta[j] * qm);
+            qm = q;
+            q = qn;
+        }
+    }
+    for (int row = row0; row < row1; ++row) {
+        const double* z = Zhat + (size_t)row * R;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j + 1 < R; j += 2) {
+            s0 = fma(z[j], p[j], s0);
+            s1 = fma(z[j + 1], p[j + 1], s1);
+        }
+        if (n < m) Y[(size_t)row * m + n] = s0 + s1;
+    }
+}

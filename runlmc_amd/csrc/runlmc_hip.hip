@@ -13,6 +13,7 @@
 #include "rl_kernels.h"
 #include "rl_kernels2.h"
 #include "rl_kernels3.h"
+#include "rl_lowrank.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -247,6 +248,23 @@ struct rl_gridop {
     int code1 = 0, code2 = 0;   // fused_code(N1), fused_code(N2); both != 0 -> v2 kernels
     bool v2 = false;
     bool rows3 = false;         // row kernel = k3_rows_mix (plan2 = {RA, RB, 2})
+    // polynomial-subspace form for smooth kernels (rl_lowrank.h)
+    bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
+    bool lr_ok = false;         // verified against the FFT path for the current parameters
+    bool lr_bypass = false;     // set while the FFT path is wanted (set-time verification)
+    int lr_r = 0;               // basis size in use (24 / 32 / 48)
+    size_t lr_min = 0;          // batches below this many elements stay on the FFT path
+    double* lr_beta = nullptr;  // dev [RL_LR_RMAX] recurrence coefficients
+    double* lr_nu = nullptr;    // dev [RL_LR_RMAX] normalisation
+    double* lr_phiJ = nullptr;  // dev [RL_LR_RMAX][m]
+    double* lr_C = nullptr;     // dev [max_tops][r][r]
+    double* lr_B = nullptr;     // dev [max_tops][D][D]
+    double* lr_eye = nullptr;   // dev [D][D]
+    double* lr_part = nullptr;  // projection partial sums
+    size_t lr_part_cap = 0;
+    double* lr_zhat = nullptr;  // mixed coefficients [rows][r]
+    size_t lr_zhat_cap = 0;
+    double* lr_scr = nullptr;   // set-time scratch: 3 vectors of D*m + partial maxima
     double* mixtab = nullptr;   // dev [D + nfac][L]: dc rows then gs rows (k_mix_tables)
     size_t mixtab_rows = 0;     // rows allocated
     bool mixtab_ok = false;     // tables match the current parameters
@@ -404,6 +422,7 @@ static int launch1p(rl_gridop* g, int D, unsigned pairs, hipStream_t st, const d
 
 #define RL_MAX_D 16
 
+static size_t lr_min_elements();
 static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_tops,
                               rl_gridop** out);
 
@@ -511,6 +530,10 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
         rows_ok = true;
     }
     g->v2 = g->code1 != 0 && rows_ok && getenv("RUNLMC_FORCE_V1") == nullptr;
+    // polynomial-subspace form (rl_lowrank.h): 1-D grids long enough for the
+    // three-kernel FFT path, decided per parameter set by verification
+    g->lr_try = m1 == 0 && m >= 2048 && getenv("RUNLMC_NO_LOWRANK") == nullptr;
+    g->lr_min = lr_min_elements();
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
 
@@ -569,7 +592,8 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     (void)hipSetDevice(g->device);
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
-                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab};
+                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_C,
+                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -589,6 +613,19 @@ extern "C" int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int*
     if (N2) *N2 = g->N2;
     if (colsA) *colsA = g->colsA;
     if (rowsB) *rowsB = g->rowsB;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (rank) *rank = g->lr_ok ? g->lr_r : 0;
+    if (min_elements) *min_elements = (long long)g->lr_min;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_set_form_gate(rl_gridop* g, long long min_elements) {
+    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    g->lr_min = min_elements < 0 ? lr_min_elements() : (size_t)min_elements;
     return RL_OK;
 }
 
@@ -677,13 +714,18 @@ static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::ve
     return RL_OK;
 }
 
+static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vector<double>& W,
+                    const std::vector<int>& Qi, const std::vector<double>& kap);
+
 static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector<double>& A,
                       const std::vector<double>& W, const std::vector<int>& Qi,
                       const std::vector<double>& kap) {
     if ((int)W.size() > g->max_fac)
         return fail(RL_ELIMIT, "rl_gridop_set: total rank exceeds max_tops*D");
+    g->lr_ok = false;
     int rc = set_common(g, Q, tops);
     if (rc == RL_OK) rc = set_factors(g, A, W, Qi, kap);
+    if (rc == RL_OK) rc = lr_setup(g, A, W, Qi, kap);
     if (rc != RL_OK) g->Q = 0;          // no half-updated operator
     return rc;
 }
@@ -1111,6 +1153,228 @@ static bool wants_two_streams(const rl_gridop* g) {
                    : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
 }
 
+
+// ---------------------------------------------------------------------------
+// polynomial-subspace form of the grid product (rl_lowrank.h)
+// ---------------------------------------------------------------------------
+// Orthonormal polynomials of degree < RL_LR_RMAX on the m equispaced points of
+// [-1, 1] by the three-term (Stieltjes / Lanczos) recurrence
+//     b_{j+1} p_{j+1} = s p_j - b_j p_{j-1},   p_0 = 1 / sqrt(m)
+// in long double (the points are symmetric, so the diagonal coefficients vanish).
+// Measured: |Phi^T Phi - I| <= 1e-14 for 48 functions at m = 2048 ... 100 004.
+// Rows RL_LR_RMAX .. RL_LR_RMAX + RL_MAX_D of the function-major copy are zero
+// padding (the set-time products read whole vectors of D blocks).
+static int lr_make_basis(rl_gridop* g) {
+    const int m = g->m, R = RL_LR_RMAX;
+    std::vector<double> phiJ((size_t)(R + 16) * m, 0.0), beta(R), nu(R);
+    std::vector<long double> prev(m, 0.0L), cur(m), nxt(m);
+    const long double p0 = 1.0L / sqrtl((long double)m);
+    for (int n = 0; n < m; ++n) cur[n] = p0;
+    long double bj = 0.0L, nuj = p0;
+    for (int j = 0; j < R; ++j) {
+        for (int n = 0; n < m; ++n) phiJ[(size_t)j * m + n] = (double)cur[n];
+        // the kernels run the monic recurrence q_{j+1} = s q_j - b_j^2 q_{j-1},
+        // Phi_j = nu_j q_j with nu_{j+1} = nu_j / b_{j+1}
+        beta[j] = (double)(bj * bj);
+        nu[j] = (double)nuj;
+        long double nrm = 0.0L;
+        for (int n = 0; n < m; ++n) {
+            const long double sn = m > 1 ? -1.0L + 2.0L * n / (m - 1) : 0.0L;
+            nxt[n] = sn * cur[n] - bj * prev[n];
+            nrm += nxt[n] * nxt[n];
+        }
+        bj = sqrtl(nrm);
+        if (!(bj > 0.0L)) return fail(RL_EINVAL, "polynomial basis degenerate");
+        nuj /= bj;
+        for (int n = 0; n < m; ++n) {
+            prev[n] = cur[n];
+            cur[n] = nxt[n] / bj;
+        }
+    }
+    RL_TRY(upload(&g->lr_phiJ, phiJ));
+    RL_TRY(upload(&g->lr_beta, beta));
+    RL_TRY(upload(&g->lr_nu, nu));
+    return RL_OK;
+}
+
+// projection chunks: 64 * RL_LR_T grid points each
+static int lr_nchunks(const rl_gridop* g) { return (g->m + 64 * RL_LR_T - 1) / (64 * RL_LR_T); }
+static size_t lr_part_need(const rl_gridop* g, int nvec) {
+    return (size_t)lr_nchunks(g) * nvec * g->D * RL_LR_RMAX;
+}
+static int lr_reserve(rl_gridop* g, int nvec) {
+    const size_t rows = (size_t)nvec * g->D;
+    const size_t need_part = lr_part_need(g, nvec), need_z = rows * RL_LR_RMAX;
+    if (g->lr_part_cap < need_part) {
+        if (g->lr_part) RL_HIP(hipFree(g->lr_part));
+        g->lr_part = nullptr;
+        g->lr_part_cap = 0;
+        RL_HIP(hipMalloc((void**)&g->lr_part, need_part * sizeof(double)));
+        g->lr_part_cap = need_part;
+    }
+    if (g->lr_zhat_cap < need_z) {
+        if (g->lr_zhat) RL_HIP(hipFree(g->lr_zhat));
+        g->lr_zhat = nullptr;
+        g->lr_zhat_cap = 0;
+        RL_HIP(hipMalloc((void**)&g->lr_zhat, need_z * sizeof(double)));
+        g->lr_zhat_cap = need_z;
+    }
+    return RL_OK;
+}
+
+// default gate: batches below this many elements stay on the transform path
+// (C2's 17 vectors: 20.7 us there against 75 us here -- 27 projection
+// workgroups on 256 CUs); RUNLMC_LR_MIN / rl_gridop_set_form_gate override it
+static size_t lr_min_elements() {
+    static const size_t v = [] {
+        const char* e = getenv("RUNLMC_LR_MIN");
+        return e ? (size_t)atoll(e) : (size_t)1 << 23;
+    }();
+    return v;
+}
+
+template <int R>
+static void lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) {
+    RL_LAUNCH((k_lr_project<R>), dim3(lr_nchunks(g), (nrows + RL_LR_ROWS - 1) / RL_LR_ROWS),
+              dim3(64 * RL_LR_WAVES), (size_t)RL_LR_WAVES * R * 65 * sizeof(double), st, X, nrows,
+              g->m, (const double*)g->lr_beta, g->lr_part);
+}
+
+template <int R>
+static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q, const double* Cq,
+                      const double* Bq, hipStream_t st) {
+    const int nrows = nvec * g->D;
+    lr_project<R>(g, X, nrows, st);
+    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
+              (const double*)g->lr_part, lr_nchunks(g), nvec, g->D, R, Q, Cq, Bq,
+              (const double*)g->lr_nu, g->lr_zhat);
+    // rows per expansion workgroup: the basis values of a point are generated once
+    // per workgroup, so few, tall row blocks (while the launch still fills the chip)
+    const int rpb = nrows >= 1024 ? 256 : 64;
+    RL_LAUNCH((k_lr_expand<R>), dim3((g->m + 255) / 256, (nrows + rpb - 1) / rpb), dim3(256), 0,
+              st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
+}
+
+// Y = Phi [sum_q B_q (x) C_q] Phi^T X for tops [q0, q0 + Q) with coupling Bq
+static int lr_apply(rl_gridop* g, const double* X, double* Y, int nvec, int q0, int Q,
+                    const double* Bq, hipStream_t st) {
+    const double* Cq = g->lr_C + (size_t)q0 * g->lr_r * g->lr_r;
+    switch (g->lr_r) {
+        case 24: lr_launch<24>(g, X, Y, nvec, Q, Cq, Bq, st); break;
+        case 32: lr_launch<32>(g, X, Y, nvec, Q, Cq, Bq, st); break;
+        case 48: lr_launch<48>(g, X, Y, nvec, Q, Cq, Bq, st); break;
+        default: return fail(RL_EINVAL, "low-rank path: bad basis size");
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
+                        hipStream_t stream);
+
+// Set-time: build C_q = Phi^T T_q Phi for every top row with the FFT kernels of
+// this handle and ACCEPT the polynomial form only if, for every top row, it
+// reproduces the FFT product of a random vector to RL_LR_TOL of the result's
+// largest entry (the D blocks of the vector are D independent trials).  Tries
+// r = 24, 32, 48; leaves lr_ok = false otherwise.
+static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vector<double>& W,
+                    const std::vector<int>& Qi, const std::vector<double>& kap) {
+    g->lr_ok = false;
+    if (!g->lr_try) return RL_OK;
+    const int D = g->D, m = g->m, Q = g->Q;
+    const size_t vec = (size_t)D * m;
+    if (!g->lr_phiJ) {
+        RL_TRY(lr_make_basis(g));
+        RL_HIP(hipMalloc((void**)&g->lr_C, (size_t)g->max_tops * RL_LR_RMAX * RL_LR_RMAX * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&g->lr_B, (size_t)g->max_tops * D * D * sizeof(double)));
+        std::vector<double> eye((size_t)D * D, 0.0);
+        for (int a = 0; a < D; ++a) eye[(size_t)a * D + a] = 1.0;
+        RL_TRY(upload(&g->lr_eye, eye));
+        // scratch: a fixed random vector, two results, the packed T Phi block
+        const size_t nvr = (RL_LR_RMAX + D - 1) / D;
+        RL_HIP(hipMalloc((void**)&g->lr_scr, (3 + nvr) * vec * sizeof(double)));
+        std::vector<double> xr(vec);
+        unsigned long long st = 0x9E3779B97F4A7C15ull;          // fixed seed: same trials every time
+        for (size_t i = 0; i < vec; ++i) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            xr[i] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+        }
+        RL_HIP(hipMemcpy(g->lr_scr, xr.data(), vec * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // dense coupling B_q = sum_{f of q} w_f a_f a_f^T + diag(kappa_q)
+    std::vector<double> B((size_t)Q * D * D, 0.0);
+    for (size_t f = 0; f < W.size(); ++f)
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b < D; ++b)
+                B[((size_t)Qi[f] * D + a) * D + b] += W[f] * A[f * D + a] * A[f * D + b];
+    for (int q = 0; q < Q; ++q)
+        for (int a = 0; a < D; ++a) B[((size_t)q * D + a) * D + a] += kap[(size_t)q * D + a];
+    RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
+
+    double* xr = g->lr_scr;
+    double* y1 = xr + vec;
+    double* y2 = y1 + vec;
+    double* tphi = y2 + vec;
+    hipStream_t st = nullptr;
+    std::vector<double> h1(vec), h2(vec), hnu(RL_LR_RMAX);
+    RL_HIP(hipMemcpy(hnu.data(), g->lr_nu, hnu.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r : {24, 32, 48}) {
+        g->lr_r = r;
+        const int nvr = (r + D - 1) / D;
+        RL_TRY(lr_reserve(g, std::max(nvr, 1)));
+        bool ok = true;
+        for (int q = 0; q < Q && ok; ++q) {
+            MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones,
+                         nullptr, nullptr};
+            // rows j of tphi = T_q Phi_j (the function-major basis IS a batch of vectors)
+            g->lr_bypass = true;
+            int rc = mvm_with_mix(g, mp, g->lr_phiJ, tphi, nvr, st);
+            g->lr_bypass = false;
+            if (rc != RL_OK) return rc;
+            // C_q[i][j] = Phi_i . (T_q Phi_j): the projection of those rows
+            const int nrows = nvr * D;
+            switch (r) {
+                case 24: lr_project<24>(g, tphi, nrows, st); break;
+                case 32: lr_project<32>(g, tphi, nrows, st); break;
+                default: lr_project<48>(g, tphi, nrows, st); break;
+            }
+            const int nparts = lr_nchunks(g);
+            std::vector<double> part((size_t)nparts * nrows * r);
+            RL_HIP(hipMemcpy(part.data(), g->lr_part, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            std::vector<double> C((size_t)r * r, 0.0);
+            for (int c = 0; c < nparts; ++c)
+                for (int j = 0; j < r; ++j)
+                    for (int i = 0; i < r; ++i)
+                        C[(size_t)i * r + j] += hnu[i] * part[((size_t)c * nrows + j) * r + i];
+            for (int i = 0; i < r; ++i)                          // T_q is symmetric
+                for (int j = i + 1; j < r; ++j) {
+                    const double v = 0.5 * (C[(size_t)i * r + j] + C[(size_t)j * r + i]);
+                    C[(size_t)i * r + j] = C[(size_t)j * r + i] = v;
+                }
+            RL_HIP(hipMemcpy(g->lr_C + (size_t)q * r * r, C.data(), C.size() * sizeof(double), hipMemcpyHostToDevice));
+            // trial: T_q xr through both forms
+            g->lr_bypass = true;
+            rc = mvm_with_mix(g, mp, xr, y1, 1, st);
+            g->lr_bypass = false;
+            if (rc != RL_OK) return rc;
+            RL_TRY(lr_apply(g, xr, y2, 1, q, 1, g->lr_eye, st));
+            RL_HIP(hipMemcpy(h1.data(), y1, vec * sizeof(double), hipMemcpyDeviceToHost));
+            RL_HIP(hipMemcpy(h2.data(), y2, vec * sizeof(double), hipMemcpyDeviceToHost));
+            double dmax = 0.0, ymax = 0.0;
+            for (size_t i = 0; i < vec; ++i) {
+                dmax = std::max(dmax, std::fabs(h1[i] - h2[i]));
+                ymax = std::max(ymax, std::fabs(h1[i]));
+            }
+            ok = dmax <= RL_LR_TOL * ymax || (ymax == 0.0 && dmax == 0.0);
+        }
+        if (ok) {
+            g->lr_ok = true;
+            return RL_OK;
+        }
+    }
+    return RL_OK;
+}
+
 static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
                         hipStream_t stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
@@ -1120,6 +1384,30 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_HIP(hipSetDevice(g->device));
+    if (g->lr_ok && !g->lr_bypass && (size_t)nvec * g->D * g->m >= g->lr_min) {
+        // smooth kernels, a batch large enough to fill the chip with projection
+        // workgroups: polynomial-subspace form, verified at set time
+        bool ready = g->lr_part_cap >= lr_part_need(g, nvec) &&
+                     g->lr_zhat_cap >= (size_t)nvec * g->D * RL_LR_RMAX;
+        if (!ready) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = stream != nullptr &&
+                                   hipStreamIsCapturing(stream, &cs) == hipSuccess &&
+                                   cs != hipStreamCaptureStatusNone;
+            if (!capturing) {            // (nothing may be allocated inside a capture)
+                RL_TRY(lr_reserve(g, nvec));
+                ready = true;
+            }
+        }
+        if (ready) {
+            trace_once("grid product: polynomial-subspace form (k_lr_project / mix / expand)");
+            const bool single = mp.nfac == 0 && mp.Q == 1 && mp.kappa == g->ones;
+            if (single)
+                return lr_apply(g, X, Y, nvec, (int)((mp.spec - g->spec) / g->L), 1, g->lr_eye,
+                                stream);
+            return lr_apply(g, X, Y, nvec, 0, g->Q, g->lr_B, stream);
+        }
+    }
     if (g->v1p && (nvec >= g->v1p_min || g->D <= 2)) {
         // short grid, enough pairs to fill the chip with one workgroup per pair
         // (measured: D=13, m=238: 21 vs 46 us at 256 vectors, 95 vs 228 us at 2048,
@@ -2004,6 +2292,9 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     RL_TRY(solver_alloc(s, w, need, nrhs, n, nblk, st));
     // everything the operator product allocates lazily must exist before capture
     RL_TRY(ski_reserve(s, nrhs));
+    if (s->g->lr_ok) RL_TRY(lr_reserve(s->g, nrhs));
+    for (const SkiTerm& t : s->extra)
+        if (t.g->lr_ok) RL_TRY(lr_reserve(t.g, nrhs));
     RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
     if (s->g->v2 && ((size_t)nrhs + 1) / 2 > s->g->chunk_pairs && wants_two_streams(s->g))
         RL_TRY(prepare_two_streams(s->g, s->g->chunk_pairs));

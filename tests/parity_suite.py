@@ -750,6 +750,89 @@ def check_row_kernel_shapes(shapes=None):
             os.environ['RUNLMC_POW2_ONLY'] = saved
 
 
+def check_polynomial_form():
+    """Smooth kernels on a long 1-D grid run as project -> r x r map -> expand
+    (rl_lowrank.h) once the batch is large enough.  Checked here: (1) RBF /
+    periodic tops are accepted (rank 24..48) and the product -- LMC, dense B,
+    single top, odd batch, m not a multiple of the 2048-point chunk -- matches
+    the oracle to the product tolerance and the transform kernels of the same
+    handle (batch below the gate) to 1e-12; (2) a Matern-3/2 top or a short
+    length scale is REJECTED at set time (rank 0) and the product is still
+    right; (3) parameters that flip between the two at successive set calls;
+    (4) RUNLMC_NO_LOWRANK keeps a handle on the transform kernels."""
+    from runlmc_amd._native import GridOp
+    knobs = ('RUNLMC_NO_LOWRANK',)
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    rng = np.random.RandomState(21)
+    try:
+        for D, Q, m, k in ((3, 2, 2500, 5), (2, 3, 4100, 2)):
+            x = np.linspace(0, 1, m)
+            smooth = np.array([np.exp(-0.5 * (1 + 2.0 * q) * x ** 2) for q in range(Q)])
+            smooth[Q - 1] = np.exp(-2 * np.sin(np.pi * x / 1.7) ** 2 / 1.3 ** 2)    # periodic
+            rough = smooth.copy()
+            rough[0] = (1 + np.sqrt(3) * 4 * x) * np.exp(-np.sqrt(3) * 4 * x)       # Matern-3/2
+            short = smooth.copy()
+            short[0] = np.exp(-0.5 * 4000.0 * x ** 2)
+            A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+            kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+            Bs = ops.coreg_mats(A, kap)
+            X = rng.randn(k, D * m)
+
+            def oracle(tops, rows=X):
+                toeps = [ops.BTTBOracle(t) for t in tops]
+                return np.array([ops.grid_sum_matvec(Bs, toeps, r) for r in rows])
+
+            g = GridOp(D, m, Q)
+            g.set_lmc(smooth, A, kap)
+            rank, gate = g.form()
+            assert rank in (24, 32, 48), rank
+            assert gate > k * D * m          # default gate: these batches stay on the FFT path
+            fft = g.matmat_host(X)
+            g0 = g
+            ref = oracle(smooth)
+            _close(fft, ref)
+            low = _poly_product(g0, X)
+            _close(low, ref)
+            _close(low, fft, 1e-12)
+            g0.set_dense(smooth, np.array(Bs))
+            _close(_poly_product(g0, X), ref)
+            one = _poly_product(g0, X[:1], top=Q - 1)[0]
+            _close(one, np.concatenate([ops.BTTBOracle(smooth[Q - 1]).matvec(r)
+                                        for r in X[0].reshape(D, m)]))
+            for bad in (rough, short):
+                g0.set_lmc(bad, A, kap)
+                assert g0.form()[0] == 0
+                _close(g0.matmat_host(X), oracle(bad))
+            g0.set_lmc(smooth, A, kap)       # and back
+            assert g0.form()[0] == rank
+            _close(_poly_product(g0, X), ref)
+            os.environ['RUNLMC_NO_LOWRANK'] = '1'
+            g1 = GridOp(D, m, Q)
+            g1.set_lmc(smooth, A, kap)
+            assert g1.form()[0] == 0
+            assert np.array_equal(g1.matmat_host(X), fft)
+            for kn in knobs:
+                os.environ.pop(kn, None)
+        # a short grid is never eligible
+        gs = GridOp(2, 500, 1)
+        gs.set_lmc(np.exp(-np.linspace(0, 1, 500) ** 2)[None], [rng.randn(1, 2)], [np.ones(2)])
+        assert gs.form()[0] == 0
+    finally:
+        for kn in knobs:
+            os.environ.pop(kn, None)
+            if saved[kn] is not None:
+                os.environ[kn] = saved[kn]
+
+
+def _poly_product(g, X, top=None):
+    """g.matmat_host with the batch gate lifted for this call."""
+    g.set_form_gate(0)
+    try:
+        return g.matmat_host(X, top=top)
+    finally:
+        g.set_form_gate(-1)
+
+
 def check_cross_dots():
     """D x D Gram matrices of the batched gradient (rl_cross_dots): the tiled
     kernel (D >= 4, m >= 1024) and the one-pair-per-workgroup kernel against

@@ -132,3 +132,7 @@ def test_row_kernel_shapes():
 
 def test_cross_dots():
     ps.check_cross_dots()
+
+
+def test_polynomial_form():
+    ps.check_polynomial_form()
