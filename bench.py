@@ -328,14 +328,17 @@ def time_steps(fn, steps, warmup, world, dev):
     return wall_ms / steps, e0.elapsed_time(e1) / steps
 
 
-def measured_traffic(config, batch):
+def measured_traffic(config, batch, form='fft'):
     """HBM-side bytes per step of the grid product from this round's PMC
-    passes (tools/pmc.sh -> profiles/r02/traffic.json), or (None, None)."""
+    passes (tools/pmc.sh -> profiles/r02/traffic.json), or (None, None).
+    Entries are keyed config:batch for the transform kernels and
+    config:batch:poly for the polynomial form."""
     try:
         table = json.load(open(TRAFFIC_FILE))
     except (OSError, ValueError):
         return None, None
-    e = table.get('%s:%d' % (config, batch))
+    key = '%s:%d' % (config, batch) + ('' if form == 'fft' else ':' + form)
+    e = table.get(key)
     return (e['bytes_per_step'], e['source']) if e else (None, None)
 
 
@@ -423,7 +426,16 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
     mvms = batch * world / (wall_ms * 1e-3)
     alg = synth.algorithmic_bytes_grid_mvm(D, Q, p.m, g.L, batch)
     achieved = alg / (wall_ms * 1e-3) / 1e9
-    traffic, source = measured_traffic(name, batch)
+    # which form the product ran in: the polynomial-subspace form (smooth
+    # kernels, batch above the gate; csrc/rl_lowrank.h) or the transform kernels
+    rank_poly, gate = g.form()
+    poly = rank_poly > 0 and batch * D * p.m >= gate
+    traffic, source = measured_traffic(name, batch, 'poly' if poly else 'fft')
+    kernel = ('grid MVM, polynomial-subspace form (k_lr_project -> k_lr_mix -> k_lr_expand, '
+              'rank %d, accepted at set time against the transform kernels), D=%d'
+              % (rank_poly, D)) if poly else (
+        'grid MVM (column transforms + row transforms with the D x D mix + adjoint '
+        'column transforms), D=%d' % D)
     out = {
         'value': mvms, 'ms_per_step': wall_ms,
         'config': {'workload': '%s synthetic D=%d Q=%d R=%d m=%d (grid %d, L=%d) '
@@ -434,14 +446,29 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'traffic_source': source,
-                     'kernel': 'grid MVM (column transforms + row transforms with the '
-                               'D x D mix + adjoint column transforms), D=%d' % D,
+                     'kernel': kernel, 'form': 'poly' if poly else 'fft',
                      'algorithmic_bytes_per_step': alg,
                      'clock': 'wall, same region as value',
                      'device_event_ms_per_step': ev_ms},
     }
     if traffic is not None:
         out['roofline']['traffic_GBps'] = traffic / (wall_ms * 1e-3) / 1e9
+
+    if poly:
+        # the same product forced onto the transform (FFT) kernels, same clock:
+        # what Matern / short-length-scale kernels and 2-D grids run
+        g.set_form_gate(1 << 62)
+        f_ms, f_ev = time_steps(lambda: g.mvm(X, out=Y), steps, warmup, world, dev)
+        g.set_form_gate(-1)
+        f_ms = max_over_ranks(f_ms, world, dev)
+        f_traffic, f_source = measured_traffic(name, batch, 'fft')
+        out['transform_kernels'] = {
+            'mvm_per_s': batch * world / (f_ms * 1e-3), 'ms_per_step': f_ms,
+            'roofline_frac': alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'traffic': f_traffic, 'traffic_source': f_source,
+            'device_event_ms_per_step': max_over_ranks(f_ev, world, dev),
+            'what': 'the same product with the polynomial form switched off '
+                    '(rl_gridop_set_form_gate): k2_cols_fwd -> k3_rows_mix -> k2_cols_inv'}
 
     if not args.no_full:
         out['full_mvm'] = time_full_operator(g, p, batch, gen, steps, world, dev, alg)

@@ -479,7 +479,7 @@ k_spmv_wide(const int* __restrict__ indptr, const int* __restrict__ indices,
 }
 
 // ---------------------------------------------------------------------------
-// k_spmv_wt_staged<VB>: W^T x for LARGE batches when W^T has the consecutive-
+// k_spmv_wt_staged<VB, XPT>: W^T x for LARGE batches when W^T has the consecutive-
 // range structure (SkiTerm::WT_lo: the entries of grid row r multiply the data
 // rows lo[r], lo[r] + 1, ...; lo is non-decreasing).  The data range of a
 // workgroup's RL_THREADS grid rows is then one contiguous piece of every
@@ -488,15 +488,21 @@ k_spmv_wide(const int* __restrict__ indptr, const int* __restrict__ indices,
 // data points near the grid point) -- are summed out of LDS.  One phase of
 // global loads per wavefront instead of one per group of four entries of its
 // longest row (k_spmv), same summation order, same results.
-//   grid (ceil(nrows / RL_THREADS), ceil(nvec / VB))
+// A workgroup walks `vgroups` groups of VB vectors with the SAME rows: weights,
+// row pointers and ranges are read once for all of them, and the pieces of the
+// next group travel from memory into registers (XPT values per thread and
+// vector, xcap <= XPT * RL_THREADS) while the current group is summed out of
+// LDS and stored -- loads, sums and stores of a workgroup overlap instead of
+// taking turns (measured at C5, 129 vectors: DESIGN.md).
+//   grid (ceil(nrows / RL_THREADS), ceil(ceil(nvec / VB) / vgroups))
 //   LDS: VB * xcap doubles (vector pieces) + ecap doubles (weights); the host
 //   guarantees every workgroup's range <= xcap and entries <= ecap
 // ---------------------------------------------------------------------------
-template <int VB>
+template <int VB, int XPT>
 __global__ void __launch_bounds__(RL_THREADS)
 k_spmv_wt_staged(const int* __restrict__ indptr, const int* __restrict__ lo,
                  const double* __restrict__ vals, int nrows, int ncols, int nvec,
-                 const double* __restrict__ X, double* __restrict__ Y, int xcap,
+                 const double* __restrict__ X, double* __restrict__ Y, int xcap, int vgroups,
                  int* __restrict__ bump) {
     if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
     RL_SMEM(smem);
@@ -505,63 +511,96 @@ k_spmv_wt_staged(const int* __restrict__ indptr, const int* __restrict__ lo,
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int r0 = blockIdx.x * nthr;
     const int rl = (r0 + nthr < nrows ? r0 + nthr : nrows) - 1;      // last row of the workgroup
-    const int v0 = blockIdx.y * VB;
-    const int nv = nvec - v0 < VB ? nvec - v0 : VB;
+    const int groups = (nvec + VB - 1) / VB;
+    const int g0 = blockIdx.y * vgroups;
+    const int ng = groups - g0 < vgroups ? groups - g0 : vgroups;
     const int k0 = indptr[r0], k1 = indptr[rl + 1];
     const int c0 = lo[r0], c1 = lo[rl] + (k1 - indptr[rl]);
+    const int len = c1 - c0;
     const int row = r0 + tid;
     const int rowc = row <= rl ? row : rl;
     const int kb = indptr[rowc];
     const int cnt = row <= rl ? indptr[rowc + 1] - kb : 0;
     const int l = lo[rowc];
     for (int i = tid; i < k1 - k0; i += nthr) vs[i] = vals[k0 + i];
+    // (unconditional loads from clamped positions: a range may be empty)
+    double xr[VB][XPT];
+    auto request = [&](int grp) {
+        const int v0 = (g0 + grp) * VB;
+        const int nv = nvec - v0 < VB ? nvec - v0 : VB;
 #pragma unroll
-    for (int j = 0; j < VB; ++j) {
-        const double* x = X + (size_t)(v0 + (j < nv ? j : 0)) * ncols + c0;
-        for (int i = tid; i < c1 - c0; i += nthr) xs[(size_t)j * xcap + i] = x[i];
-    }
-    __syncthreads();
-    double acc[VB];
+        for (int j = 0; j < VB; ++j) {
+            const double* x = X + (size_t)(v0 + (j < nv ? j : 0)) * ncols;
 #pragma unroll
-    for (int j = 0; j < VB; ++j) acc[j] = 0.0;
+            for (int u = 0; u < XPT; ++u) {
+                int c = c0 + tid + u * nthr;
+                c = c < ncols ? c : ncols - 1;
+                xr[j][u] = x[c];
+            }
+        }
+    };
+    request(0);
     const double* a = vs + (kb - k0);
-    const double* xr = xs + (l - c0);
-    for (int e = 0; e < cnt; ++e) {
-        const double w = a[e];
-#pragma unroll
-        for (int j = 0; j < VB; ++j) acc[j] = fma(w, xr[(size_t)j * xcap + e], acc[j]);
-    }
-    if (row <= rl) {
+    const double* xrow = xs + (l - c0);
+    for (int grp = 0; grp < ng; ++grp) {
 #pragma unroll
         for (int j = 0; j < VB; ++j)
-            if (j < nv) Y[(size_t)(v0 + j) * nrows + row] = acc[j];
+#pragma unroll
+            for (int u = 0; u < XPT; ++u) {
+                const int i = tid + u * nthr;
+                if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
+            }
+        __syncthreads();
+        if (grp + 1 < ng) request(grp + 1);
+        double acc[VB];
+#pragma unroll
+        for (int j = 0; j < VB; ++j) acc[j] = 0.0;
+        for (int e = 0; e < cnt; ++e) {
+            const double w = a[e];
+#pragma unroll
+            for (int j = 0; j < VB; ++j) acc[j] = fma(w, xrow[(size_t)j * xcap + e], acc[j]);
+        }
+        const int v0 = (g0 + grp) * VB;
+        if (row <= rl) {
+#pragma unroll
+            for (int j = 0; j < VB; ++j)
+                if (v0 + j < nvec) Y[(size_t)(v0 + j) * nrows + row] = acc[j];
+        }
+        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_spmv_w_staged<VB>: Y = W g + diag (.) X2 for LARGE batches when W is held
-// as base column + four weights per row with non-decreasing bases
+// k_spmv_w_staged<VB, XPT>: Y = W g (+ diag (.) X2) for LARGE batches when W is
+// held as base column + four weights per row with non-decreasing bases
 // (SkiTerm::W4_base / W4_w): the grid range of a workgroup's RL_THREADS data
 // rows is one contiguous piece of every grid vector, staged into LDS with
 // coalesced loads; base and weights of a row are independent loads.  Two
 // dependent levels of global loads (bases of the first and last row -> range)
 // instead of three (row pointers -> entries -> gathered values), no index
-// array, same summation order as k_spmv.
-//   grid (ceil(nrows / RL_THREADS), ceil(nvec / VB))    LDS: VB * xcap doubles
+// array, same summation order as k_spmv.  A workgroup walks `vgroups` groups of
+// VB vectors with the same rows (base, weights and diag stay in registers) and
+// requests the next group's pieces while it sums the current one, like
+// k_spmv_wt_staged.
+//   grid (ceil(nrows / RL_THREADS), ceil(ceil(nvec / VB) / vgroups))
+//   LDS: VB * xcap doubles, xcap <= XPT * RL_THREADS
 // ---------------------------------------------------------------------------
-template <int VB>
+template <int VB, int XPT>
 __global__ void __launch_bounds__(RL_THREADS)
 k_spmv_w_staged(const int* __restrict__ base, const double* __restrict__ w4, int nrows,
                 int ncols, int nvec, const double* __restrict__ G, double* __restrict__ Y,
-                const double* __restrict__ diag, const double* __restrict__ X2, int xcap) {
+                const double* __restrict__ diag, const double* __restrict__ X2, int xcap,
+                int vgroups) {
     RL_SMEM(smem);
     double* xs = reinterpret_cast<double*>(smem);          // [VB][xcap]
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int r0 = blockIdx.x * nthr;
     const int rl = (r0 + nthr < nrows ? r0 + nthr : nrows) - 1;
-    const int v0 = blockIdx.y * VB;
-    const int nv = nvec - v0 < VB ? nvec - v0 : VB;
+    const int groups = (nvec + VB - 1) / VB;
+    const int g0 = blockIdx.y * vgroups;
+    const int ng = groups - g0 < vgroups ? groups - g0 : vgroups;
     const int c0 = base[r0], c1 = base[rl] + 4;
+    const int len = c1 - c0;
     const int row = r0 + tid;
     const int rowc = row <= rl ? row : rl;
     const int b = base[rowc];
@@ -569,25 +608,50 @@ k_spmv_w_staged(const int* __restrict__ base, const double* __restrict__ w4, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = w4[(size_t)4 * rowc + e];
     const double dg = diag != nullptr ? diag[rowc] : 0.0;
-    double x2[VB];
+    double xr[VB][XPT], x2[VB];
+    auto request = [&](int grp) {
+        const int v0 = (g0 + grp) * VB;
+        const int nv = nvec - v0 < VB ? nvec - v0 : VB;
 #pragma unroll
-    for (int j = 0; j < VB; ++j)
-        x2[j] = diag != nullptr ? X2[(size_t)(v0 + (j < nv ? j : 0)) * nrows + rowc] : 0.0;
+        for (int j = 0; j < VB; ++j) {
+            const size_t v = (size_t)(v0 + (j < nv ? j : 0));
+            const double* g = G + v * ncols;
 #pragma unroll
-    for (int j = 0; j < VB; ++j) {
-        const double* g = G + (size_t)(v0 + (j < nv ? j : 0)) * ncols + c0;
-        for (int i = tid; i < c1 - c0; i += nthr) xs[(size_t)j * xcap + i] = g[i];
-    }
-    __syncthreads();
-    if (row > rl) return;
-    const double* xr = xs + (b - c0);
+            for (int u = 0; u < XPT; ++u) {
+                int c = c0 + tid + u * nthr;
+                c = c < ncols ? c : ncols - 1;
+                xr[j][u] = g[c];
+            }
+            x2[j] = diag != nullptr ? X2[v * nrows + rowc] : 0.0;
+        }
+    };
+    request(0);
+    const double* xrow = xs + (b - c0);
+    for (int grp = 0; grp < ng; ++grp) {
+        double d2[VB];
 #pragma unroll
-    for (int j = 0; j < VB; ++j) {
-        double acc = 0.0;
+        for (int j = 0; j < VB; ++j) {
+            d2[j] = x2[j];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = fma(w[e], xr[(size_t)j * xcap + e], acc);
-        if (diag != nullptr) acc = fma(dg, x2[j], acc);
-        if (j < nv) Y[(size_t)(v0 + j) * nrows + row] = acc;
+            for (int u = 0; u < XPT; ++u) {
+                const int i = tid + u * nthr;
+                if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
+            }
+        }
+        __syncthreads();
+        if (grp + 1 < ng) request(grp + 1);
+        const int v0 = (g0 + grp) * VB;
+        if (row <= rl) {
+#pragma unroll
+            for (int j = 0; j < VB; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fma(w[e], xrow[(size_t)j * xcap + e], acc);
+                if (diag != nullptr) acc = fma(dg, d2[j], acc);
+                if (v0 + j < nvec) Y[(size_t)(v0 + j) * nrows + row] = acc;
+            }
+        }
+        __syncthreads();
     }
 }
 

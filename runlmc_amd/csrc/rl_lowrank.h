@@ -26,10 +26,24 @@
 
 #define RL_LR_RMAX 48          // basis functions generated per handle
 #define RL_LR_T 32             // grid points per lane and projection chunk (chunk = 64 T)
-#define RL_LR_G 4              // ... requested G lane-steps ahead of their use
-#define RL_LR_RB 2             // rows per wave of the projection
 #define RL_LR_WAVES 4          // waves per projection workgroup
-#define RL_LR_ROWS (RL_LR_RB * RL_LR_WAVES)   // rows per projection workgroup
+#define RL_LR_CUS 256          // compute units of the one target (MI355X, 8 XCDs x 32)
+// rows per wave of the projection (RB x R running sums in registers: 4 x 24 or
+// 2 x 32 / 2 x 48 doubles) and how many lane-steps ahead the x values are requested
+// (a ring of G x RB doubles in registers)
+#define RL_LR_RB(R) ((R) <= 24 ? 4 : 2)
+#define RL_LR_G(R) ((R) <= 24 ? 4 : 8)
+#define RL_LR_ROWS(R) (RL_LR_RB(R) * RL_LR_WAVES)   // rows per projection workgroup
+// two projection waves per SIMD (256 registers each); the emulator has no such attribute
+// (and no scalar registers: RL_LR_UNIFORM marks a value that is the same in every
+// lane of a wave, so that row pointers and offsets live in SGPRs)
+#if defined(RL_EMU)
+#define RL_LR_PROJECT_ATTR
+#define RL_LR_UNIFORM(x) (x)
+#else
+#define RL_LR_PROJECT_ATTR __attribute__((amdgpu_waves_per_eu(2)))
+#define RL_LR_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 #define RL_LR_TOL 2e-13        // accepted |y_fft - y_lr| / max|y_fft| at set time
 
 // The basis is never read from memory by the two streaming kernels: a lane
@@ -45,75 +59,71 @@ __device__ __forceinline__ double lr_point(int n, int m) {
 // ---------------------------------------------------------------------------
 // k_lr_project<R>: part[chunk][row][j] = sum_{n in chunk} q_j(n) X[row][n],
 // rows = the nrows contiguous length-m blocks of X (vector-major, output-minor).
-//   grid (nchunks, ceil(nrows / RL_LR_ROWS))   block 64 * RL_LR_WAVES
+//   grid (nchunks, ceil(nrows / RL_LR_ROWS(R)))   block 64 * RL_LR_WAVES
 // Lanes run along the grid (every load is 512 contiguous bytes of one row), a
-// wave owns RL_LR_RB rows and keeps their RB x R running sums in registers over
+// wave owns RB = RL_LR_RB(R) rows and keeps their RB x R running sums in registers over
 // the RL_LR_T points of each lane; the 64 lanes are summed once per chunk
-// through LDS.  x values are requested RL_LR_G lane-steps before their use.
+// through LDS.  x values are requested RL_LR_G(R) lane-steps before their use.
 // ---------------------------------------------------------------------------
 template <int R>
-__global__ void __launch_bounds__(64 * RL_LR_WAVES)
+__global__ void __launch_bounds__(64 * RL_LR_WAVES) RL_LR_PROJECT_ATTR
 k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __restrict__ beta,
              double* __restrict__ part) {
+    constexpr int RB = RL_LR_RB(R), G = RL_LR_G(R), ROWS = RL_LR_ROWS(R);
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);       // [WAVES][R][65]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.y * RL_LR_ROWS + wave * RL_LR_RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = RL_LR_UNIFORM(tid >> 6);
+    const int row0 = blockIdx.y * ROWS + wave * RB;
     const int n_begin = blockIdx.x * (64 * RL_LR_T);
-    const double* xrow[RL_LR_RB];
+    const double* xrow[RB];
 #pragma unroll
-    for (int r = 0; r < RL_LR_RB; ++r)
+    for (int r = 0; r < RB; ++r)
         xrow[r] = X + (size_t)(row0 + r < nrows ? row0 + r : nrows - 1) * m;
-    double acc[RL_LR_RB][R];
+    double acc[RB][R];
 #pragma unroll
-    for (int r = 0; r < RL_LR_RB; ++r)
+    for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int j = 0; j < R; ++j) acc[r][j] = 0.0;
-    constexpr int NG = RL_LR_T / RL_LR_G;
-    double xa[RL_LR_G][RL_LR_RB], xb[RL_LR_G][RL_LR_RB];
-    // unconditional loads from clamped points; points past the end count as zero
-    auto request = [&](double (*xs)[RL_LR_RB], int g) {
+    // x values travel through a ring of G lane-steps: the slot of the step just
+    // consumed is requested again for the step G ahead (unconditional loads from
+    // clamped points; points past the end count as zero)
+    static_assert(RL_LR_T % G == 0, "ring length divides the chunk");
+    double xr[G][RB];
+    auto request = [&](int slot, int step) {
+        const int n = n_begin + lane + 64 * step;
+        const int nc = n < m ? n : m - 1;
 #pragma unroll
-        for (int k = 0; k < RL_LR_G; ++k) {
-            const int n = n_begin + lane + 64 * (g * RL_LR_G + k);
-            const int nc = n < m ? n : m - 1;
-#pragma unroll
-            for (int r = 0; r < RL_LR_RB; ++r) xs[k][r] = xrow[r][nc];
-        }
+        for (int r = 0; r < RB; ++r) xr[slot][r] = xrow[r][nc];
     };
-    auto consume = [&](double (*xs)[RL_LR_RB], int g) {
 #pragma unroll
-        for (int k = 0; k < RL_LR_G; ++k) {
-            const int n = n_begin + lane + 64 * (g * RL_LR_G + k);
+    for (int k = 0; k < G; ++k) request(k, k);
+#pragma unroll 1
+    for (int t = 0; t < RL_LR_T; t += G) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int n = n_begin + lane + 64 * (t + k);
             const double s = lr_point(n, m);
             const double live = n < m ? 1.0 : 0.0;
-            double x[RL_LR_RB];
+            double x[RB];
 #pragma unroll
-            for (int r = 0; r < RL_LR_RB; ++r) x[r] = xs[k][r] * live;
+            for (int r = 0; r < RB; ++r) x[r] = xr[k][r] * live;
+            // (the last G requests repeat the chunk's last step: no branch, a cache hit)
+            request(k, t + k + G < RL_LR_T ? t + k + G : RL_LR_T - 1);
             double qm = 0.0, q = 1.0;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
 #pragma unroll
-                for (int r = 0; r < RL_LR_RB; ++r) acc[r][j] = fma(q, x[r], acc[r][j]);
+                for (int r = 0; r < RB; ++r) acc[r][j] = fma(q, x[r], acc[r][j]);
                 const double qn = fma(s, q, -beta[j] * qm);
                 qm = q;
                 q = qn;
             }
         }
-    };
-    static_assert(NG % 2 == 0, "ping-pong over pairs of groups");
-    request(xa, 0);
-#pragma unroll 1
-    for (int g = 0; g < NG; g += 2) {
-        request(xb, g + 1);
-        consume(xa, g);
-        request(xa, g + 2 < NG ? g + 2 : g);      // (the last one is a repeat, unused)
-        consume(xb, g + 1);
     }
     // sum over the 64 lanes, one row at a time: [wave][j][lane] in LDS, then one
     // thread per (wave, j)
 #pragma unroll
-    for (int r = 0; r < RL_LR_RB; ++r) {
+    for (int r = 0; r < RB; ++r) {
 #pragma unroll
         for (int j = 0; j < R; ++j) red[(wave * R + j) * 65 + lane] = acc[r][j];
         __syncthreads();
@@ -121,14 +131,14 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
             const int w = e / R, j = e - w * R;
             const double* src = red + (size_t)e * 65;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
+#pragma unroll 2
             for (int l = 0; l < 64; l += 4) {
                 s0 += src[l];
                 s1 += src[l + 1];
                 s2 += src[l + 2];
                 s3 += src[l + 3];
             }
-            const int row = blockIdx.y * RL_LR_ROWS + w * RL_LR_RB + r;
+            const int row = blockIdx.y * ROWS + w * RB + r;
             if (row < nrows)
                 part[((size_t)blockIdx.x * nrows + row) * R + j] = (s0 + s1) + (s2 + s3);
         }

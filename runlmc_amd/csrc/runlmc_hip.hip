@@ -1235,7 +1235,7 @@ static size_t lr_min_elements() {
 
 template <int R>
 static void lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) {
-    RL_LAUNCH((k_lr_project<R>), dim3(lr_nchunks(g), (nrows + RL_LR_ROWS - 1) / RL_LR_ROWS),
+    RL_LAUNCH((k_lr_project<R>), dim3(lr_nchunks(g), (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R)),
               dim3(64 * RL_LR_WAVES), (size_t)RL_LR_WAVES * R * 65 * sizeof(double), st, X, nrows,
               g->m, (const double*)g->lr_beta, g->lr_part);
 }
@@ -1249,8 +1249,12 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
               (const double*)g->lr_part, lr_nchunks(g), nvec, g->D, R, Q, Cq, Bq,
               (const double*)g->lr_nu, g->lr_zhat);
     // rows per expansion workgroup: the basis values of a point are generated once
-    // per workgroup, so few, tall row blocks (while the launch still fills the chip)
-    const int rpb = nrows >= 1024 ? 256 : 64;
+    // per workgroup, so few, tall row blocks -- as many of them as make ONE resident
+    // round of workgroups (8 per CU: C5's 391 x 6 blocks of 256 rows were 1.15
+    // rounds, the second one a seventh full)
+    const int nbx = (g->m + 255) / 256;
+    const int nby = std::max(1, std::min(nrows, 8 * RL_LR_CUS / nbx));
+    const int rpb = (nrows + nby - 1) / nby;
     RL_LAUNCH((k_lr_expand<R>), dim3((g->m + 255) / 256, (nrows + rpb - 1) / rpb), dim3(256), 0,
               st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
 }
@@ -1892,6 +1896,16 @@ static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int sc
               scatter);
 }
 
+// groups of 8 vectors a staged-SpMV workgroup walks with the same rows
+// (RUNLMC_STAGED_GROUPS; measured at C5: DESIGN.md)
+static int staged_vgroups() {
+    static const int v = [] {
+        const char* e = getenv("RUNLMC_STAGED_GROUPS");
+        return e ? std::max(1, atoi(e)) : 4;
+    }();
+    return v;
+}
+
 // the three stages in INTERNAL row order
 static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st,
                       int* bump = nullptr) {
@@ -1900,18 +1914,30 @@ static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStrea
     constexpr int VB = 8;
     const size_t lds = ((size_t)VB * s->wt_xmax + s->wt_emax) * sizeof(double);
     if (s->WT_lo != nullptr && s->wt_xmax > 0 && lds <= 64 * 1024 &&
+        s->wt_xmax <= 4 * RL_THREADS &&
         ((size_t)s->ngrid * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
         getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
         trace_once("W^T product: k_spmv_wt_staged");
         static unsigned long long seen = 0;
         if (first_on_device(&seen)) {
-            (void)hipFuncSetAttribute((const void*)k_spmv_wt_staged<VB>,
+            (void)hipFuncSetAttribute((const void*)k_spmv_wt_staged<VB, 1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spmv_wt_staged<VB, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spmv_wt_staged<VB, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         }
         const unsigned gx = (s->ngrid + RL_THREADS - 1) / RL_THREADS;
-        RL_LAUNCH(k_spmv_wt_staged<VB>, dim3(gx, (nvec + VB - 1) / VB), dim3(RL_THREADS), lds, st,
-                  (const int*)s->WT_indptr, (const int*)s->WT_lo, (const double*)s->WT_data,
-                  s->ngrid, s->n, nvec, Xp, G, s->wt_xmax, bump);
+        const int vg = staged_vgroups();
+        const dim3 grid(gx, ((nvec + VB - 1) / VB + vg - 1) / vg);
+#define RL_WT_STAGED(XPT)                                                                       \
+    RL_LAUNCH((k_spmv_wt_staged<VB, XPT>), grid, dim3(RL_THREADS), lds, st,                     \
+              (const int*)s->WT_indptr, (const int*)s->WT_lo, (const double*)s->WT_data,        \
+              s->ngrid, s->n, nvec, Xp, G, s->wt_xmax, vg, bump)
+        if (s->wt_xmax <= RL_THREADS) RL_WT_STAGED(1);
+        else if (s->wt_xmax <= 2 * RL_THREADS) RL_WT_STAGED(2);
+        else RL_WT_STAGED(4);
+#undef RL_WT_STAGED
         RL_HIP(hipGetLastError());
         return RL_OK;
     }
@@ -1926,18 +1952,30 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
     constexpr int VB = 8;
     const size_t lds = (size_t)VB * s->w_xmax * sizeof(double);
     if (s->W4_base != nullptr && s->w_xmax > 0 && lds <= 64 * 1024 &&
+        s->w_xmax <= 4 * RL_THREADS &&
         ((size_t)s->n * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
         getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
         trace_once("W product: k_spmv_w_staged");
         static unsigned long long seen = 0;
         if (first_on_device(&seen)) {
-            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged<VB>,
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged<VB, 1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged<VB, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged<VB, 4>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         }
         const unsigned gx = (s->n + RL_THREADS - 1) / RL_THREADS;
-        RL_LAUNCH(k_spmv_w_staged<VB>, dim3(gx, (nvec + VB - 1) / VB), dim3(RL_THREADS), lds, st,
-                  (const int*)s->W4_base, (const double*)s->W4_w, s->n, s->ngrid, nvec, G, Yp,
-                  diag, X2p, s->w_xmax);
+        const int vg = staged_vgroups();
+        const dim3 grid(gx, ((nvec + VB - 1) / VB + vg - 1) / vg);
+#define RL_W_STAGED(XPT)                                                                        \
+    RL_LAUNCH((k_spmv_w_staged<VB, XPT>), grid, dim3(RL_THREADS), lds, st,                      \
+              (const int*)s->W4_base, (const double*)s->W4_w, s->n, s->ngrid, nvec, G, Yp, diag, \
+              X2p, s->w_xmax, vg)
+        if (s->w_xmax <= RL_THREADS) RL_W_STAGED(1);
+        else if (s->w_xmax <= 2 * RL_THREADS) RL_W_STAGED(2);
+        else RL_W_STAGED(4);
+#undef RL_W_STAGED
         RL_HIP(hipGetLastError());
         return RL_OK;
     }
