@@ -500,6 +500,14 @@ struct Minres2Bufs {
     const double* g;        // [nrhs][ngrid]
     const double* eps;      // [n] or NULL
     int ngrid;
+    // unfused W product whose kernel left the noise term out (eps_runs > 0): P adds
+    // eps (.) y_{r-1} to the operator output it reads from q -- P holds y_{r-1}
+    // anyway, the W kernel would read it a second time (same fma, same bits).  The
+    // noise is constant per output and the rows of an output are contiguous: rows
+    // [eps_end[k-1], eps_end[k]) carry eps_val[k]; no per-row array is read.
+    int eps_runs;
+    int eps_end[RL_MAX_D];
+    double eps_val[RL_MAX_D];
 };
 
 // init: x = 0, y_{-1} unused, y_0 = b, w = 0; partial = b.b from k_dot_partial(b, b)
@@ -632,6 +640,26 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
         px[u] = mb.x[off + ic];
         pq[u] = g == nullptr ? mb.q[off + ic] : 0.0;
     }
+    // noise runs that meet this workgroup's rows [lo, hi): almost always one
+    int ka = 0, kb = 0;
+    if (g == nullptr && mb.eps_runs > 0) {
+        while (ka + 1 < mb.eps_runs && lo >= mb.eps_end[ka]) ++ka;
+        kb = ka;
+        while (kb + 1 < mb.eps_runs && rlast >= mb.eps_end[kb]) ++kb;
+    }
+    auto eps_row = [&](int i) {
+        double e = mb.eps_val[ka];
+        for (int k = ka; k < kb; ++k)
+            if (i >= mb.eps_end[k]) e = mb.eps_val[k + 1];
+        return e;
+    };
+    if (g == nullptr && mb.eps_runs > 0) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = lo + threadIdx.x + u * blockDim.x;
+            pq[u] = fma(eps_row(i < hi ? i : rlast), pr2[u], pq[u]);
+        }
+    }
     if (ell) {
         double gv[PF][NZ];
 #pragma unroll
@@ -745,6 +773,11 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
                 tw2[u] = w2[i];
                 tx[u] = mb.x[i];
             }
+            if (mb.eps_runs > 0) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+                    tq[u] = fma(eps_row(it0 + u * (int)blockDim.x), tr2[u], tq[u]);
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const size_t i = off + it0 + u * blockDim.x;
@@ -775,6 +808,7 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
             for (int k = mb.W_indptr[i]; k < k1; ++k) qi = fma(mb.W_data[k], g[mb.W_indices[k]], qi);
         } else {
             qi = mb.q[off + i];
+            if (mb.eps_runs > 0) qi = fma(eps_row(i), r2i, qi);
         }
         double r1i = 0.0;
         if (fin) {

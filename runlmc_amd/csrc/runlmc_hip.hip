@@ -1581,6 +1581,8 @@ struct rl_ski {
     // Internal row order: data points sorted by grid position (W, WT and
     // noise_diag above are stored in THAT order); perm[i] = caller's row of
     // internal row i.  P1/P2: dev [pcap][n] staging for caller-order entry points.
+    std::vector<int> eps_end;       // noise in runs: rows [eps_end[k-1], eps_end[k]) carry eps_val[k]
+    std::vector<double> eps_val;    // (empty: more than RL_MAX_D runs)
     bool permuted = false;
     int* perm = nullptr;
     std::vector<int> h_perm;
@@ -1855,6 +1857,22 @@ extern "C" int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens)
         for (int i = 0; i < s->n; ++i) sorted[i] = diag[s->h_perm[i]];
         diag.swap(sorted);
     }
+    // runs of equal values in internal order (one per output when every output's
+    // rows are contiguous): what the solver's vector kernel takes instead of the array
+    s->eps_end.clear();
+    s->eps_val.clear();
+    for (int i = 0; i < s->n; ++i) {
+        if (i == 0 || diag[i] != diag[i - 1]) {
+            if ((int)s->eps_val.size() == RL_MAX_D) {       // not per-output after all
+                s->eps_end.clear();
+                s->eps_val.clear();
+                break;
+            }
+            if (i > 0) s->eps_end.push_back(i);
+            s->eps_val.push_back(diag[i]);
+        }
+    }
+    if (!s->eps_val.empty()) s->eps_end.push_back(s->n);
     RL_HIP(hipSetDevice(s->g->device));
     RL_HIP(hipMemcpy(s->noise_diag, diag.data(), diag.size() * sizeof(double),
                      hipMemcpyHostToDevice));
@@ -1985,12 +2003,14 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
     return RL_OK;
 }
 // Yp = K~ Xp, both in internal row order (what the solver iterates on)
+// (noise = false: Yp = W K_UU W^T Xp only -- the caller adds eps (.) Xp itself)
 static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st,
-                       int* bump = nullptr) {
+                       int* bump = nullptr, bool noise = true) {
     RL_TRY(ski_reserve(s, nvec));
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st));
-    RL_TRY(ski_w_int(s, s->G2, Yp, nvec, s->has_noise ? s->noise_diag : nullptr, Xp, st));
+    RL_TRY(ski_w_int(s, s->G2, Yp, nvec, s->has_noise && noise ? s->noise_diag : nullptr, Xp,
+                     st));
     for (const SkiTerm& t : s->extra) {       // Yp += W_t K_t W_t^T Xp
         launch_spmv(t.WT_indptr, t.WT_indices, t.WT_data, t.ngrid, s->n, nvec, Xp, s->G1,
                     nullptr, nullptr, st);
@@ -2232,7 +2252,7 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         RL_TRY(ski_wt_int(s, yin, s->G1, nrhs, st, mb.giter));
         RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nrhs, st));
     } else {
-        RL_TRY(ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter));
+        RL_TRY(ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter, mb.eps_runs == 0));
     }
     RL_LAUNCH(k_minres2_p, grid, blk, red, st, mb, n, par);
     RL_LAUNCH(k_minres2_b, grid, blk, red, st, mb, n, par, rtol, maxiter);
@@ -2389,6 +2409,17 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         mb.g = s->G2;
         mb.eps = s->has_noise ? s->noise_diag : nullptr;
         mb.ngrid = s->ngrid;
+        // single-term operator, W as its own kernel, noise in a few constant runs
+        // (one per output): the noise term moves into P
+        mb.eps_runs = 0;
+        if (!fuse_w && s->extra.empty() && s->has_noise && !s->eps_end.empty() &&
+            getenv("RUNLMC_NO_LATE_NOISE") == nullptr) {
+            mb.eps_runs = (int)s->eps_end.size();
+            for (int k = 0; k < mb.eps_runs; ++k) {
+                mb.eps_end[k] = s->eps_end[k];
+                mb.eps_val[k] = s->eps_val[k];
+            }
+        }
         if (lanczos_out != nullptr) {
             const size_t bytes = (size_t)nrhs * lanczos_cap * 2 * sizeof(double);
             if (s->lanczos_bytes < bytes) {

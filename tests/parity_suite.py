@@ -1018,7 +1018,8 @@ def check_staged_wt_product():
     """The LDS-staged W^T and W products of large batches (k_spmv_wt_staged,
     k_spmv_w_staged), forced on small ones: bit-identical to the CSR kernels (same summation order) for
     uniform, clustered and gappy inputs, ragged outputs and a batch that is not
-    a multiple of the vector block; through apply_wt and through a solve."""
+    a multiple of the vector block nor of the groups a workgroup walks; through
+    apply_wt and through a solve."""
     from runlmc_amd.util import synth
     from runlmc_amd._native import solve_batch
     rng = np.random.RandomState(17)
@@ -1053,7 +1054,7 @@ def check_staged_wt_product():
                 p.WT.indptr = p.WT.indptr.astype(np.int32)
             fk = synth.functional_kernel(p)
             ad = (0,)
-            V = rng.randn(11, p.n)
+            V = rng.randn(37, p.n)       # 5 groups of 8: two workgroup columns of 4 and 1
 
             def results():
                 K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
