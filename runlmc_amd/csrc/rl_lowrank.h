@@ -25,7 +25,7 @@
 #include "rl_device.h"
 
 #define RL_LR_RMAX 48          // basis functions generated per handle
-#define RL_LR_T 32             // grid points per lane and projection chunk (chunk = 64 T)
+#define RL_LR_T 32             // lane-steps of a projection chunk (64 points each) are a multiple of this
 #define RL_LR_WAVES 4          // waves per projection workgroup
 #define RL_LR_CUS 256          // compute units of the one target (MI355X, 8 XCDs x 32)
 // rows per wave of the projection (RB x R running sums in registers: 4 x 24 or
@@ -62,19 +62,20 @@ __device__ __forceinline__ double lr_point(int n, int m) {
 //   grid (nchunks, ceil(nrows / RL_LR_ROWS(R)))   block 64 * RL_LR_WAVES
 // Lanes run along the grid (every load is 512 contiguous bytes of one row), a
 // wave owns RB = RL_LR_RB(R) rows and keeps their RB x R running sums in registers over
-// the RL_LR_T points of each lane; the 64 lanes are summed once per chunk
+// the `steps` points of each lane (a multiple of RL_LR_T, chosen by the host: long
+// chunks amortise the reduction); the 64 lanes are summed once per chunk
 // through LDS.  x values are requested RL_LR_G(R) lane-steps before their use.
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ void __launch_bounds__(64 * RL_LR_WAVES) RL_LR_PROJECT_ATTR
 k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __restrict__ beta,
-             double* __restrict__ part) {
+             int steps, double* __restrict__ part) {
     constexpr int RB = RL_LR_RB(R), G = RL_LR_G(R), ROWS = RL_LR_ROWS(R);
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);       // [WAVES][R][65]
     const int tid = threadIdx.x, lane = tid & 63, wave = RL_LR_UNIFORM(tid >> 6);
     const int row0 = blockIdx.y * ROWS + wave * RB;
-    const int n_begin = blockIdx.x * (64 * RL_LR_T);
+    const int n_begin = blockIdx.x * (64 * steps);
     const double* xrow[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -98,7 +99,7 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
 #pragma unroll
     for (int k = 0; k < G; ++k) request(k, k);
 #pragma unroll 1
-    for (int t = 0; t < RL_LR_T; t += G) {
+    for (int t = 0; t < steps; t += G) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const int n = n_begin + lane + 64 * (t + k);
@@ -108,7 +109,7 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
 #pragma unroll
             for (int r = 0; r < RB; ++r) x[r] = xr[k][r] * live;
             // (the last G requests repeat the chunk's last step: no branch, a cache hit)
-            request(k, t + k + G < RL_LR_T ? t + k + G : RL_LR_T - 1);
+            request(k, t + k + G < steps ? t + k + G : steps - 1);
             double qm = 0.0, q = 1.0;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
@@ -201,38 +202,48 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
 
 // ---------------------------------------------------------------------------
 // k_lr_expand<R>: Y[row][n] = sum_j q_j(n) Zhat[row][j]  (Zhat carries nu).
-//   grid (ceil(m / 256), ceil(nrows / rows_per_block))   block 256
-// A thread owns one grid point: its R basis values (recurrence, once) stay in
-// registers for all the rows of the block, the coefficients of a row are the
-// same for every lane.
+//   grid (ceil(m / (256 NP)), ceil(nrows / rows_per_block))   block 256
+// A thread owns NP = RL_LR_NP grid points (256 apart; two per thread measured
+// 318 vs 250 us at C5, non-temporal stores 271 vs 243): their R basis values
+// (recurrence, once) stay in registers for all the rows of the block; the
+// coefficients of a row are the same for every lane (scalar loads).
 // ---------------------------------------------------------------------------
+#define RL_LR_NP 1
 template <int R>
 __global__ void __launch_bounds__(256)
 k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __restrict__ beta,
             int rows_per_block, double* __restrict__ Y) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n0 = blockIdx.x * (256 * RL_LR_NP) + threadIdx.x;
     const int row0 = blockIdx.y * rows_per_block;
     const int row1 = row0 + rows_per_block < nrows ? row0 + rows_per_block : nrows;
-    const double s = lr_point(n < m ? n : m - 1, m);
-    double p[R];
-    {
+    double p[RL_LR_NP][R];
+#pragma unroll
+    for (int c = 0; c < RL_LR_NP; ++c) {
+        const int n = n0 + 256 * c;
+        const double s = lr_point(n < m ? n : m - 1, m);
         double qm = 0.0, q = 1.0;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            p[j] = q;
+            p[c][j] = q;
             const double qn = fma(s, q, -beta[j] * qm);
             qm = q;
             q = qn;
         }
     }
-    for (int row = row0; row < row1; ++row) {
-        const double* z = Zhat + (size_t)row * R;
-        double s0 = 0.0, s1 = 0.0;
+    auto one_row = [&](const double* __restrict__ z, int row) {
 #pragma unroll
-        for (int j = 0; j + 1 < R; j += 2) {
-            s0 = fma(z[j], p[j], s0);
-            s1 = fma(z[j + 1], p[j + 1], s1);
+        for (int c = 0; c < RL_LR_NP; ++c) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j + 1 < R; j += 2) {
+                s0 = fma(z[j], p[c][j], s0);
+                s1 = fma(z[j + 1], p[c][j + 1], s1);
+            }
+            const int n = n0 + 256 * c;
+            if (n < m) Y[(size_t)row * m + n] = s0 + s1;
         }
-        if (n < m) Y[(size_t)row * m + n] = s0 + s1;
-    }
+    };
+    // (one row at a time: with the coefficients of two rows requested together the
+    // scalar registers run out and the loads are staggered -- 324 vs 250 us at C5)
+    for (int row = row0; row < row1; ++row) one_row(Zhat + (size_t)row * R, row);
 }

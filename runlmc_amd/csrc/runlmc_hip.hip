@@ -251,6 +251,11 @@ struct rl_gridop {
     // polynomial-subspace form for smooth kernels (rl_lowrank.h)
     bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
     bool lr_ok = false;         // verified against the FFT path for the current parameters
+    bool lr_dirty = false;      // parameters changed since the last verification: the
+                                // set-time work (lr_setup) runs when the first batch above
+                                // the gate asks for it -- small-batch users never pay it
+    std::vector<double> lr_A, lr_W, lr_kap;    // the parameters lr_setup will need
+    std::vector<int> lr_Qi;
     bool lr_bypass = false;     // set while the FFT path is wanted (set-time verification)
     int lr_r = 0;               // basis size in use (24 / 32 / 48)
     size_t lr_min = 0;          // batches below this many elements stay on the FFT path
@@ -616,8 +621,11 @@ extern "C" int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int*
     return RL_OK;
 }
 
-extern "C" int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements) {
-    if (!g) return fail(RL_EINVAL, "gridop is NULL");
+static int lr_ensure(rl_gridop* g);
+extern "C" int rl_gridop_form(const rl_gridop* gc, int* rank, long long* min_elements) {
+    if (!gc) return fail(RL_EINVAL, "gridop is NULL");
+    rl_gridop* g = const_cast<rl_gridop*>(gc);      // (runs the pending verification)
+    if (g->Q >= 1) RL_TRY(lr_ensure(g));
     if (rank) *rank = g->lr_ok ? g->lr_r : 0;
     if (min_elements) *min_elements = (long long)g->lr_min;
     return RL_OK;
@@ -723,9 +731,16 @@ static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector
     if ((int)W.size() > g->max_fac)
         return fail(RL_ELIMIT, "rl_gridop_set: total rank exceeds max_tops*D");
     g->lr_ok = false;
+    g->lr_dirty = false;
     int rc = set_common(g, Q, tops);
     if (rc == RL_OK) rc = set_factors(g, A, W, Qi, kap);
-    if (rc == RL_OK) rc = lr_setup(g, A, W, Qi, kap);
+    if (rc == RL_OK && g->lr_try) {
+        g->lr_A = A;
+        g->lr_W = W;
+        g->lr_Qi = Qi;
+        g->lr_kap = kap;
+        g->lr_dirty = true;
+    }
     if (rc != RL_OK) g->Q = 0;          // no half-updated operator
     return rc;
 }
@@ -1197,10 +1212,30 @@ static int lr_make_basis(rl_gridop* g) {
     return RL_OK;
 }
 
-// projection chunks: 64 * RL_LR_T grid points each
-static int lr_nchunks(const rl_gridop* g) { return (g->m + 64 * RL_LR_T - 1) / (64 * RL_LR_T); }
+// Projection chunks of 64 * steps grid points, steps a multiple of RL_LR_T: the
+// longest chunk (the 64-lane reduction at its end costs about 8 lane-steps) that
+// still leaves whole rounds of resident workgroups (2 per CU) well filled.
+static int lr_steps(const rl_gridop* g, int nrows, int R) {
+    const int rowblocks = (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R);
+    const double resident = 2.0 * RL_LR_CUS;
+    int best = RL_LR_T;
+    double best_cost = 1e300;
+    for (int steps = RL_LR_T; steps <= 8 * RL_LR_T; steps *= 2) {
+        const int chunks = (g->m + 64 * steps - 1) / (64 * steps);
+        const double rounds = std::ceil((double)chunks * rowblocks / resident);
+        const double cost = rounds * (steps + 8);
+        if (cost < best_cost * 0.97) {          // (longer only for a real gain)
+            best_cost = cost;
+            best = steps;
+        }
+        if (chunks == 1) break;
+    }
+    return best;
+}
+// partial sums: sized for the shortest chunks
+static int lr_nchunks_max(const rl_gridop* g) { return (g->m + 64 * RL_LR_T - 1) / (64 * RL_LR_T); }
 static size_t lr_part_need(const rl_gridop* g, int nvec) {
-    return (size_t)lr_nchunks(g) * nvec * g->D * RL_LR_RMAX;
+    return (size_t)lr_nchunks_max(g) * nvec * g->D * RL_LR_RMAX;
 }
 static int lr_reserve(rl_gridop* g, int nvec) {
     const size_t rows = (size_t)nvec * g->D;
@@ -1233,29 +1268,38 @@ static size_t lr_min_elements() {
     return v;
 }
 
+// launches the projection, returns the number of chunks (partial sums per row)
 template <int R>
-static void lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) {
-    RL_LAUNCH((k_lr_project<R>), dim3(lr_nchunks(g), (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R)),
+static int lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) {
+    const int steps = lr_steps(g, nrows, R);
+    const int chunks = (g->m + 64 * steps - 1) / (64 * steps);
+    RL_LAUNCH((k_lr_project<R>), dim3(chunks, (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R)),
               dim3(64 * RL_LR_WAVES), (size_t)RL_LR_WAVES * R * 65 * sizeof(double), st, X, nrows,
-              g->m, (const double*)g->lr_beta, g->lr_part);
+              g->m, (const double*)g->lr_beta, steps, g->lr_part);
+    return chunks;
 }
 
 template <int R>
 static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q, const double* Cq,
                       const double* Bq, hipStream_t st) {
     const int nrows = nvec * g->D;
-    lr_project<R>(g, X, nrows, st);
+    const int chunks = lr_project<R>(g, X, nrows, st);
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
-              (const double*)g->lr_part, lr_nchunks(g), nvec, g->D, R, Q, Cq, Bq,
+              (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
               (const double*)g->lr_nu, g->lr_zhat);
     // rows per expansion workgroup: the basis values of a point are generated once
-    // per workgroup, so few, tall row blocks -- as many of them as make ONE resident
-    // round of workgroups (8 per CU: C5's 391 x 6 blocks of 256 rows were 1.15
-    // rounds, the second one a seventh full)
-    const int nbx = (g->m + 255) / 256;
-    const int nby = std::max(1, std::min(nrows, 8 * RL_LR_CUS / nbx));
-    const int rpb = (nrows + nby - 1) / nby;
-    RL_LAUNCH((k_lr_expand<R>), dim3((g->m + 255) / 256, (nrows + rpb - 1) / rpb), dim3(256), 0,
+    // per workgroup (48 instructions against 26 per row).  32 rows when that makes
+    // at least two resident rounds of workgroups (measured at C5, 1290 rows: 243 us
+    // against 270 with 258 rows in ONE round and 390 with 645), otherwise as many
+    // row blocks as make one round.  Resident workgroups per CU: 8 (52 VGPRs).
+    const int per_cu = 8;
+    const int nbx = (g->m + 256 * RL_LR_NP - 1) / (256 * RL_LR_NP);
+    int rpb = 32;
+    if ((size_t)nbx * ((nrows + 31) / 32) < (size_t)2 * per_cu * RL_LR_CUS) {
+        const int nby = std::max(1, std::min(nrows, per_cu * RL_LR_CUS / nbx));
+        rpb = (nrows + nby - 1) / nby;
+    }
+    RL_LAUNCH((k_lr_expand<R>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
               st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
 }
 
@@ -1337,12 +1381,12 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
             if (rc != RL_OK) return rc;
             // C_q[i][j] = Phi_i . (T_q Phi_j): the projection of those rows
             const int nrows = nvr * D;
+            int nparts = 0;
             switch (r) {
-                case 24: lr_project<24>(g, tphi, nrows, st); break;
-                case 32: lr_project<32>(g, tphi, nrows, st); break;
-                default: lr_project<48>(g, tphi, nrows, st); break;
+                case 24: nparts = lr_project<24>(g, tphi, nrows, st); break;
+                case 32: nparts = lr_project<32>(g, tphi, nrows, st); break;
+                default: nparts = lr_project<48>(g, tphi, nrows, st); break;
             }
-            const int nparts = lr_nchunks(g);
             std::vector<double> part((size_t)nparts * nrows * r);
             RL_HIP(hipMemcpy(part.data(), g->lr_part, part.size() * sizeof(double), hipMemcpyDeviceToHost));
             std::vector<double> C((size_t)r * r, 0.0);
@@ -1379,6 +1423,29 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
     return RL_OK;
 }
 
+static int lr_ensure(rl_gridop* g);
+// before a capture: pending verification and buffers for batches of nvec vectors
+static int lr_prepare(rl_gridop* g, int nvec) {
+    if (!g->lr_try || (size_t)nvec * g->D * g->m < g->lr_min) return RL_OK;
+    RL_TRY(lr_ensure(g));
+    if (g->lr_ok) RL_TRY(lr_reserve(g, nvec));
+    return RL_OK;
+}
+
+// runs the verification the last parameter update left pending
+static int lr_ensure(rl_gridop* g) {
+    if (!g->lr_dirty) return RL_OK;
+    g->lr_dirty = false;
+    RL_HIP(hipSetDevice(g->device));
+    return lr_setup(g, g->lr_A, g->lr_W, g->lr_Qi, g->lr_kap);
+}
+
+static bool stream_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return stream != nullptr && hipStreamIsCapturing(stream, &cs) == hipSuccess &&
+           cs != hipStreamCaptureStatusNone;
+}
+
 static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
                         hipStream_t stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
@@ -1388,20 +1455,18 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_HIP(hipSetDevice(g->device));
-    if (g->lr_ok && !g->lr_bypass && (size_t)nvec * g->D * g->m >= g->lr_min) {
+    const bool lr_batch = g->lr_try && !g->lr_bypass && (size_t)nvec * g->D * g->m >= g->lr_min;
+    // (nothing may be allocated or copied inside a capture: a pending verification
+    // waits for the next product outside one; the solver runs it before it captures)
+    if (lr_batch && g->lr_dirty && !stream_capturing(stream)) RL_TRY(lr_ensure(g));
+    if (lr_batch && g->lr_ok && !g->lr_dirty) {
         // smooth kernels, a batch large enough to fill the chip with projection
         // workgroups: polynomial-subspace form, verified at set time
         bool ready = g->lr_part_cap >= lr_part_need(g, nvec) &&
                      g->lr_zhat_cap >= (size_t)nvec * g->D * RL_LR_RMAX;
-        if (!ready) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            const bool capturing = stream != nullptr &&
-                                   hipStreamIsCapturing(stream, &cs) == hipSuccess &&
-                                   cs != hipStreamCaptureStatusNone;
-            if (!capturing) {            // (nothing may be allocated inside a capture)
-                RL_TRY(lr_reserve(g, nvec));
-                ready = true;
-            }
+        if (!ready && !stream_capturing(stream)) {
+            RL_TRY(lr_reserve(g, nvec));
+            ready = true;
         }
         if (ready) {
             trace_once("grid product: polynomial-subspace form (k_lr_project / mix / expand)");
@@ -2350,9 +2415,8 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     RL_TRY(solver_alloc(s, w, need, nrhs, n, nblk, st));
     // everything the operator product allocates lazily must exist before capture
     RL_TRY(ski_reserve(s, nrhs));
-    if (s->g->lr_ok) RL_TRY(lr_reserve(s->g, nrhs));
-    for (const SkiTerm& t : s->extra)
-        if (t.g->lr_ok) RL_TRY(lr_reserve(t.g, nrhs));
+    RL_TRY(lr_prepare(s->g, nrhs));
+    for (const SkiTerm& t : s->extra) RL_TRY(lr_prepare(t.g, nrhs));
     RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
     if (s->g->v2 && ((size_t)nrhs + 1) / 2 > s->g->chunk_pairs && wants_two_streams(s->g))
         RL_TRY(prepare_two_streams(s->g, s->g->chunk_pairs));

@@ -30,24 +30,39 @@ for path in paths:
         for row in csv.DictReader(f):
             name = row.get('Kernel_Name', '').split('(')[0].replace('void ', '')
             tot[name][row['Counter_Name']] += float(row['Counter_Value'])
-bytes_total, detail = 0.0, {}
-for name, c in tot.items():
-    if not (name.startswith('k2_') or name.startswith('k3_') or name.startswith('k1_product')):
-        continue
-    double = not name.startswith('k2_cols_fwd')
-    rd = c.get('FETCH_SIZE', 0.0) * 1024 * (2 if double else 1)
-    wr = c.get('WRITE_SIZE', 0.0) * 1024
-    detail[name] = {'read_bytes_per_step': rd / steps, 'write_bytes_per_step': wr / steps,
-                    'fetch_doubled': double}
-    bytes_total += rd + wr
+def entry(prefixes, doubled):
+    """Sum of the kernels whose names start with one of `prefixes`."""
+    bytes_total, detail = 0.0, {}
+    for name, c in tot.items():
+        if not name.startswith(prefixes):
+            continue
+        double = doubled(name)
+        rd = c.get('FETCH_SIZE', 0.0) * 1024 * (2 if double else 1)
+        wr = c.get('WRITE_SIZE', 0.0) * 1024
+        detail[name] = {'read_bytes_per_step': rd / steps, 'write_bytes_per_step': wr / steps,
+                        'fetch_doubled': double}
+        bytes_total += rd + wr
+    return bytes_total, detail
+
+
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                         'profiles', 'r02', 'traffic.json')
 try:
     table = json.load(open(out_path))
 except (OSError, ValueError):
     table = {}
-table['%s:%d' % (config, batch)] = {'bytes_per_step': bytes_total / steps, 'source': label,
-                                    'kernels': detail}
+# transform kernels (bench.py times them beside the polynomial form, same step count)
+b_fft, d_fft = entry(('k2_', 'k3_', 'k1_product'), lambda n: not n.startswith('k2_cols_fwd'))
+if d_fft:
+    table['%s:%d' % (config, batch)] = {'bytes_per_step': b_fft / steps, 'source': label,
+                                        'kernels': d_fft}
+    print(config, batch, 'transform kernels: bytes per step %.4g' % (b_fft / steps))
+# polynomial form: 8-byte loads per lane, FETCH_SIZE as reported.  (The handful of
+# set-time launches of these kernels -- r rows each -- are in the sums: < 1 %.)
+b_lr, d_lr = entry(('k_lr_',), lambda n: False)
+if d_lr:
+    table['%s:%d:poly' % (config, batch)] = {'bytes_per_step': b_lr / steps, 'source': label,
+                                             'kernels': d_lr}
+    print(config, batch, 'polynomial form: bytes per step %.4g' % (b_lr / steps))
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(table, open(out_path, 'w'), indent=1, sort_keys=True)
-print(config, batch, 'bytes per step %.4g' % (bytes_total / steps))
