@@ -57,9 +57,15 @@ if d_fft:
     table['%s:%d' % (config, batch)] = {'bytes_per_step': b_fft / steps, 'source': label,
                                         'kernels': d_fft}
     print(config, batch, 'transform kernels: bytes per step %.4g' % (b_fft / steps))
-# polynomial form: 8-byte loads per lane, FETCH_SIZE as reported.  (The handful of
-# set-time launches of these kernels -- r rows each -- are in the sums: < 1 %.)
-b_lr, d_lr = entry(('k_lr_',), lambda n: False)
+# polynomial form.  Calibrated on byte counts that are known exactly: the
+# projection reads every element of x once (C5: 1.032 GB; FETCH_SIZE reports
+# 519.6 MB per launch -- its 512-byte-per-wave loads are 128-byte requests tallied
+# at 64, the guide's factor 2) and writes 49 x 1290 x 24 partial sums (12.14 MB;
+# WRITE_SIZE reports 12.14 MB: as reported), the expansion writes y once (1.032 GB;
+# WRITE_SIZE 1.0324 GB).  So FETCH_SIZE doubled, WRITE_SIZE as reported.  (The
+# handful of set-time launches of these kernels -- r rows each -- are in the
+# sums: < 1 %.)
+b_lr, d_lr = entry(('k_lr_',), lambda n: True)
 if d_lr:
     table['%s:%d:poly' % (config, batch)] = {'bytes_per_step': b_lr / steps, 'source': label,
                                              'kernels': d_lr}
