@@ -30,9 +30,9 @@
 #define RL_LR_CUS 256          // compute units of the one target (MI355X, 8 XCDs x 32)
 // rows per wave of the projection (RB x R running sums in registers: 4 x 24 or
 // 2 x 32 / 2 x 48 doubles) and how many lane-steps ahead the x values are requested
-// (a ring of G x RB doubles in registers)
+// (a ring of G x RB x 2 doubles in registers: a point and its mirror)
 #define RL_LR_RB(R) ((R) <= 24 ? 4 : 2)
-#define RL_LR_G(R) ((R) <= 24 ? 4 : 8)
+#define RL_LR_G(R) ((R) <= 24 ? 2 : 4)
 #define RL_LR_ROWS(R) (RL_LR_RB(R) * RL_LR_WAVES)   // rows per projection workgroup
 // two projection waves per SIMD (256 registers each); the emulator has no such attribute
 // (and no scalar registers: RL_LR_UNIFORM marks a value that is the same in every
@@ -52,15 +52,26 @@
 // nu from the host's long-double recurrence; the normalisation nu is applied to
 // the r coefficients in k_lr_mix).  Evaluated in fp64 the recurrence reproduces
 // the long-double basis to 1e-14 of its largest entry (degree 48, m = 5e3 .. 1e5).
+// The grid is symmetric about its centre and q_j(-s) = (-1)^j q_j(s): a lane owns
+// a grid point n of the first half TOGETHER with its mirror m-1-n.  One recurrence
+// serves both, the projection feeds the even degrees with x(n) + x(mirror) and the
+// odd ones with x(n) - x(mirror), the expansion forms the even and the odd part of
+// y once and stores their sum and their difference: half the multiply-adds and
+// half the recurrences per element (the centre point of an odd grid is its own
+// mirror and counts once).  "Slots" below are the (m + 1) / 2 points of that
+// first half.
+__device__ __forceinline__ int lr_slots(int m) { return (m + 1) / 2; }
 __device__ __forceinline__ double lr_point(int n, int m) {
     return m > 1 ? fma(2.0 / (double)(m - 1), (double)n, -1.0) : 0.0;
 }
 
 // ---------------------------------------------------------------------------
-// k_lr_project<R>: part[chunk][row][j] = sum_{n in chunk} q_j(n) X[row][n],
-// rows = the nrows contiguous length-m blocks of X (vector-major, output-minor).
+// k_lr_project<R>: part[chunk][row][j] = sum_{n or its mirror in chunk} q_j(n) X[row][n],
+// rows = the nrows contiguous length-m blocks of X (vector-major, output-minor);
+// a chunk is 64 * steps slots.
 //   grid (nchunks, ceil(nrows / RL_LR_ROWS(R)))   block 64 * RL_LR_WAVES
-// Lanes run along the grid (every load is 512 contiguous bytes of one row), a
+// Lanes run along the grid (every load is 512 contiguous bytes of one row --
+// ascending for the slots, descending for their mirrors), a
 // wave owns RB = RL_LR_RB(R) rows and keeps their RB x R running sums in registers over
 // the `steps` points of each lane (a multiple of RL_LR_T, chosen by the host: long
 // chunks amortise the reduction); the 64 lanes are summed once per chunk
@@ -89,12 +100,16 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
     // consumed is requested again for the step G ahead (unconditional loads from
     // clamped points; points past the end count as zero)
     static_assert(RL_LR_T % G == 0, "ring length divides the chunk");
-    double xr[G][RB];
+    const int slots = lr_slots(m);
+    double xr[G][RB], xm[G][RB];
     auto request = [&](int slot, int step) {
         const int n = n_begin + lane + 64 * step;
-        const int nc = n < m ? n : m - 1;
+        const int nc = n < slots ? n : slots - 1;
 #pragma unroll
-        for (int r = 0; r < RB; ++r) xr[slot][r] = xrow[r][nc];
+        for (int r = 0; r < RB; ++r) {
+            xr[slot][r] = xrow[r][nc];
+            xm[slot][r] = xrow[r][m - 1 - nc];
+        }
     };
 #pragma unroll
     for (int k = 0; k < G; ++k) request(k, k);
@@ -103,18 +118,25 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const int n = n_begin + lane + 64 * (t + k);
-            const double s = lr_point(n, m);
-            const double live = n < m ? 1.0 : 0.0;
-            double x[RB];
+            const int nc = n < slots ? n : slots - 1;
+            const double s = lr_point(nc, m);
+            const double live = n < slots ? 1.0 : 0.0;
+            const double pair = m - 1 - nc != nc ? live : 0.0;     // (the centre has no mirror)
+            double xe[RB], xo[RB];          // what the even / the odd degrees see
 #pragma unroll
-            for (int r = 0; r < RB; ++r) x[r] = xr[k][r] * live;
+            for (int r = 0; r < RB; ++r) {
+                const double a = xr[k][r] * live, b = xm[k][r] * pair;
+                xe[r] = a + b;
+                xo[r] = a - b;
+            }
             // (the last G requests repeat the chunk's last step: no branch, a cache hit)
             request(k, t + k + G < steps ? t + k + G : steps - 1);
             double qm = 0.0, q = 1.0;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
 #pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r][j] = fma(q, x[r], acc[r][j]);
+                for (int r = 0; r < RB; ++r)
+                    acc[r][j] = fma(q, (j & 1) ? xo[r] : xe[r], acc[r][j]);
                 const double qn = fma(s, q, -beta[j] * qm);
                 qm = q;
                 q = qn;
@@ -202,48 +224,47 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
 
 // ---------------------------------------------------------------------------
 // k_lr_expand<R>: Y[row][n] = sum_j q_j(n) Zhat[row][j]  (Zhat carries nu).
-//   grid (ceil(m / (256 NP)), ceil(nrows / rows_per_block))   block 256
-// A thread owns NP = RL_LR_NP grid points (256 apart; two per thread measured
-// 318 vs 250 us at C5, non-temporal stores 271 vs 243): their R basis values
-// (recurrence, once) stay in registers for all the rows of the block; the
-// coefficients of a row are the same for every lane (scalar loads).
+//   grid (ceil(slots / 256), ceil(nrows / rows_per_block))   block 256
+// A thread owns one slot (a grid point and its mirror): the R basis values of
+// the point (recurrence, once) stay in registers for all the rows of the block;
+// the coefficients of a row are the same for every lane (scalar loads); the even
+// and the odd degrees are summed separately, y(n) is their sum and y(mirror)
+// their difference.  (Measured and dropped: two slots per thread 318 vs 250 us
+// at C5, two rows of coefficients in flight 324 -- the scalar registers run
+// out --, non-temporal stores 271 vs 243.)
 // ---------------------------------------------------------------------------
-#define RL_LR_NP 1
 template <int R>
 __global__ void __launch_bounds__(256)
 k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __restrict__ beta,
             int rows_per_block, double* __restrict__ Y) {
-    const int n0 = blockIdx.x * (256 * RL_LR_NP) + threadIdx.x;
+    const int slots = lr_slots(m);
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int nc = n < slots ? n : slots - 1;
+    const int mir = m - 1 - nc;
+    const bool live = n < slots, pair = live && mir != nc;
     const int row0 = blockIdx.y * rows_per_block;
     const int row1 = row0 + rows_per_block < nrows ? row0 + rows_per_block : nrows;
-    double p[RL_LR_NP][R];
-#pragma unroll
-    for (int c = 0; c < RL_LR_NP; ++c) {
-        const int n = n0 + 256 * c;
-        const double s = lr_point(n < m ? n : m - 1, m);
+    const double s = lr_point(nc, m);
+    double p[R];
+    {
         double qm = 0.0, q = 1.0;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            p[c][j] = q;
+            p[j] = q;
             const double qn = fma(s, q, -beta[j] * qm);
             qm = q;
             q = qn;
         }
     }
-    auto one_row = [&](const double* __restrict__ z, int row) {
+    for (int row = row0; row < row1; ++row) {
+        const double* z = Zhat + (size_t)row * R;
+        double ev = 0.0, od = 0.0;
 #pragma unroll
-        for (int c = 0; c < RL_LR_NP; ++c) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int j = 0; j + 1 < R; j += 2) {
-                s0 = fma(z[j], p[c][j], s0);
-                s1 = fma(z[j + 1], p[c][j + 1], s1);
-            }
-            const int n = n0 + 256 * c;
-            if (n < m) Y[(size_t)row * m + n] = s0 + s1;
+        for (int j = 0; j + 1 < R; j += 2) {
+            ev = fma(z[j], p[j], ev);
+            od = fma(z[j + 1], p[j + 1], od);
         }
-    };
-    // (one row at a time: with the coefficients of two rows requested together the
-    // scalar registers run out and the loads are staggered -- 324 vs 250 us at C5)
-    for (int row = row0; row < row1; ++row) one_row(Zhat + (size_t)row * R, row);
+        if (live) Y[(size_t)row * m + nc] = ev + od;
+        if (pair) Y[(size_t)row * m + mir] = ev - od;
+    }
 }

@@ -1212,7 +1212,8 @@ static int lr_make_basis(rl_gridop* g) {
     return RL_OK;
 }
 
-// Projection chunks of 64 * steps grid points, steps a multiple of RL_LR_T: the
+// Projection chunks of 64 * steps slots (a grid point of the first half and its
+// mirror, rl_lowrank.h), steps a multiple of RL_LR_T: the
 // longest chunk (the 64-lane reduction at its end costs about 8 lane-steps) that
 // still leaves whole rounds of resident workgroups (2 per CU) well filled.
 static int lr_steps(const rl_gridop* g, int nrows, int R) {
@@ -1221,7 +1222,7 @@ static int lr_steps(const rl_gridop* g, int nrows, int R) {
     int best = RL_LR_T;
     double best_cost = 1e300;
     for (int steps = RL_LR_T; steps <= 8 * RL_LR_T; steps *= 2) {
-        const int chunks = (g->m + 64 * steps - 1) / (64 * steps);
+        const int chunks = ((g->m + 1) / 2 + 64 * steps - 1) / (64 * steps);
         const double rounds = std::ceil((double)chunks * rowblocks / resident);
         const double cost = rounds * (steps + 8);
         if (cost < best_cost * 0.97) {          // (longer only for a real gain)
@@ -1233,7 +1234,9 @@ static int lr_steps(const rl_gridop* g, int nrows, int R) {
     return best;
 }
 // partial sums: sized for the shortest chunks
-static int lr_nchunks_max(const rl_gridop* g) { return (g->m + 64 * RL_LR_T - 1) / (64 * RL_LR_T); }
+static int lr_nchunks_max(const rl_gridop* g) {
+    return ((g->m + 1) / 2 + 64 * RL_LR_T - 1) / (64 * RL_LR_T);
+}
 static size_t lr_part_need(const rl_gridop* g, int nvec) {
     return (size_t)lr_nchunks_max(g) * nvec * g->D * RL_LR_RMAX;
 }
@@ -1272,7 +1275,7 @@ static size_t lr_min_elements() {
 template <int R>
 static int lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) {
     const int steps = lr_steps(g, nrows, R);
-    const int chunks = (g->m + 64 * steps - 1) / (64 * steps);
+    const int chunks = ((g->m + 1) / 2 + 64 * steps - 1) / (64 * steps);
     RL_LAUNCH((k_lr_project<R>), dim3(chunks, (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R)),
               dim3(64 * RL_LR_WAVES), (size_t)RL_LR_WAVES * R * 65 * sizeof(double), st, X, nrows,
               g->m, (const double*)g->lr_beta, steps, g->lr_part);
@@ -1293,7 +1296,7 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
     // against 270 with 258 rows in ONE round and 390 with 645), otherwise as many
     // row blocks as make one round.  Resident workgroups per CU: 8 (52 VGPRs).
     const int per_cu = 8;
-    const int nbx = (g->m + 256 * RL_LR_NP - 1) / (256 * RL_LR_NP);
+    const int nbx = ((g->m + 1) / 2 + 255) / 256;        // slots: a point and its mirror
     int rpb = 32;
     if ((size_t)nbx * ((nrows + 31) / 32) < (size_t)2 * per_cu * RL_LR_CUS) {
         const int nby = std::max(1, std::min(nrows, per_cu * RL_LR_CUS / nbx));

@@ -765,7 +765,7 @@ def check_polynomial_form():
     saved = {k: os.environ.pop(k, None) for k in knobs}
     rng = np.random.RandomState(21)
     try:
-        for D, Q, m, k in ((3, 2, 2500, 5), (2, 3, 4100, 2)):
+        for D, Q, m, k in ((3, 2, 2500, 5), (2, 3, 4101, 2)):     # (even and odd grids)
             x = np.linspace(0, 1, m)
             smooth = np.array([np.exp(-0.5 * (1 + 2.0 * q) * x ** 2) for q in range(Q)])
             smooth[Q - 1] = np.exp(-2 * np.sin(np.pi * x / 1.7) ** 2 / 1.3 ** 2)    # periodic
