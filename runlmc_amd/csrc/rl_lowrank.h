@@ -85,8 +85,11 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);       // [WAVES][R][65]
     const int tid = threadIdx.x, lane = tid & 63, wave = RL_LR_UNIFORM(tid >> 6);
-    const int row0 = blockIdx.y * ROWS + wave * RB;
-    const int n_begin = blockIdx.x * (64 * steps);
+    // (chunk fastest: consecutive workgroups read neighbouring chunks of the same
+    // rows; the row-fastest order that pays in the expansion measured 206 vs 190 us here)
+    const int pbx = blockIdx.x, pby = blockIdx.y;
+    const int row0 = pby * ROWS + wave * RB;
+    const int n_begin = pbx * (64 * steps);
     const double* xrow[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -161,9 +164,9 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
                 s2 += src[l + 2];
                 s3 += src[l + 3];
             }
-            const int row = blockIdx.y * ROWS + w * RB + r;
+            const int row = pby * ROWS + w * RB + r;
             if (row < nrows)
-                part[((size_t)blockIdx.x * nrows + row) * R + j] = (s0 + s1) + (s2 + s3);
+                part[((size_t)pbx * nrows + row) * R + j] = (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
     }
@@ -238,11 +241,17 @@ __global__ void __launch_bounds__(256)
 k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __restrict__ beta,
             int rows_per_block, double* __restrict__ Y) {
     const int slots = lr_slots(m);
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    // workgroups are numbered with the ROW block fastest: consecutive workgroups
+    // write the same columns of different rows (measured at C5: 204-215 us against
+    // 252-266 with the column block fastest, where the whole chip writes the same
+    // few rows in lockstep)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int bx = lin / gridDim.y, by = lin - bx * gridDim.y;
+    const int n = bx * 256 + threadIdx.x;
     const int nc = n < slots ? n : slots - 1;
     const int mir = m - 1 - nc;
     const bool live = n < slots, pair = live && mir != nc;
-    const int row0 = blockIdx.y * rows_per_block;
+    const int row0 = by * rows_per_block;
     const int row1 = row0 + rows_per_block < nrows ? row0 + rows_per_block : nrows;
     const double s = lr_point(nc, m);
     double p[R];

@@ -1290,15 +1290,16 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
               (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
               (const double*)g->lr_nu, g->lr_zhat);
-    // rows per expansion workgroup: the basis values of a point are generated once
-    // per workgroup (48 instructions against 26 per row).  32 rows when that makes
-    // at least two resident rounds of workgroups (measured at C5, 1290 rows: 243 us
-    // against 270 with 258 rows in ONE round and 390 with 645), otherwise as many
-    // row blocks as make one round.  Resident workgroups per CU: 8 (52 VGPRs).
+    // rows per expansion workgroup: the basis values of a slot are generated once
+    // per workgroup (48 instructions against 14 per row and slot).  16 rows when
+    // that makes at least two resident rounds of workgroups (measured at C5, 1290
+    // rows, row blocks numbered fastest: 4 / 8 / 16 / 32 rows: 200-211 us, flat),
+    // otherwise as many row blocks as make one round.  Resident workgroups per
+    // CU: 8 (58 VGPRs).
     const int per_cu = 8;
     const int nbx = ((g->m + 1) / 2 + 255) / 256;        // slots: a point and its mirror
-    int rpb = 32;
-    if ((size_t)nbx * ((nrows + 31) / 32) < (size_t)2 * per_cu * RL_LR_CUS) {
+    int rpb = 16;
+    if ((size_t)nbx * ((nrows + 15) / 16) < (size_t)2 * per_cu * RL_LR_CUS) {
         const int nby = std::max(1, std::min(nrows, per_cu * RL_LR_CUS / nbx));
         rpb = (nrows + nby - 1) / nby;
     }
