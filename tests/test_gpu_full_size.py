@@ -92,6 +92,31 @@ def test_c5_grid_mvm_vs_oracle(c5, c5_gridop, nvec, check):
     assert _rel(alone, Y[check[-1]]) < 1e-13
 
 
+def test_c5_both_forms_of_the_product(c5, c5_gridop):
+    """The 129-vector C5 batch runs in the polynomial-subspace form (rank 24,
+    accepted at set time); the same batch forced onto the transform kernels of the
+    same handle agrees on EVERY vector to 1e-12 of the result's largest entry, and
+    so do the single-top products the gradient uses (rl_gridop_mvm_top)."""
+    g = c5_gridop
+    rank, gate = g.form()
+    assert rank == 24 and 129 * c5.D * c5.m >= gate
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(129, c5.D * c5.m, dtype=torch.float64, generator=gen).to(g.device)
+    poly = g.mvm(X).cpu().numpy()
+    poly_top = g.mvm(X, top=c5.Q - 1).cpu().numpy()
+    g.set_form_gate(1 << 62)
+    try:
+        fft = g.mvm(X).cpu().numpy()
+        fft_top = g.mvm(X, top=c5.Q - 1).cpu().numpy()
+    finally:
+        g.set_form_gate(-1)
+    assert not np.array_equal(poly, fft)             # (two different kernels ran)
+    scale = np.abs(fft).max(axis=1, keepdims=True)
+    assert (np.abs(poly - fft) / scale).max() < 1e-12
+    scale = np.abs(fft_top).max(axis=1, keepdims=True)
+    assert (np.abs(poly_top - fft_top) / scale).max() < 1e-12
+
+
 def test_c5_full_operator_vs_oracle(native, c5, c5_gridop):
     """K~ = W K_UU W^T + eps at n = 10^6 on a 129-vector batch (LDS-staged
     W^T / W products and sorted data order by size); three of the outputs
