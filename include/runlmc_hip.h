@@ -72,7 +72,7 @@ int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int
  *   RUNLMC_NO_LOWRANK=1 keeps every handle on the transform kernels.        */
 int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements);
 /* Moves that batch gate for this handle (0: every batch; < 0: back to the
- * default, 2^23 elements or RUNLMC_LR_MIN).  Below the gate the polynomial
+ * default, 2^20 elements or RUNLMC_LR_MIN).  Below the gate the polynomial
  * form is slower than the transform kernels (too few workgroups).           */
 int rl_gridop_set_form_gate(rl_gridop* g, long long min_elements);
 /* Parameters of the LMC kernel, in the reference's own factored form

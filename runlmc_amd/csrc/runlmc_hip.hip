@@ -1260,13 +1260,15 @@ static int lr_reserve(rl_gridop* g, int nvec) {
     return RL_OK;
 }
 
-// default gate: batches below this many elements stay on the transform path
-// (C2's 17 vectors: 20.7 us there against 75 us here -- 27 projection
-// workgroups on 256 CUs); RUNLMC_LR_MIN / rl_gridop_set_form_gate override it
+// default gate: batches below this many elements (k * D * m) stay on the transform
+// path.  Measured (tools/form_crossover.py): at the C2 grid the two forms meet at 32
+// vectors (0.64 M elements: 28 us each; 17 vectors 28 vs 19 us, 64 vectors 30 vs
+// 33 us, 256 vectors 39 vs 83 us), at the C5 grid a two-vector batch (2 M elements)
+// already takes 37 against 60 us.  RUNLMC_LR_MIN / rl_gridop_set_form_gate override.
 static size_t lr_min_elements() {
     static const size_t v = [] {
         const char* e = getenv("RUNLMC_LR_MIN");
-        return e ? (size_t)atoll(e) : (size_t)1 << 23;
+        return e ? (size_t)atoll(e) : (size_t)1 << 20;
     }();
     return v;
 }
