@@ -18,5 +18,6 @@ python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail 
 tools/r02_nllprof.sh final > $out/nllprof.txt 2>&1
 python3 tools/grad_accuracy.py > $out/grad_accuracy.txt 2>&1
 python3 tools/mall_probe.py > $out/mall_probe.txt 2>&1
+python3 tools/form_crossover.py > $out/form_crossover.txt 2>&1
 for w in fx2007 weather weather1000 synth; do python3 examples/fit_real_data.py $w 10 > $out/fit_$w.txt 2>&1; tail -1 $out/fit_$w.txt; done
 tail -c 1500 $out/bench_default.txt
