@@ -279,3 +279,64 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
         if (pair) Y[(size_t)row * m + mir] = ev - od;
     }
 }
+
+// ---------------------------------------------------------------------------
+// Row-wise pieces for SMALL systems (rl_solver.h, Minres2Bufs::poly_part): with
+// K_UU = Phi M Phi^T a solver round needs no grid vector at all.  A data row i of
+// output d interpolates the four grid points n_i .. n_i + 3 with weights w_i:
+//   (W Phi)[i, j] = sum_e w_i[e] Phi_j(n_i + e)
+// so the projection of W^T y is accumulated row by row (lr_row_accumulate) and the
+// four grid values of a row come straight from the r mixed coefficients of its
+// output (lr_row_values) -- four recurrences per row each way, rank RL_LR_RS.
+// Points past the end of the grid only ever meet zero weights (the polynomial is
+// finite there).
+// ---------------------------------------------------------------------------
+#define RL_LR_RS 24
+// g[e] = sum_j z[j] q_j(n + e),  e < 4   (z carries the normalisation)
+__device__ __forceinline__ void lr_row_values(const double* z, const double* __restrict__ beta,
+                                              int n, int m, double g[4]) {
+    double s[4], qm[4], q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] = lr_point(n + e, m);
+        qm[e] = 0.0;
+        q[e] = 1.0;
+        g[e] = 0.0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < RL_LR_RS; ++j) {
+        const double zj = z[j], bj = beta[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            g[e] = fma(zj, q[e], g[e]);
+            const double qn = fma(s[e], q[e], -bj * qm[e]);
+            qm[e] = q[e];
+            q[e] = qn;
+        }
+    }
+}
+// acc[j] += y * sum_e w[e] q_j(n + e)
+__device__ __forceinline__ void lr_row_accumulate(double acc[RL_LR_RS],
+                                                  const double* __restrict__ beta, int n, int m,
+                                                  const double w[4], double y) {
+    double s[4], qm[4], q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] = lr_point(n + e, m);
+        qm[e] = 0.0;
+        q[e] = 1.0;
+    }
+#pragma unroll
+    for (int j = 0; j < RL_LR_RS; ++j) {
+        const double bj = beta[j];
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t = fma(w[e], q[e], t);
+            const double qn = fma(s[e], q[e], -bj * qm[e]);
+            qm[e] = q[e];
+            q[e] = qn;
+        }
+        acc[j] = fma(y, t, acc[j]);
+    }
+}

@@ -508,7 +508,71 @@ struct Minres2Bufs {
     int eps_runs;
     int eps_end[RL_MAX_D];
     double eps_val[RL_MAX_D];
+    // SMALL systems through the polynomial form (poly_part != NULL; rl_lowrank.h,
+    // "row-wise pieces"): a round is P and B alone.  B ends with the projection of
+    // W^T y_r accumulated over its rows (a row block lies inside ONE output: poly_tab),
+    // P starts by mixing the r D coefficients of its system (sum over the blocks of
+    // every output, then sum_q B_q (x) C_q) and evaluates the four grid values of
+    // each of its rows from them.  The round counter is two counters, each written
+    // by the tail of one kernel and read by the other (giter: B -> P, giter2: P -> B).
+    const int* poly_tab;      // [nblk][3]: first row, end row, output of a row block
+    const int* poly_ob;       // [D + 1]: first block of each output
+    double* poly_part;        // [nrhs][nblk][RL_LR_RS], unnormalised basis
+    const double* poly_C;     // [Q][r][r]
+    const double* poly_B;     // [Q][D][D]
+    const double* poly_nu;    // [r]
+    const double* poly_beta;  // [r]
+    int poly_Q, poly_D, poly_m;
+    int* giter2;
 };
+
+// sum of acc[j] over the workgroup -> out[j] (thread j writes), j < RL_LR_RS
+__device__ __forceinline__ void block_reduce_rs(const double acc[RL_LR_RS], double* red,
+                                                double* out) {
+#if defined(RL_EMU)
+    for (int j = 0; j < RL_LR_RS; ++j) {
+        const double v = block_reduce_sum(acc[j], red);
+        if ((int)threadIdx.x == j) out[j] = v;
+    }
+#else
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int j = 0; j < RL_LR_RS; ++j) {
+        const double v = wave_sum(acc[j]);
+        if (lane == 0) red[wave * RL_LR_RS + j] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < RL_LR_RS) {
+        double r = 0.0;
+        for (int i = 0; i < nw; ++i) r += red[i * RL_LR_RS + threadIdx.x];
+        out[threadIdx.x] = r;
+    }
+    __syncthreads();
+#endif
+}
+
+// projection partials of an arbitrary batch of data-space vectors (the first
+// round's y_0 = b):  part[rhs][blk][j] = sum_{i in block} y_i (W Phi~)[i, j]
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_poly_project_rows(const double* __restrict__ Yv, int n, Minres2Bufs mb) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int lo = mb.poly_tab[3 * blk], hi = mb.poly_tab[3 * blk + 1];
+    const int dout = mb.poly_tab[3 * blk + 2];
+    double acc[RL_LR_RS];
+#pragma unroll
+    for (int j = 0; j < RL_LR_RS; ++j) acc[j] = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        double w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = mb.W4_w[(size_t)4 * i + e];
+        lr_row_accumulate(acc, mb.poly_beta, mb.W4_base[i] - dout * mb.poly_m, mb.poly_m, w,
+                          Yv[(size_t)rhs * n + i]);
+    }
+    block_reduce_rs(acc, red, mb.poly_part + ((size_t)rhs * nblk + blk) * RL_LR_RS);
+}
+
 
 // init: x = 0, y_{-1} unused, y_0 = b, w = 0; partial = b.b from k_dot_partial(b, b)
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
@@ -545,7 +609,10 @@ k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ p
         it[I_ITN] = 0;
         it[I_ISTOP] = beta1 > 0.0 ? 0 : RL_ISTOP_ZERO_RHS;
         it[I_ACTIVE] = beta1 > 0.0 ? 1 : 0;
-        if (rhs == 0) *mb.giter = 0;
+        if (rhs == 0) {
+            *mb.giter = mb.poly_part != nullptr ? 1 : 0;
+            if (mb.poly_part != nullptr) *mb.giter2 = 0;
+        }
     }
 }
 
@@ -559,6 +626,9 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     const int p2 = par;                     // (round - 1) & 1, from the host
     const double* si = mb.S[p2] + (size_t)rhs * S_NFIELDS;
     double* so = mb.S[1 - p2] + (size_t)rhs * S_NFIELDS;
+    // (polynomial rounds: hand the round number on to B, which reads giter2 only)
+    if (mb.poly_part != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *mb.giter2 = *mb.giter;
     if (!mb.I[rhs * I_NFIELDS + I_ACTIVE]) {
         // keep the two copies identical for frozen systems
         if (blockIdx.x == 0 && threadIdx.x < S_NFIELDS) so[threadIdx.x] = si[threadIdx.x];
@@ -580,6 +650,13 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     constexpr int PF = 4;
     int lo, hi;
     block_range(n, &lo, &hi);
+    const bool poly = mb.poly_part != nullptr;
+    int dout = 0;
+    if (poly) {
+        lo = mb.poly_tab[3 * blockIdx.x];
+        hi = mb.poly_tab[3 * blockIdx.x + 1];
+        dout = mb.poly_tab[3 * blockIdx.x + 2];
+    }
     const size_t off = (size_t)rhs * n;
     const double* g = mb.W_indptr != nullptr ? mb.g + (size_t)rhs * mb.ngrid : nullptr;
     double pr2[PF], pr1[PF], pq[PF], pw1[PF], pw2[PF], px[PF];
@@ -660,7 +737,54 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
             pq[u] = fma(eps_row(i < hi ? i : rlast), pr2[u], pq[u]);
         }
     }
-    if (ell) {
+    if (ell && poly) {
+        // mixed coefficients of this block's output from B's projection partials:
+        //   Z[b][j]  = nu_j sum_{blocks of output b} part[rhs][blk][j]
+        //   Zh[i]    = nu_i sum_q sum_b B_q[dout][b] sum_j C_q[i][j] Z[b][j]
+        constexpr int RS = RL_LR_RS;
+        const int D = mb.poly_D, Q = mb.poly_Q;
+        double* Zs = red + 2 * RL_SOLVER_THREADS;      // [D][RS]
+        double* Us = Zs + D * RS;                       // [D][RS]
+        double* Zh = Us + D * RS;                       // [RS]
+        for (int e = threadIdx.x; e < D * RS; e += blockDim.x) {
+            const int b = e / RS, j = e - b * RS;
+            double sum = 0.0;
+            for (int kb = mb.poly_ob[b]; kb < mb.poly_ob[b + 1]; ++kb)
+                sum += mb.poly_part[((size_t)rhs * nblk + kb) * RS + j];
+            Zs[e] = mb.poly_nu[j] * sum;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < D * RS; e += blockDim.x) {
+            const int b = e / RS, i = e - b * RS;
+            double u = 0.0;
+            for (int q = 0; q < Q; ++q) {
+                const double* c = mb.poly_C + ((size_t)q * RS + i) * RS;
+                double t = 0.0;
+                for (int j = 0; j < RS; ++j) t = fma(c[j], Zs[b * RS + j], t);
+                u = fma(mb.poly_B[((size_t)q * D + dout) * D + b], t, u);
+            }
+            Us[e] = u;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < RS) {
+            double t = 0.0;
+            for (int b = 0; b < D; ++b) t += Us[b * RS + threadIdx.x];
+            Zh[threadIdx.x] = mb.poly_nu[threadIdx.x] * t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (lo + u * (int)blockDim.x >= hi) break;       // (uniform: no row of this group)
+            const int i = lo + threadIdx.x + u * blockDim.x;
+            const int ic = i < hi ? i : rlast;
+            double gv[NZ];
+            lr_row_values(Zh, mb.poly_beta, eb[u] - dout * mb.poly_m, mb.poly_m, gv);
+            double qi = mb.eps != nullptr ? mb.eps[ic] * pr2[u] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) qi = fma(ew[u][j], gv[j], qi);
+            pq[u] = qi;
+        }
+    } else if (ell) {
         double gv[PF][NZ];
 #pragma unroll
         for (int u = 0; u < PF; ++u)
@@ -921,6 +1045,15 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
     double* y = mb.tri[p2];
     int lo, hi;
     block_range(n, &lo, &hi);
+    const bool poly = mb.poly_part != nullptr;
+    int dout = 0;
+    if (poly) {
+        lo = mb.poly_tab[3 * blockIdx.x];
+        hi = mb.poly_tab[3 * blockIdx.x + 1];
+        dout = mb.poly_tab[3 * blockIdx.x + 2];
+        // (the next P reads giter only: written here, read by no workgroup of B)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *mb.giter = *mb.giter2 + 1;
+    }
     const size_t off = (size_t)rhs * n;
     constexpr int PF = 4;
     double py[PF], pr[PF];
@@ -938,7 +1071,7 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
     double xx = 0.0, alfa = 0.0;
     sum2_partials(go ? mb.partC + (size_t)rhs * nblk : nullptr,
                   go ? mb.partA[1 - p2] + (size_t)rhs * nblk : nullptr, nblk, red, &xx, &alfa);
-    const int round = *mb.giter;
+    const int round = poly ? *mb.giter2 : *mb.giter;
     if (go && round >= 2) {
         // every workgroup of this system takes the same decision from the same
         // numbers; workgroup 0 records it
@@ -957,14 +1090,37 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
         const double beta = so[S_BETA];
         const double coef = alfa / beta;      // SciPy: y -= (alfa / beta) r2, r2 unnormalised
         double acc = 0.0;
+        double yn[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int i = lo + threadIdx.x + u * blockDim.x;
+            yn[u] = 0.0;
             if (i < hi) {
                 const double yi = py[u] - coef * pr[u];
                 y[off + i] = yi;
+                yn[u] = yi;
                 acc = fma(yi, yi, acc);
             }
+        }
+        if (poly) {
+            // projection of W^T y_r over this block's rows (all inside output dout;
+            // a block has at most PF * blockDim.x rows)
+            double pa[RL_LR_RS];
+#pragma unroll
+            for (int j = 0; j < RL_LR_RS; ++j) pa[j] = 0.0;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (lo + u * (int)blockDim.x >= hi) break;   // (uniform: no row of this group)
+                const int i = lo + threadIdx.x + u * blockDim.x;
+                const int ic = i < hi ? i : (hi > lo ? hi - 1 : lo);
+                double w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = mb.W4_w[(size_t)4 * ic + e];
+                lr_row_accumulate(pa, mb.poly_beta, mb.W4_base[ic] - dout * mb.poly_m,
+                                  mb.poly_m, w, yn[u]);
+            }
+            block_reduce_rs(pa, red + 2 * RL_SOLVER_THREADS,
+                            mb.poly_part + ((size_t)rhs * nblk + blockIdx.x) * RL_LR_RS);
         }
         int it0 = lo + threadIdx.x + PF * blockDim.x;
         for (; it0 + (PF - 1) * (int)blockDim.x < hi; it0 += PF * blockDim.x) {

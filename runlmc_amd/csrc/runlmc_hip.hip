@@ -251,6 +251,9 @@ struct rl_gridop {
     // polynomial-subspace form for smooth kernels (rl_lowrank.h)
     bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
     bool lr_ok = false;         // verified against the FFT path for the current parameters
+    int lr_rejects = 0;         // consecutive parameter sets the verification rejected: after
+                                // three the handle stops trying (Matern fits would pay the
+                                // set-time work at every optimiser step for nothing)
     bool lr_dirty = false;      // parameters changed since the last verification: the
                                 // set-time work (lr_setup) runs when the first batch above
                                 // the gate asks for it -- small-batch users never pay it
@@ -537,7 +540,9 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     g->v2 = g->code1 != 0 && rows_ok && getenv("RUNLMC_FORCE_V1") == nullptr;
     // polynomial-subspace form (rl_lowrank.h): 1-D grids long enough for the
     // three-kernel FFT path, decided per parameter set by verification
-    g->lr_try = m1 == 0 && m >= 2048 && getenv("RUNLMC_NO_LOWRANK") == nullptr;
+    // (short grids only matter to the solver's opt-in polynomial rounds)
+    g->lr_try = m1 == 0 && m >= (getenv("RUNLMC_POLY_ROUND") != nullptr ? 2 * RL_LR_RMAX : 2048) &&
+                getenv("RUNLMC_NO_LOWRANK") == nullptr;
     g->lr_min = lr_min_elements();
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
@@ -1373,6 +1378,7 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
     std::vector<double> h1(vec), h2(vec), hnu(RL_LR_RMAX);
     RL_HIP(hipMemcpy(hnu.data(), g->lr_nu, hnu.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int r : {24, 32, 48}) {
+        if (r > 24 && m < 2048) break;      // (short grids: only the solver's rank-24 rounds use the form)
         g->lr_r = r;
         const int nvr = (r + D - 1) / D;
         RL_TRY(lr_reserve(g, std::max(nvr, 1)));
@@ -1423,9 +1429,11 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
         }
         if (ok) {
             g->lr_ok = true;
+            g->lr_rejects = 0;
             return RL_OK;
         }
     }
+    if (++g->lr_rejects >= 3) g->lr_try = false;
     return RL_OK;
 }
 
@@ -1614,6 +1622,7 @@ struct SkiTerm {
     // (k_spmv_wt_staged stages them in LDS); 0 = no structure
     int wt_xmax = 0, wt_emax = 0;
     int w_xmax = 0;            // largest grid range of RL_THREADS consecutive data rows
+    std::vector<int> h_base;   // host copy of W4_base (row blocks per output, polynomial rounds)
 };
 
 // buffers of one rl_solve_batch call
@@ -1652,6 +1661,13 @@ struct rl_ski {
     // Internal row order: data points sorted by grid position (W, WT and
     // noise_diag above are stored in THAT order); perm[i] = caller's row of
     // internal row i.  P1/P2: dev [pcap][n] staging for caller-order entry points.
+    // polynomial rounds of small solves (rl_solver.h, Minres2Bufs::poly_part): row
+    // blocks that lie inside one output, first block of each output, partial sums
+    std::vector<int> h_base;
+    int *poly_tab = nullptr, *poly_ob = nullptr;
+    int poly_nblk = 0;              // 0: not built yet, -1: not applicable
+    double* poly_part = nullptr;
+    size_t poly_part_cap = 0;
     std::vector<int> eps_end;       // noise in runs: rows [eps_end[k-1], eps_end[k]) carry eps_val[k]
     std::vector<double> eps_val;    // (empty: more than RL_MAX_D runs)
     bool permuted = false;
@@ -1789,6 +1805,7 @@ static int upload_term(SkiTerm* t, int n, int ngrid, const int* W_indptr, const 
                     sp_val.push_back(w4[(size_t)4 * i + (r - base[i])]);
                 }
             }
+            t->h_base = base;
             RL_TRY(upload_raw((void**)&t->W4_base, base.data(), (size_t)n * sizeof(int)));
             RL_TRY(upload_raw((void**)&t->W4_w, w4.data(), (size_t)4 * n * sizeof(double)));
             RL_TRY(upload_raw((void**)&t->WT_lo, lo.data(), (size_t)ngrid * sizeof(int)));
@@ -1855,6 +1872,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     s->W_indptr = t0.W_indptr; s->W_indices = t0.W_indices; s->W_data = t0.W_data;
     s->WT_indptr = t0.WT_indptr; s->WT_indices = t0.WT_indices; s->WT_data = t0.WT_data;
     s->W4_base = t0.W4_base; s->W4_w = t0.W4_w; s->WT_lo = t0.WT_lo; s->nnzWT = t0.nnzWT;
+    s->h_base.swap(t0.h_base);
     s->wt_xmax = t0.wt_xmax; s->wt_emax = t0.wt_emax; s->w_xmax = t0.w_xmax;
     s->max_ngrid = ngrid;
     s->nnz = W_indptr[n];
@@ -1906,7 +1924,8 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     if (s->ws_valid) free_work(s->ws);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
-                    s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf};
+                    s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
+                    s->poly_part};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -2289,12 +2308,79 @@ static int minres_iteration(rl_ski* s, const MinresBufs& mb, SolverWork& w, int 
 // unnormalised Lanczos vector, P, B; identical arguments every round
 static bool g_is_v2(const rl_gridop* g) { return g->v2; }
 
+// Polynomial rounds of a small MINRES solve (rl_solver.h): are they possible for
+// this handle and batch, and if so build (once) the row blocks -- at most 1024 rows,
+// each inside ONE output -- and make sure the form is verified at rank RL_LR_RS.
+// OPT-IN (RUNLMC_POLY_ROUND=1), parity-tested, not the default: measured at C2 a
+// round is 19 + 17 us in two kernels against 42 us in five, but the per-step
+// verification (0.54 ms) and the unchanged rest of a step leave the NLL + gradient
+// step between equal and 9 % faster (7.33 vs 7.34 ms on one box, 6.99 vs 7.69 on
+// another; eps = 1: 6.0 vs 6.6 ms) -- see DESIGN.md section 8.
+static int poly_round_prepare(rl_ski* s, int nrhs, int max_blk, bool* ok) {
+    *ok = false;
+    rl_gridop* g = s->g;
+    if (!s->extra.empty() || s->W4_base == nullptr || s->h_base.empty() ||
+        !g->lr_try || s->poly_nblk < 0 || getenv("RUNLMC_POLY_ROUND") == nullptr)
+        return RL_OK;
+    if (s->poly_nblk == 0) {
+        const int D = g->D, m = g->m, n = s->n;
+        std::vector<int> tab, ob(D + 1, 0);
+        int i = 0;
+        for (int d = 0; d < D; ++d) {
+            ob[d] = (int)tab.size() / 3;
+            const int start = i;
+            while (i < n && s->h_base[i] < (d + 1) * m) ++i;
+            const int cnt = i - start;
+            // (1024 rows per block; 512 / 256 measured slower at C2: 8.1 / 11.1 against
+            // 7.0 ms per step -- every workgroup repeats the mix of its system)
+            const int nb = (cnt + 1023) / 1024;
+            for (int b = 0; b < nb; ++b) {
+                const int per = (cnt + nb - 1) / nb;
+                tab.push_back(start + b * per);
+                tab.push_back(std::min(start + (b + 1) * per, i));
+                tab.push_back(d);
+            }
+        }
+        ob[D] = (int)tab.size() / 3;
+        if (i != n || tab.empty()) {
+            s->poly_nblk = -1;
+            return RL_OK;
+        }
+        RL_TRY(upload_raw((void**)&s->poly_tab, tab.data(), tab.size() * sizeof(int)));
+        RL_TRY(upload_raw((void**)&s->poly_ob, ob.data(), ob.size() * sizeof(int)));
+        s->poly_nblk = (int)tab.size() / 3;
+    }
+    if (s->poly_nblk > std::max(max_blk, RL_SOLVER_THREADS)) return RL_OK;
+    RL_TRY(lr_ensure(g));
+    if (!g->lr_ok || g->lr_r != RL_LR_RS) return RL_OK;
+    const size_t need = (size_t)nrhs * s->poly_nblk * RL_LR_RS;
+    if (s->poly_part_cap < need) {
+        if (s->poly_part) RL_HIP(hipFree(s->poly_part));
+        s->poly_part = nullptr;
+        s->poly_part_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->poly_part, need * sizeof(double)));
+        s->poly_part_cap = need;
+    }
+    *ok = true;
+    return RL_OK;
+}
+
 static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int nblk, int round,
                          double rtol, int maxiter, hipStream_t st) {
     const int par = (round - 1) & 1;
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
     const double* yin = mb.tri[1 - par];      // y_{r-1}: the operator's input this round
+    if (mb.poly_part != nullptr) {
+        // the operator lives inside P and B (rl_solver.h: polynomial rounds)
+        trace_once("minres round: polynomial form inside P and B, no grid vectors");
+        const size_t lds = (2 * RL_SOLVER_THREADS +
+                            std::max(2 * mb.poly_D * RL_LR_RS + RL_LR_RS, RL_SOLVER_THREADS)) *
+                           sizeof(double);
+        RL_LAUNCH(k_minres2_p, grid, blk, lds, st, mb, n, par);
+        RL_LAUNCH(k_minres2_b, grid, blk, lds, st, mb, n, par, rtol, maxiter);
+        return RL_OK;
+    }
     if (mb.W_indptr != nullptr && mb.fuse_wt) {
         trace_once(g_is_v2(s->g) ? "minres round: W^T in k2_cols_fwd, W in P"
                                  : "minres round: W^T in k_cols_fwd, W in P");
@@ -2399,6 +2485,14 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     if (const char* e = getenv("RUNLMC_SOLVER_MAXBLK"))
         max_blk = std::max(1, std::min(atoi(e), RL_SOLVER_THREADS));
     nblk = std::max(1, std::min(nblk, max_blk));
+    // small single-term MINRES solves of a smooth kernel: polynomial rounds, whose
+    // row blocks follow the outputs (every other kernel of the solve takes the same
+    // NUMBER of blocks; its partial sums do not care where the block borders are)
+    bool poly_round = false;
+    if (method == RL_MINRES && getenv("RUNLMC_MINRES_V1") == nullptr &&
+        (size_t)n * nrhs < ((size_t)1 << 22) && getenv("RUNLMC_NO_FUSE_W") == nullptr)
+        RL_TRY(poly_round_prepare(s, nrhs, max_blk, &poly_round));
+    if (poly_round) nblk = s->poly_nblk;
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
     const size_t red = RL_SOLVER_THREADS * sizeof(double);
 
@@ -2479,6 +2573,21 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         mb.g = s->G2;
         mb.eps = s->has_noise ? s->noise_diag : nullptr;
         mb.ngrid = s->ngrid;
+        mb.poly_part = nullptr;
+        mb.giter2 = w.count + 3;
+        if (poly_round && fuse_w) {
+            rl_gridop* g = s->g;
+            mb.poly_tab = s->poly_tab;
+            mb.poly_ob = s->poly_ob;
+            mb.poly_part = s->poly_part;
+            mb.poly_C = g->lr_C;
+            mb.poly_B = g->lr_B;
+            mb.poly_nu = g->lr_nu;
+            mb.poly_beta = g->lr_beta;
+            mb.poly_Q = g->Q;
+            mb.poly_D = g->D;
+            mb.poly_m = g->m;
+        }
         // single-term operator, W as its own kernel, noise in a few constant runs
         // (one per output): the noise term moves into P
         mb.eps_runs = 0;
@@ -2505,6 +2614,9 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             mb.lanczos_cap = lanczos_cap;
         }
         RL_LAUNCH(k_minres2_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], mb);
+        if (mb.poly_part != nullptr)        // projection of W^T y_0 for the first round's P
+            RL_LAUNCH(k_poly_project_rows, grid, blk, 3 * RL_SOLVER_THREADS * sizeof(double), st,
+                      Bi, n, mb);
         RL_TRY(active_count(w, nrhs, st, &active));
         // x lags one round behind: after `done` rounds it holds iterate done - 1.
         // The first round runs eagerly so that graph replays of per_graph rounds

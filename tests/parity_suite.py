@@ -17,7 +17,7 @@ import torch
 
 from oracle import operators as ops
 from oracle import likelihood as olik
-from oracle.solver import iterative_solve
+from oracle.solver import iterative_solve, minres_ps
 from cases import Case, GOLDEN
 
 from runlmc_amd.linalg.bttb import BTTB
@@ -831,6 +831,86 @@ def _poly_product(g, X, top=None):
         return g.matmat_host(X, top=top)
     finally:
         g.set_form_gate(-1)
+
+
+def check_polynomial_rounds():
+    """Small MINRES solves of a smooth kernel run their rounds as P and B alone
+    (rl_solver.h, polynomial rounds: the projection of W^T y rides in B, the four
+    grid values of a row are evaluated in P).  Against the same solve on the
+    transform kernels (the default; the rounds are opt-in, RUNLMC_POLY_ROUND=1)
+    and against the oracle's MINRES:
+    iterates after a fixed number of iterations to 1e-8, converged solutions,
+    iteration counts and exit codes; ragged outputs (one of three rows), a frozen
+    system (zero right-hand side) in the batch, a second solve after a
+    parameter change."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch
+    from oracle.kernels import KernelSpec, RBFSpec
+    knobs = ('RUNLMC_POLY_ROUND', 'RUNLMC_TRACE')
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    rng = np.random.RandomState(31)
+    try:
+        for D, Q, m, ragged in ((3, 2, 300, False), (4, 1, 260, True)):
+            p = synth.make_problem(D, Q, 1, m, eps=1.0)
+            p.noise = p.noise + 1.0
+            if ragged:
+                from runlmc_amd.approx.interpolation import autogrid, multi_interpolant
+                lens = [m, 3, m - 70, 17][:D]
+                p.Xs = [np.sort(rng.rand(k)).reshape(-1, 1) for k in lens]
+                p.lens = lens
+                p.n = int(sum(lens))
+                p.Ys = [rng.rand(k) for k in lens]
+                p.y = np.hstack(p.Ys)
+                p.grid = autogrid(p.Xs, lo=None, hi=None, m=[m])[0]
+                p.grid_dists = p.grid - p.grid[0]
+                p.m = len(p.grid)
+                p.W = multi_interpolant(p.Xs, p.grid)
+                p.WT = p.W.transpose().tocsr()
+                p.WT.sort_indices()
+                p.WT.indices = p.WT.indices.astype(np.int32)
+                p.WT.indptr = p.WT.indptr.astype(np.int32)
+            fk = synth.functional_kernel(p)
+            ad = (0,)
+            B = np.vstack([p.y, np.zeros(p.n)] + [rng.randint(0, 2, p.n) * 2.0 - 1 for _ in range(3)])
+            spec = KernelSpec(p.D, [RBFSpec(g) for g in p.inv_lengthscales], list(p.coreg_vecs),
+                              list(p.coreg_diags), p.noise)
+            spec.set_input_dim(1)
+            oop = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+
+            def run(poly, maxiter=None):
+                if poly:
+                    os.environ['RUNLMC_POLY_ROUND'] = '1'
+                else:
+                    os.environ.pop('RUNLMC_POLY_ROUND', None)
+                K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+                op = K.device_operator()
+                kw = {} if maxiter is None else dict(maxiter=maxiter)
+                out = solve_batch(op, torch.from_numpy(B).to(op.device), tol=1e-4, **kw)
+                return out[0].cpu().numpy(), np.array(out[1]), np.array(out[3]), op
+
+            Xp, itp, stp, op = run(True, maxiter=6)
+            assert op.grid.form()[0] == 24       # (short grids are verified only for these rounds)
+            Xf, itf, stf, _ = run(False, maxiter=6)
+            assert np.array_equal(itp, itf) and np.array_equal(stp, stf)
+            for v in (0, 2, 4):
+                _close(Xp[v], Xf[v], 1e-8)
+                xo = minres_ps(oop.matvec, B[v], rtol=1e-10, maxiter=6)[0]
+                _close(Xp[v], xo, 1e-8)
+            assert not np.any(Xp[1])                 # the zero right-hand side stays zero
+            Xp, itp, stp, _ = run(True)
+            Xf, itf, stf, _ = run(False)
+            assert np.all(np.abs(itp - itf) <= 3), (itp, itf)
+            assert np.array_equal(stp, stf)
+            for v in (0, 2, 3, 4):
+                _close(Xp[v], Xf[v], 2e-5)
+                xo, ito, erro, _ = iterative_solve(oop.matvec, B[v], tol=1e-4)
+                assert abs(int(itp[v]) - ito) <= 5
+                _close(Xp[v], xo, 2e-5)
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
 
 
 def check_cross_dots():

@@ -159,3 +159,7 @@ def test_cross_dots():
 
 def test_polynomial_form():
     ps.check_polynomial_form()
+
+
+def test_polynomial_rounds():
+    ps.check_polynomial_rounds()
