@@ -292,7 +292,8 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
 // finite there).
 // ---------------------------------------------------------------------------
 #define RL_LR_RS 24
-// g[e] = sum_j z[j] q_j(n + e),  e < 4   (z carries the normalisation)
+// g[e] = sum_j z[j] q_j(n + e),  e < 4   (z carries the normalisation; pass it in
+// REGISTERS: read from LDS inside the recurrence it costs a round trip per degree)
 __device__ __forceinline__ void lr_row_values(const double* z, const double* __restrict__ beta,
                                               int n, int m, double g[4]) {
     double s[4], qm[4], q[4];
@@ -303,7 +304,7 @@ __device__ __forceinline__ void lr_row_values(const double* z, const double* __r
         q[e] = 1.0;
         g[e] = 0.0;
     }
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < RL_LR_RS; ++j) {
         const double zj = z[j], bj = beta[j];
 #pragma unroll

@@ -518,11 +518,9 @@ struct Minres2Bufs {
     const int* poly_tab;      // [nblk][3]: first row, end row, output of a row block
     const int* poly_ob;       // [D + 1]: first block of each output
     double* poly_part;        // [nrhs][nblk][RL_LR_RS], unnormalised basis
-    const double* poly_C;     // [Q][r][r]
-    const double* poly_B;     // [Q][D][D]
-    const double* poly_nu;    // [r]
+    const double* poly_M;     // [D][r][D][r]: nu_i nu_j sum_q B_q[a][b] C_q[i][j]
     const double* poly_beta;  // [r]
-    int poly_Q, poly_D, poly_m;
+    int poly_D, poly_m;
     int* giter2;
 };
 
@@ -535,11 +533,39 @@ __device__ __forceinline__ void block_reduce_rs(const double acc[RL_LR_RS], doub
         if ((int)threadIdx.x == j) out[j] = v;
     }
 #else
+    // halving butterfly over the 64 lanes: at distance 32 a lane keeps one half of
+    // the 24 sums and receives that half from its partner (12 exchanges), at 16 a
+    // quarter (6), at 8 an eighth (3); the last three sums of a lane go through plain
+    // exchanges at 4, 2, 1 -- 30 cross-lane moves instead of 24 x 6
+    static_assert(RL_LR_RS == 24, "butterfly written for 24 sums");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    double a[12], b[6], c[3];
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
 #pragma unroll
-    for (int j = 0; j < RL_LR_RS; ++j) {
-        const double v = wave_sum(acc[j]);
-        if (lane == 0) red[wave * RL_LR_RS + j] = v;
+    for (int k = 0; k < 12; ++k) {
+        const double mine = h5 ? acc[12 + k] : acc[k], send = h5 ? acc[k] : acc[12 + k];
+        a[k] = mine + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double mine = h4 ? a[6 + k] : a[k], send = h4 ? a[k] : a[6 + k];
+        b[k] = mine + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double mine = h3 ? b[3 + k] : b[k], send = h3 ? b[k] : b[3 + k];
+        c[k] = mine + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] += __shfl_xor(c[k], 4, 64);
+        c[k] += __shfl_xor(c[k], 2, 64);
+        c[k] += __shfl_xor(c[k], 1, 64);
+    }
+    if ((lane & 7) == 0) {
+        const int j0 = (h5 ? 12 : 0) + (h4 ? 6 : 0) + (h3 ? 3 : 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) red[wave * RL_LR_RS + j0 + k] = c[k];
     }
     __syncthreads();
     if ((int)threadIdx.x < RL_LR_RS) {
@@ -739,46 +765,51 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     }
     if (ell && poly) {
         // mixed coefficients of this block's output from B's projection partials:
-        //   Z[b][j]  = nu_j sum_{blocks of output b} part[rhs][blk][j]
-        //   Zh[i]    = nu_i sum_q sum_b B_q[dout][b] sum_j C_q[i][j] Z[b][j]
+        //   Z[b][j] = sum_{blocks of output b} part[rhs][blk][j]
+        //   Zh[i]   = sum_{b, j} M[dout][i][b][j] Z[b][j],
+        //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]  (host, per parameter update)
         constexpr int RS = RL_LR_RS;
-        const int D = mb.poly_D, Q = mb.poly_Q;
+        const int D = mb.poly_D;
         double* Zs = red + 2 * RL_SOLVER_THREADS;      // [D][RS]
-        double* Us = Zs + D * RS;                       // [D][RS]
-        double* Zh = Us + D * RS;                       // [RS]
+        double* Zh = Zs + D * RS;                       // [RS]
         for (int e = threadIdx.x; e < D * RS; e += blockDim.x) {
             const int b = e / RS, j = e - b * RS;
             double sum = 0.0;
             for (int kb = mb.poly_ob[b]; kb < mb.poly_ob[b + 1]; ++kb)
                 sum += mb.poly_part[((size_t)rhs * nblk + kb) * RS + j];
-            Zs[e] = mb.poly_nu[j] * sum;
+            Zs[e] = sum;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < D * RS; e += blockDim.x) {
-            const int b = e / RS, i = e - b * RS;
-            double u = 0.0;
-            for (int q = 0; q < Q; ++q) {
-                const double* c = mb.poly_C + ((size_t)q * RS + i) * RS;
+        {
+            // 24 dot products of length D * RS: ten threads each, then ten partial sums
+            constexpr int NP = 10;
+            double* Ps = Zh + RS;                       // [RS][NP]
+            const int i = threadIdx.x % RS, part = threadIdx.x / RS;
+            if (part < NP) {
+                const double* mrow = mb.poly_M + ((size_t)dout * RS + i) * D * RS;
                 double t = 0.0;
-                for (int j = 0; j < RS; ++j) t = fma(c[j], Zs[b * RS + j], t);
-                u = fma(mb.poly_B[((size_t)q * D + dout) * D + b], t, u);
+                for (int e = part; e < D * RS; e += NP) t = fma(mrow[e], Zs[e], t);
+                Ps[i * NP + part] = t;
             }
-            Us[e] = u;
+            __syncthreads();
+            if ((int)threadIdx.x < RS) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) t += Ps[threadIdx.x * NP + k];
+                Zh[threadIdx.x] = t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if ((int)threadIdx.x < RS) {
-            double t = 0.0;
-            for (int b = 0; b < D; ++b) t += Us[b * RS + threadIdx.x];
-            Zh[threadIdx.x] = mb.poly_nu[threadIdx.x] * t;
-        }
-        __syncthreads();
+        double zr[RS];
+#pragma unroll
+        for (int j = 0; j < RS; ++j) zr[j] = Zh[j];
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (lo + u * (int)blockDim.x >= hi) break;       // (uniform: no row of this group)
             const int i = lo + threadIdx.x + u * blockDim.x;
             const int ic = i < hi ? i : rlast;
             double gv[NZ];
-            lr_row_values(Zh, mb.poly_beta, eb[u] - dout * mb.poly_m, mb.poly_m, gv);
+            lr_row_values(zr, mb.poly_beta, eb[u] - dout * mb.poly_m, mb.poly_m, gv);
             double qi = mb.eps != nullptr ? mb.eps[ic] * pr2[u] : 0.0;
 #pragma unroll
             for (int j = 0; j < NZ; ++j) qi = fma(ew[u][j], gv[j], qi);
@@ -1066,6 +1097,21 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
             pr[u] = r2[off + i];
         }
     }
+    // (polynomial rounds: base column and weights of the rows, requested with them)
+    int pb[PF];
+    double pw[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        pb[u] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw[u][e] = 0.0;
+        const int i = lo + threadIdx.x + u * blockDim.x;
+        if (poly && go && i < hi) {
+            pb[u] = mb.W4_base[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pw[u][e] = mb.W4_w[(size_t)4 * i + e];
+        }
+    }
     // ||x||^2 of the iteration under test and alfa of the one under way (the
     // same reduction P uses: alfa must be bit-identical in both kernels)
     double xx = 0.0, alfa = 0.0;
@@ -1112,12 +1158,9 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
             for (int u = 0; u < PF; ++u) {
                 if (lo + u * (int)blockDim.x >= hi) break;   // (uniform: no row of this group)
                 const int i = lo + threadIdx.x + u * blockDim.x;
-                const int ic = i < hi ? i : (hi > lo ? hi - 1 : lo);
-                double w[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = mb.W4_w[(size_t)4 * ic + e];
-                lr_row_accumulate(pa, mb.poly_beta, mb.W4_base[ic] - dout * mb.poly_m,
-                                  mb.poly_m, w, yn[u]);
+                // (rows past the block: zero weights, zero y)
+                lr_row_accumulate(pa, mb.poly_beta, (i < hi ? pb[u] : dout * mb.poly_m) -
+                                  dout * mb.poly_m, mb.poly_m, pw[u], yn[u]);
             }
             block_reduce_rs(pa, red + 2 * RL_SOLVER_THREADS,
                             mb.poly_part + ((size_t)rhs * nblk + blockIdx.x) * RL_LR_RS);

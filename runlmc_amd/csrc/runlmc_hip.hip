@@ -266,6 +266,8 @@ struct rl_gridop {
     double* lr_nu = nullptr;    // dev [RL_LR_RMAX] normalisation
     double* lr_phiJ = nullptr;  // dev [RL_LR_RMAX][m]
     double* lr_C = nullptr;     // dev [max_tops][r][r]
+    double* lr_M = nullptr;     // dev [D][24][D][24]: the whole coefficient map (polynomial rounds)
+    std::vector<double> lr_hC;  // host copy of lr_C for it
     double* lr_B = nullptr;     // dev [max_tops][D][D]
     double* lr_eye = nullptr;   // dev [D][D]
     double* lr_part = nullptr;  // projection partial sums
@@ -602,7 +604,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     (void)hipSetDevice(g->device);
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
-                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_C,
+                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_C, g->lr_M,
                     g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1412,6 +1414,8 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
                     C[(size_t)i * r + j] = C[(size_t)j * r + i] = v;
                 }
             RL_HIP(hipMemcpy(g->lr_C + (size_t)q * r * r, C.data(), C.size() * sizeof(double), hipMemcpyHostToDevice));
+            if (g->lr_hC.size() < (size_t)Q * r * r) g->lr_hC.resize((size_t)Q * r * r);
+            std::copy(C.begin(), C.end(), g->lr_hC.begin() + (size_t)q * r * r);
             // trial: T_q xr through both forms
             g->lr_bypass = true;
             rc = mvm_with_mix(g, mp, xr, y1, 1, st);
@@ -1430,6 +1434,28 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
         if (ok) {
             g->lr_ok = true;
             g->lr_rejects = 0;
+            if (r == RL_LR_RS && getenv("RUNLMC_POLY_ROUND") != nullptr) {
+                // the whole coefficient map of the solver's polynomial rounds
+                //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
+                std::vector<double> M((size_t)D * r * D * r, 0.0);
+                for (int q = 0; q < Q; ++q)
+                    for (int a = 0; a < D; ++a)
+                        for (int b = 0; b < D; ++b) {
+                            const double bq = B[((size_t)q * D + a) * D + b];
+                            if (bq == 0.0) continue;
+                            for (int i = 0; i < r; ++i)
+                                for (int j = 0; j < r; ++j)
+                                    M[(((size_t)a * r + i) * D + b) * r + j] +=
+                                        bq * g->lr_hC[((size_t)q * r + i) * r + j];
+                        }
+                for (int a = 0; a < D; ++a)
+                    for (int i = 0; i < r; ++i)
+                        for (int b = 0; b < D; ++b)
+                            for (int j = 0; j < r; ++j)
+                                M[(((size_t)a * r + i) * D + b) * r + j] *= hnu[i] * hnu[j];
+                if (!g->lr_M) RL_HIP(hipMalloc((void**)&g->lr_M, M.size() * sizeof(double)));
+                RL_HIP(hipMemcpy(g->lr_M, M.data(), M.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
             return RL_OK;
         }
     }
@@ -2375,7 +2401,7 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         // the operator lives inside P and B (rl_solver.h: polynomial rounds)
         trace_once("minres round: polynomial form inside P and B, no grid vectors");
         const size_t lds = (2 * RL_SOLVER_THREADS +
-                            std::max(2 * mb.poly_D * RL_LR_RS + RL_LR_RS, RL_SOLVER_THREADS)) *
+                            std::max(mb.poly_D * RL_LR_RS + 11 * RL_LR_RS, RL_SOLVER_THREADS)) *
                            sizeof(double);
         RL_LAUNCH(k_minres2_p, grid, blk, lds, st, mb, n, par);
         RL_LAUNCH(k_minres2_b, grid, blk, lds, st, mb, n, par, rtol, maxiter);
@@ -2580,11 +2606,8 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             mb.poly_tab = s->poly_tab;
             mb.poly_ob = s->poly_ob;
             mb.poly_part = s->poly_part;
-            mb.poly_C = g->lr_C;
-            mb.poly_B = g->lr_B;
-            mb.poly_nu = g->lr_nu;
+            mb.poly_M = g->lr_M;
             mb.poly_beta = g->lr_beta;
-            mb.poly_Q = g->Q;
             mb.poly_D = g->D;
             mb.poly_m = g->m;
         }
