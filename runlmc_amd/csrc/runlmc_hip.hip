@@ -1434,7 +1434,7 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
         if (ok) {
             g->lr_ok = true;
             g->lr_rejects = 0;
-            if (r == RL_LR_RS && getenv("RUNLMC_POLY_ROUND") != nullptr) {
+            if (r == RL_LR_RS && getenv("RUNLMC_NO_POLY_ROUND") == nullptr) {
                 // the whole coefficient map of the solver's polynomial rounds
                 //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
                 std::vector<double> M((size_t)D * r * D * r, 0.0);
@@ -2337,16 +2337,16 @@ static bool g_is_v2(const rl_gridop* g) { return g->v2; }
 // Polynomial rounds of a small MINRES solve (rl_solver.h): are they possible for
 // this handle and batch, and if so build (once) the row blocks -- at most 1024 rows,
 // each inside ONE output -- and make sure the form is verified at rank RL_LR_RS.
-// OPT-IN (RUNLMC_POLY_ROUND=1), parity-tested, not the default: measured at C2 a
-// round is 19 + 17 us in two kernels against 42 us in five, but the per-step
-// verification (0.54 ms) and the unchanged rest of a step leave the NLL + gradient
-// step between equal and 9 % faster (7.33 vs 7.34 ms on one box, 6.99 vs 7.69 on
-// another; eps = 1: 6.0 vs 6.6 ms) -- see DESIGN.md section 8.
+// Default where the grid is eligible for the polynomial form anyway (1-D, >= 2048
+// points; RUNLMC_NO_POLY_ROUND=1 switches the rounds off, RUNLMC_POLY_ROUND=1 also
+// admits grids of 96 .. 2047 points).  Measured at C2: a round is 17 + 12 us in two
+// kernels against 42 us in five, the NLL + gradient step 6.1 against 7.5 ms
+// (eps = 1: 5.3 against 6.8) including the 0.54 ms verification per step.
 static int poly_round_prepare(rl_ski* s, int nrhs, int max_blk, bool* ok) {
     *ok = false;
     rl_gridop* g = s->g;
     if (!s->extra.empty() || s->W4_base == nullptr || s->h_base.empty() ||
-        !g->lr_try || s->poly_nblk < 0 || getenv("RUNLMC_POLY_ROUND") == nullptr)
+        !g->lr_try || s->poly_nblk < 0 || getenv("RUNLMC_NO_POLY_ROUND") != nullptr)
         return RL_OK;
     if (s->poly_nblk == 0) {
         const int D = g->D, m = g->m, n = s->n;

@@ -837,8 +837,8 @@ def check_polynomial_rounds():
     """Small MINRES solves of a smooth kernel run their rounds as P and B alone
     (rl_solver.h, polynomial rounds: the projection of W^T y rides in B, the four
     grid values of a row are evaluated in P).  Against the same solve on the
-    transform kernels (the default; the rounds are opt-in, RUNLMC_POLY_ROUND=1)
-    and against the oracle's MINRES:
+    transform kernels (short grids take these rounds only with RUNLMC_POLY_ROUND=1;
+    from 2048 grid points they are the default) and against the oracle's MINRES:
     iterates after a fixed number of iterations to 1e-8, converged solutions,
     iteration counts and exit codes; ragged outputs (one of three rows), a frozen
     system (zero right-hand side) in the batch, a second solve after a
