@@ -768,6 +768,7 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
         //   Z[b][j] = sum_{blocks of output b} part[rhs][blk][j]
         //   Zh[i]   = sum_{b, j} M[dout][i][b][j] Z[b][j],
         //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]  (host, per parameter update)
+        RL_STAMP(7);
         constexpr int RS = RL_LR_RS;
         const int D = mb.poly_D;
         double* Zs = red + 2 * RL_SOLVER_THREADS;      // [D][RS]
@@ -780,6 +781,7 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
             Zs[e] = sum;
         }
         __syncthreads();
+        RL_STAMP(8);
         {
             // 24 dot products of length D * RS: ten threads each, then ten partial sums
             constexpr int NP = 10;
@@ -800,6 +802,7 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
             }
             __syncthreads();
         }
+        RL_STAMP(9);
         double zr[RS];
 #pragma unroll
         for (int j = 0; j < RS; ++j) zr[j] = Zh[j];
@@ -1148,6 +1151,7 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
                 acc = fma(yi, yi, acc);
             }
         }
+        RL_STAMP(42);
         if (poly) {
             // projection of W^T y_r over this block's rows (all inside output dout;
             // a block has at most PF * blockDim.x rows)
@@ -1162,8 +1166,10 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
                 lr_row_accumulate(pa, mb.poly_beta, (i < hi ? pb[u] : dout * mb.poly_m) -
                                   dout * mb.poly_m, mb.poly_m, pw[u], yn[u]);
             }
+            RL_STAMP(43);
             block_reduce_rs(pa, red + 2 * RL_SOLVER_THREADS,
                             mb.poly_part + ((size_t)rhs * nblk + blockIdx.x) * RL_LR_RS);
+            RL_STAMP(44);
         }
         int it0 = lo + threadIdx.x + PF * blockDim.x;
         for (; it0 + (PF - 1) * (int)blockDim.x < hi; it0 += PF * blockDim.x) {
