@@ -294,6 +294,29 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
 #define RL_LR_RS 24
 // g[e] = sum_j z[j] q_j(n + e),  e < 4   (z carries the normalisation; pass it in
 // REGISTERS: read from LDS inside the recurrence it costs a round trip per degree)
+// (lr_point_values: the same at four arbitrary points)
+__device__ __forceinline__ void lr_point_values(const double* z, const double* __restrict__ beta,
+                                                const int n[4], int m, double g[4]) {
+    double s[4], qm[4], q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] = lr_point(n[e], m);
+        qm[e] = 0.0;
+        q[e] = 1.0;
+        g[e] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < RL_LR_RS; ++j) {
+        const double zj = z[j], bj = beta[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            g[e] = fma(zj, q[e], g[e]);
+            const double qn = fma(s[e], q[e], -bj * qm[e]);
+            qm[e] = q[e];
+            q[e] = qn;
+        }
+    }
+}
 __device__ __forceinline__ void lr_row_values(const double* z, const double* __restrict__ beta,
                                               int n, int m, double g[4]) {
     double s[4], qm[4], q[4];

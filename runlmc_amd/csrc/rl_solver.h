@@ -515,7 +515,8 @@ struct Minres2Bufs {
     // every output, then sum_q B_q (x) C_q) and evaluates the four grid values of
     // each of its rows from them.  The round counter is two counters, each written
     // by the tail of one kernel and read by the other (giter: B -> P, giter2: P -> B).
-    const int* poly_tab;      // [nblk][3]: first row, end row, output of a row block
+    const int* poly_tab;      // [nblk][RL_PT]: first row, end row, output of a row block, first
+                              // grid point (within the output) and number of grid points its rows touch
     const int* poly_ob;       // [D + 1]: first block of each output
     double* poly_part;        // [nrhs][nblk][RL_LR_RS], unnormalised basis
     const double* poly_M;     // [D][r][D][r]: nu_i nu_j sum_q B_q[a][b] C_q[i][j]
@@ -524,6 +525,8 @@ struct Minres2Bufs {
     int* giter2;
 };
 
+#define RL_PT 5             // ints per entry of Minres2Bufs::poly_tab
+#define RL_PG 2048          // grid points of a row block evaluated through LDS at most
 // sum of acc[j] over the workgroup -> out[j] (thread j writes), j < RL_LR_RS
 __device__ __forceinline__ void block_reduce_rs(const double acc[RL_LR_RS], double* red,
                                                 double* out) {
@@ -584,8 +587,8 @@ k_poly_project_rows(const double* __restrict__ Yv, int n, Minres2Bufs mb) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
-    const int lo = mb.poly_tab[3 * blk], hi = mb.poly_tab[3 * blk + 1];
-    const int dout = mb.poly_tab[3 * blk + 2];
+    const int lo = mb.poly_tab[RL_PT * blk], hi = mb.poly_tab[RL_PT * blk + 1];
+    const int dout = mb.poly_tab[RL_PT * blk + 2];
     double acc[RL_LR_RS];
 #pragma unroll
     for (int j = 0; j < RL_LR_RS; ++j) acc[j] = 0.0;
@@ -679,9 +682,9 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     const bool poly = mb.poly_part != nullptr;
     int dout = 0;
     if (poly) {
-        lo = mb.poly_tab[3 * blockIdx.x];
-        hi = mb.poly_tab[3 * blockIdx.x + 1];
-        dout = mb.poly_tab[3 * blockIdx.x + 2];
+        lo = mb.poly_tab[RL_PT * blockIdx.x];
+        hi = mb.poly_tab[RL_PT * blockIdx.x + 1];
+        dout = mb.poly_tab[RL_PT * blockIdx.x + 2];
     }
     const size_t off = (size_t)rhs * n;
     const double* g = mb.W_indptr != nullptr ? mb.g + (size_t)rhs * mb.ngrid : nullptr;
@@ -806,13 +809,39 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
         double zr[RS];
 #pragma unroll
         for (int j = 0; j < RS; ++j) zr[j] = Zh[j];
+        // Where the block's rows are about as dense as the grid points they touch
+        // (C2: 1000 rows on 1003 points) the grid range is evaluated ONCE into LDS,
+        // four points per thread, and the rows gather from it -- a quarter of the
+        // recurrences of evaluating four points per row.
+        const int g0 = mb.poly_tab[RL_PT * blockIdx.x + 3], glen = mb.poly_tab[RL_PT * blockIdx.x + 4];
+        const bool via_grid = glen <= RL_PG && glen <= 2 * (hi - lo);
+        double* Gs = Zh + RS + 10 * RS;                  // [RL_PG]
+        if (via_grid) {
+            for (int p0 = threadIdx.x; p0 < glen; p0 += 4 * blockDim.x) {
+                int np[4];
+                double gp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) np[e] = g0 + p0 + e * (int)blockDim.x;
+                lr_point_values(zr, mb.poly_beta, np, mb.poly_m, gp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (p0 + e * (int)blockDim.x < glen) Gs[p0 + e * blockDim.x] = gp[e];
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (lo + u * (int)blockDim.x >= hi) break;       // (uniform: no row of this group)
             const int i = lo + threadIdx.x + u * blockDim.x;
             const int ic = i < hi ? i : rlast;
             double gv[NZ];
-            lr_row_values(zr, mb.poly_beta, eb[u] - dout * mb.poly_m, mb.poly_m, gv);
+            if (via_grid) {
+                const int p = eb[u] - dout * mb.poly_m - g0;
+#pragma unroll
+                for (int j = 0; j < NZ; ++j) gv[j] = Gs[p + j < glen ? p + j : glen - 1];
+            } else {
+                lr_row_values(zr, mb.poly_beta, eb[u] - dout * mb.poly_m, mb.poly_m, gv);
+            }
             double qi = mb.eps != nullptr ? mb.eps[ic] * pr2[u] : 0.0;
 #pragma unroll
             for (int j = 0; j < NZ; ++j) qi = fma(ew[u][j], gv[j], qi);
@@ -1082,9 +1111,9 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
     const bool poly = mb.poly_part != nullptr;
     int dout = 0;
     if (poly) {
-        lo = mb.poly_tab[3 * blockIdx.x];
-        hi = mb.poly_tab[3 * blockIdx.x + 1];
-        dout = mb.poly_tab[3 * blockIdx.x + 2];
+        lo = mb.poly_tab[RL_PT * blockIdx.x];
+        hi = mb.poly_tab[RL_PT * blockIdx.x + 1];
+        dout = mb.poly_tab[RL_PT * blockIdx.x + 2];
         // (the next P reads giter only: written here, read by no workgroup of B)
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *mb.giter = *mb.giter2 + 1;
     }

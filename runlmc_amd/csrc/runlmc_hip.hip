@@ -2353,7 +2353,7 @@ static int poly_round_prepare(rl_ski* s, int nrhs, int max_blk, bool* ok) {
         std::vector<int> tab, ob(D + 1, 0);
         int i = 0;
         for (int d = 0; d < D; ++d) {
-            ob[d] = (int)tab.size() / 3;
+            ob[d] = (int)tab.size() / RL_PT;
             const int start = i;
             while (i < n && s->h_base[i] < (d + 1) * m) ++i;
             const int cnt = i - start;
@@ -2362,19 +2362,24 @@ static int poly_round_prepare(rl_ski* s, int nrhs, int max_blk, bool* ok) {
             const int nb = (cnt + 1023) / 1024;
             for (int b = 0; b < nb; ++b) {
                 const int per = (cnt + nb - 1) / nb;
-                tab.push_back(start + b * per);
-                tab.push_back(std::min(start + (b + 1) * per, i));
+                const int r0 = start + b * per, r1 = std::min(start + (b + 1) * per, i);
+                tab.push_back(r0);
+                tab.push_back(r1);
                 tab.push_back(d);
+                // grid points (within the output) the block's rows touch
+                const int gfirst = s->h_base[r0] - d * m;
+                tab.push_back(gfirst);
+                tab.push_back(s->h_base[r1 - 1] - d * m + 4 - gfirst);
             }
         }
-        ob[D] = (int)tab.size() / 3;
+        ob[D] = (int)tab.size() / RL_PT;
         if (i != n || tab.empty()) {
             s->poly_nblk = -1;
             return RL_OK;
         }
         RL_TRY(upload_raw((void**)&s->poly_tab, tab.data(), tab.size() * sizeof(int)));
         RL_TRY(upload_raw((void**)&s->poly_ob, ob.data(), ob.size() * sizeof(int)));
-        s->poly_nblk = (int)tab.size() / 3;
+        s->poly_nblk = (int)tab.size() / RL_PT;
     }
     if (s->poly_nblk > std::max(max_blk, RL_SOLVER_THREADS)) return RL_OK;
     RL_TRY(lr_ensure(g));
@@ -2401,7 +2406,7 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         // the operator lives inside P and B (rl_solver.h: polynomial rounds)
         trace_once("minres round: polynomial form inside P and B, no grid vectors");
         const size_t lds = (2 * RL_SOLVER_THREADS +
-                            std::max(mb.poly_D * RL_LR_RS + 11 * RL_LR_RS, RL_SOLVER_THREADS)) *
+                            std::max(mb.poly_D * RL_LR_RS + 11 * RL_LR_RS + RL_PG, RL_SOLVER_THREADS)) *
                            sizeof(double);
         RL_LAUNCH(k_minres2_p, grid, blk, lds, st, mb, n, par);
         RL_LAUNCH(k_minres2_b, grid, blk, lds, st, mb, n, par, rtol, maxiter);
