@@ -1377,7 +1377,7 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
     double* y2 = y1 + vec;
     double* tphi = y2 + vec;
     hipStream_t st = nullptr;
-    std::vector<double> h1(vec), h2(vec), hnu(RL_LR_RMAX);
+    std::vector<double> h1(2 * vec), hnu(RL_LR_RMAX);
     RL_HIP(hipMemcpy(hnu.data(), g->lr_nu, hnu.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int r : {24, 32, 48}) {
         if (r > 24 && m < 2048) break;      // (short grids: only the solver's rank-24 rounds use the form)
@@ -1422,11 +1422,11 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
             g->lr_bypass = false;
             if (rc != RL_OK) return rc;
             RL_TRY(lr_apply(g, xr, y2, 1, q, 1, g->lr_eye, st));
-            RL_HIP(hipMemcpy(h1.data(), y1, vec * sizeof(double), hipMemcpyDeviceToHost));
-            RL_HIP(hipMemcpy(h2.data(), y2, vec * sizeof(double), hipMemcpyDeviceToHost));
+            // (y1 and y2 are neighbours in the scratch buffer: one copy, one round trip)
+            RL_HIP(hipMemcpy(h1.data(), y1, 2 * vec * sizeof(double), hipMemcpyDeviceToHost));
             double dmax = 0.0, ymax = 0.0;
             for (size_t i = 0; i < vec; ++i) {
-                dmax = std::max(dmax, std::fabs(h1[i] - h2[i]));
+                dmax = std::max(dmax, std::fabs(h1[i] - h1[vec + i]));
                 ymax = std::max(ymax, std::fabs(h1[i]));
             }
             ok = dmax <= RL_LR_TOL * ymax || (ymax == 0.0 && dmax == 0.0);
