@@ -1702,6 +1702,8 @@ struct rl_ski {
     double *P1 = nullptr, *P2 = nullptr;
     int pcap = 0;
     hipStream_t solver_stream = nullptr;   // capturable stream of rl_solve_batch
+    int* pin_count = nullptr;              // pinned host [2]: active-system counts in flight
+    hipEvent_t count_ev[2] = {nullptr, nullptr};
     // the solver's buffers are kept between calls (a solve frees eighteen of them
     // and a hipFree is ~100 us: 1.7 of the 2.9 ms a C2 solve spent outside its
     // rounds); capacities in elements.  RUNLMC_WS_CACHE_MB bounds what is kept.
@@ -1947,6 +1949,9 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
             if (p) (void)hipFree(p);
     }
     if (s->solver_stream) (void)hipStreamDestroy(s->solver_stream);
+    if (s->pin_count) (void)hipHostFree(s->pin_count);
+    for (hipEvent_t e : s->count_ev)
+        if (e) (void)hipEventDestroy(e);
     if (s->ws_valid) free_work(s->ws);
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
@@ -2668,6 +2673,20 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             RL_HIP(e);
             RL_HIP(hipGraphInstantiate(&guard.exec, guard.graph, nullptr, nullptr, 0));
         }
+        // Polynomial rounds cost next to nothing for frozen systems (P and B return
+        // at once, there is no operator kernel), so the host does not wait for the
+        // count of a replay before it launches the next one: the count of replay j
+        // is read while replay j + 1 runs (one replay of no-ops at the end of a
+        // solve against a host round trip per replay).
+        const bool lagged = guard.exec != nullptr && mb.poly_part != nullptr &&
+                            getenv("RUNLMC_NO_LAGGED_COUNT") == nullptr;
+        if (lagged && !s->pin_count) {
+            RL_HIP(hipHostMalloc((void**)&s->pin_count, 2 * sizeof(int), hipHostMallocDefault));
+            for (hipEvent_t& e : s->count_ev)
+                RL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        bool pending[2] = {false, false};
+        int slot = 0;
         while (done <= maxiter && active > 0) {
             if (guard.exec) {
                 RL_HIP(hipGraphLaunch(guard.exec, st));
@@ -2679,8 +2698,23 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             const bool check = check_every > 0 && (done - 1) % check_every == 0;
             if (check)
                 RL_TRY(residual_check(s, w, Bi, Xi, mb.q, nrhs, n, nblk, tol, 1, st));
-            if (check || guard.exec || (done - 1) % 10 == 0)
-                RL_TRY(active_count(w, nrhs, st, &active));
+            if (lagged && !check) {
+                RL_LAUNCH(k_count_active, dim3(1), dim3(64), 0, st, w.I, nrhs, w.count);
+                RL_HIP(hipMemcpyAsync(&s->pin_count[slot], w.count, sizeof(int),
+                                      hipMemcpyDeviceToHost, st));
+                RL_HIP(hipEventRecord(s->count_ev[slot], st));
+                pending[slot] = true;
+                const int other = slot ^ 1;
+                if (pending[other]) {
+                    RL_HIP(hipEventSynchronize(s->count_ev[other]));
+                    active = s->pin_count[other];
+                    pending[other] = false;
+                }
+                slot = other;
+            } else if (check || guard.exec || (done - 1) % 10 == 0) {
+                RL_TRY(active_count(w, nrhs, st, &active));        // (synchronises: nothing pending)
+                pending[0] = pending[1] = false;
+            }
         }
         RL_TRY(residual_check(s, w, Bi, Xi, mb.q, nrhs, n, nblk, tol, 0, st));
     } else if (method == RL_MINRES) {

@@ -230,6 +230,8 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
     std::memmove(d, s, n);
     return hipSuccess;

@@ -52,6 +52,9 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
 
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
+enum { hipHostMallocDefault = 0 };
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n,
                           hipMemcpyKind k, hipStream_t s);
