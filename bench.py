@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02', 'traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r03', 'traffic.json')
 
 
 def parse():
@@ -48,6 +48,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c5', choices=['c1', 'c2', 'c5'])
+    ap.add_argument('--kern', default='rbf', choices=['rbf', 'periodic', 'matern', 'mix'],
+                    help='kernel family of the headline (reference benchmarks/benchlib/'
+                         'bench.py:94,284-297); the other three are timed under "families"')
+    ap.add_argument('--no-families', action='store_true',
+                    help='skip the product timings of the other kernel families')
     ap.add_argument('--batch', type=int, default=0,
                     help='vectors per step (default: probes per GPU + 1)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline')
@@ -62,6 +67,9 @@ def parse():
                     help='budget of each bounded CPU sample')
     # debugging aids for the multi-rank path on a one-GPU box
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
+    ap.add_argument('--force-dist', action='store_true',
+                    help='with ONE rank: initialise the process group anyway and push the '
+                         "step's broadcast / all-reduce through it (RCCL on a one-GPU box)")
     ap.add_argument('--same-gpu', action='store_true',
                     help='every rank uses cuda:0 (only meaningful with gloo)')
     # internal: the CPU-baseline child process (never imports torch)
@@ -141,14 +149,17 @@ def cpu_child(spec_json):
     from runlmc_amd.util import synth
     from oracle import likelihood as olik
     from oracle import operators as ops
-    from oracle.kernels import KernelSpec, RBFSpec
+    from oracle.kernels import KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec
     req = json.loads(spec_json)
     out = {}
     cores = usable_cores()
     for name, job in req['jobs'].items():
         D, Q, R, m_data, n_probes = synth.CONFIGS[job['config']]
-        p = synth.make_problem(D, Q, R, m_data, eps=job.get('eps', 0.1))
-        spec = KernelSpec(p.D, [RBFSpec(g) for g in p.inv_lengthscales],
+        p = synth.make_problem(D, Q, R, m_data, eps=job.get('eps', 0.1),
+                               kern=job.get('kern', 'rbf'))
+        spec = KernelSpec(p.D, synth.kernel_objects(p.kern_desc, rbf=RBFSpec,
+                                                    periodic=StdPeriodicSpec,
+                                                    matern=Matern32Spec),
                           list(p.coreg_vecs), list(p.coreg_diags), p.noise)
         spec.set_input_dim(1)
         res = {}
@@ -284,6 +295,18 @@ def dist_setup(args):
             dist.init_process_group('gloo', rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
+        if args.force_dist:
+            # a world of ONE rank through the real backend: the step's collectives
+            # (alpha broadcast, gradient all-reduce) then run on RCCL itself
+            from runlmc_amd.util import dist as rdist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29511')
+            if args.dist_backend == 'nccl':
+                dist.init_process_group('nccl', rank=0, world_size=1,
+                                        device_id=torch.device('cuda', 0))
+            else:
+                dist.init_process_group('gloo', rank=0, world_size=1)
+            rdist.force_collectives(True)
     return rank, world, local
 
 
@@ -380,7 +403,25 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2):
                         # a few entries, so that runs can be compared with each other
                         grad_sample=[float(v) for v in np.concatenate(
                             [np.ravel(g[3]), np.ravel(g[1][0]), np.ravel(g[0][0])])[:12]])
+    if group is not None:
+        # the same BITS on every rank?  (64-bit checksums of alpha and of the gradient,
+        # max and min over the ranks)
+        import torch.distributed as tdist
+        flat = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.array(g[2])] + [g[3]]])
+        sums = torch.stack([lik.deriv.alpha_dev.view(torch.int64).sum(),
+                            torch.from_numpy(flat.copy()).view(torch.int64).sum().to(
+                                lik.deriv.alpha_dev.device)])
+        on = sums if tdist.get_backend() == 'nccl' else sums.cpu()
+        hi, lo = on.clone(), on.clone()
+        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX, group=group)
+        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN, group=group)
+        info['bits_equal_across_ranks'] = {'alpha': bool(hi[0] == lo[0]),
+                                           'gradient': bool(hi[1] == lo[1])}
     info['seconds'] = best
+    # (neither side converges at the reference's noise level -- SciPy's own tests stop
+    # the solves --, so the per-iteration cost is the comparison that does not depend
+    # on where the two sides happen to stop)
+    info['seconds_per_iteration'] = best / max(info['iterations_max'], 1)
     return info
 
 
@@ -404,13 +445,79 @@ def time_full_operator(g, p, batch, gen, steps, world, dev, alg):
             'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors' % batch}
 
 
+FORM_NAMES = {0: 'transform', 1: 'polynomial', 2: 'filter'}
+
+
+def product_form(g, batch, D, m):
+    """(label, kernel description) of the form the operator's product runs in
+    for this batch: per-top forms from the handle (csrc/rl_lowrank.h,
+    rl_filter.h), transform kernels below the batch gate or if any top needs
+    them."""
+    forms, structured = g.top_forms()
+    rank_poly, gate = g.form()
+    big = batch * D * m >= gate
+    names = [FORM_NAMES[f] for f in forms]
+    if not (big and structured):
+        return 'fft', names, ('grid MVM (column transforms + row transforms with the D x D mix '
+                              '+ adjoint column transforms), D=%d' % D)
+    if all(f == 1 for f in forms):
+        return 'poly', names, ('grid MVM, polynomial-subspace form (k_lr_project -> k_lr_mix -> '
+                               'k_lr_expand, rank %d, accepted at set time against the transform '
+                               'kernels), D=%d' % (rank_poly, D))
+    if all(f == 2 for f in forms):
+        return 'filter', names, ('grid MVM, recursive-filter form of exponential-polynomial top '
+                                 'rows (k_sf_carries -> k_sf_scan -> k_sf_apply: block maps on the '
+                                 'fp64 matrix cores, states chained by DPP), D=%d' % D)
+    return 'filter+poly', names, ('grid MVM, filter part (k_sf_*) + polynomial part (k_lr_*, '
+                                  'accumulating), D=%d' % D)
+
+
+def time_family(kern, name, args, rank, world, dev, steps, warmup):
+    """The batched K_UU product of another kernel family of the reference's
+    benchmark (bench.py:94,284-297) at the same (D, Q, m) and batch: forms chosen per
+    top row, the product in those forms and on the transform kernels, same clock."""
+    import torch
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import GridOp
+    D, Q, R, m_data, n_probes = synth.CONFIGS[name]
+    p = synth.make_problem(D, Q, R, m_data, kern=kern)
+    g = GridOp(D, p.m, Q, device_index=dev.index)
+    g.set_lmc(synth.tops(p), list(p.coreg_vecs), list(p.coreg_diags))
+    batch = n_probes + 1
+    gen = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    X = torch.randn(batch, D * p.m, dtype=torch.float64, generator=gen).to(dev)
+    Y = torch.empty_like(X)
+    form, names, kernel = product_form(g, batch, D, p.m)
+    wall_ms, ev_ms = time_steps(lambda: g.mvm(X, out=Y), steps, warmup, world, dev)
+    wall_ms = max_over_ranks(wall_ms, world, dev)
+    alg = synth.algorithmic_bytes_grid_mvm(D, Q, p.m, g.L, batch)
+    achieved = alg / (wall_ms * 1e-3) / 1e9
+    traffic, source = measured_traffic(name, batch, form if kern == 'rbf' else kern)
+    out = {'kernels': [list(d) for d in p.kern_desc], 'top_forms': names,
+           'mvm_per_s': batch * world / (wall_ms * 1e-3), 'ms_per_step': wall_ms,
+           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                        'traffic_source': source, 'kernel': kernel, 'form': form,
+                        'algorithmic_bytes_per_step': alg,
+                        'device_event_ms_per_step': max_over_ranks(ev_ms, world, dev)}}
+    if form != 'fft':
+        g.set_form_gate(1 << 62)
+        f_ms, _ = time_steps(lambda: g.mvm(X, out=Y), steps, warmup, world, dev)
+        g.set_form_gate(-1)
+        f_ms = max_over_ranks(f_ms, world, dev)
+        out['transform_kernels'] = {'ms_per_step': f_ms,
+                                    'roofline_frac': alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def bench_config(name, args, rank, world, dev, steps, warmup, headline):
     """All device measurements of one (D, Q, m) configuration."""
     import torch
     from runlmc_amd.util import synth
     from runlmc_amd._native import GridOp, SkiOp
     D, Q, R, m_data, n_probes = synth.CONFIGS[name]
-    p = synth.make_problem(D, Q, R, m_data)
+    kern = args.kern
+    p = synth.make_problem(D, Q, R, m_data, kern=kern)
     g = GridOp(D, p.m, Q, device_index=dev.index)
     tops = synth.tops(p)
     g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
@@ -426,27 +533,24 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
     mvms = batch * world / (wall_ms * 1e-3)
     alg = synth.algorithmic_bytes_grid_mvm(D, Q, p.m, g.L, batch)
     achieved = alg / (wall_ms * 1e-3) / 1e9
-    # which form the product ran in: the polynomial-subspace form (smooth
-    # kernels, batch above the gate; csrc/rl_lowrank.h) or the transform kernels
-    rank_poly, gate = g.form()
-    poly = rank_poly > 0 and batch * D * p.m >= gate
-    traffic, source = measured_traffic(name, batch, 'poly' if poly else 'fft')
-    kernel = ('grid MVM, polynomial-subspace form (k_lr_project -> k_lr_mix -> k_lr_expand, '
-              'rank %d, accepted at set time against the transform kernels), D=%d'
-              % (rank_poly, D)) if poly else (
-        'grid MVM (column transforms + row transforms with the D x D mix + adjoint '
-        'column transforms), D=%d' % D)
+    # which form the product ran in (per-top forms are decided at set time)
+    form, form_names, kernel = product_form(g, batch, D, p.m)
+    poly = form != 'fft'
+    traffic, source = measured_traffic(name, batch, form if kern == 'rbf' else kern)
     out = {
         'value': mvms, 'ms_per_step': wall_ms,
         'config': {'workload': '%s synthetic D=%d Q=%d R=%d m=%d (grid %d, L=%d) '
-                               'N=%d probes/GPU, batch=%d vectors/step, K_UU product'
-                               % (name, D, Q, R, m_data, p.m, g.L, n_probes, batch),
+                               'N=%d probes/GPU, batch=%d vectors/step, K_UU product, '
+                               'kernel family %s'
+                               % (name, D, Q, R, m_data, p.m, g.L, n_probes, batch, kern),
+                   'kern': kern, 'kernels': [list(d) for d in p.kern_desc],
+                   'top_forms': form_names,
                    'D': D, 'Q': Q, 'm': p.m, 'L': g.L, 'batch': batch,
                    'fft_split': [g.N1, g.N2], 'parallelism': 'probe-shard x%d' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'traffic_source': source,
-                     'kernel': kernel, 'form': 'poly' if poly else 'fft',
+                     'kernel': kernel, 'form': form,
                      'algorithmic_bytes_per_step': alg,
                      'clock': 'wall, same region as value',
                      'device_event_ms_per_step': ev_ms},
@@ -467,8 +571,16 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
             'roofline_frac': alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'traffic': f_traffic, 'traffic_source': f_source,
             'device_event_ms_per_step': max_over_ranks(f_ev, world, dev),
-            'what': 'the same product with the polynomial form switched off '
+            'what': 'the same product with the structured forms switched off '
                     '(rl_gridop_set_form_gate): k2_cols_fwd -> k3_rows_mix -> k2_cols_inv'}
+
+    if headline and not args.no_families and world == 1:
+        # the reference benchmark's other kernel families at the same shape and batch
+        fam = {}
+        for other in synth.KERN_FAMILIES:
+            if other != kern:
+                fam[other] = time_family(other, name, args, rank, world, dev, steps, warmup)
+        out['families'] = fam
 
     if not args.no_full:
         out['full_mvm'] = time_full_operator(g, p, batch, gen, steps, world, dev, alg)
@@ -492,12 +604,16 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
 
     if not args.no_nll:
         for key, eps in (('nll_grad', 0.1), ('nll_grad_eps1', 1.0)):
-            pe = p if eps == 0.1 else synth.make_problem(D, Q, R, m_data, eps=eps)
+            pe = p if eps == 0.1 else synth.make_problem(D, Q, R, m_data, eps=eps, kern=kern)
             np.random.seed(4321)
             # the config's N probes in total, dealt round-robin to the ranks
             # (strong scaling of one optimiser step)
             probes = np.random.randint(0, 2, (n_probes, pe.n)) * 2 - 1
-            info = gpu_nll_grad(pe, probes, n_probes)
+            group = None
+            if args.force_dist or world > 1:
+                import torch.distributed as tdist
+                group = tdist.group.WORLD
+            info = gpu_nll_grad(pe, probes, n_probes, group=group)
             info['seconds'] = max_over_ranks(info['seconds'], world, dev)
             info.update(n_probes_global=n_probes, scaling='strong', eps=eps,
                         probes_per_rank=-(-n_probes // world))
@@ -541,7 +657,7 @@ def main():
                                   max(args.warmup, 10), False)
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        jobs = {args.config: dict(config=args.config, mvm=True)}
+        jobs = {args.config: dict(config=args.config, mvm=True, kern=args.kern)}
         if 'nll_grad' in out:
             it = out['nll_grad']['iterations_mean']
             small = args.config != 'c5'
@@ -549,7 +665,7 @@ def main():
                 nll=True, **({} if small else
                              dict(bounded=True, iterations_target=it)))
         if other in out:
-            jobs[other] = dict(config=other, mvm=True, nll='nll_grad' in out[other])
+            jobs[other] = dict(config=other, mvm=True, nll='nll_grad' in out[other], kern=args.kern)
         cpu = run_cpu_child(jobs, args.cpu_seconds)
         mine = cpu[args.config]
         out['cpu_baseline'] = dict(
@@ -565,6 +681,7 @@ def main():
             out['cpu_baseline']['nll_grad'] = mine['nll_grad']
             out['nll_grad']['speedup_vs_cpu'] = mine['nll_grad']['seconds'] / out['nll_grad']['seconds']
             out['nll_grad']['cpu_kind'] = mine['nll_grad']['kind']
+            out['nll_grad']['cpu_seconds_per_iteration_per_solve'] = mine['nll_grad']['per_iteration_s']
         if other in cpu:
             o = cpu[other]
             out[other]['cpu_baseline'] = dict(
@@ -578,11 +695,18 @@ def main():
                     o['nll_grad']['seconds'] / out[other]['nll_grad']['seconds']
                 out[other]['nll_grad']['cpu_kind'] = o['nll_grad']['kind']
 
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        out['collectives'] = {'backend': dist.get_backend(), 'world_size': world,
+                              'forced_in_world_of_one': bool(args.force_dist and world == 1),
+                              'per_step': 'broadcast of alpha (n doubles) + one all-reduce of '
+                                          'the gradient partials'}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

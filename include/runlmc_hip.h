@@ -71,6 +71,17 @@ int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int
  *                  against the transform kernels inside the set call.
  *   RUNLMC_NO_LOWRANK=1 keeps every handle on the transform kernels.        */
 int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements);
+/* The form EACH top row runs in for the current parameters (forms host [Q], may
+ * be NULL): 0 transform kernels; 1 polynomial-subspace form; 2 recursive
+ * filter -- an exponential-polynomial row t_i = (c0 + c1 i + c2 i^2) rho^i, i.e.
+ * the reference's Matern-3/2 kernel on a regular grid and its derivative
+ * (runlmc/kern/matern32.py:40-55), is exactly semiseparable and its product a
+ * two-sided scan (csrc/rl_filter.h), detected from the row itself.
+ * *structured = 1 when no top needs the transform kernels, so that operator
+ * products of batches above the gate move x and y and nothing else.  Single-top
+ * products (rl_gridop_mvm_top) take each top's own form either way.
+ * RUNLMC_NO_FILTER=1 switches form 2 off.                                       */
+int rl_gridop_top_forms(const rl_gridop* g, int* forms, int* structured);
 /* Moves that batch gate for this handle (0: every batch; < 0: back to the
  * default, 2^20 elements or RUNLMC_LR_MIN).  Below the gate the polynomial
  * form is slower than the transform kernels (too few workgroups).           */

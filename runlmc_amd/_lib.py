@@ -34,6 +34,7 @@ _SIGNATURES = {
     'rl_gridop_info': [_vp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p],
     'rl_gridop_form': [_vp, _c_int_p, ctypes.POINTER(ctypes.c_longlong)],
     'rl_gridop_set_form_gate': [_vp, ctypes.c_longlong],
+    'rl_gridop_top_forms': [_vp, _c_int_p, _c_int_p],
     'rl_gridop_set_lmc': [_vp, _i, _vp, _vp, _vp, _vp],
     'rl_gridop_set_dense': [_vp, _i, _vp, _vp],
     'rl_gridop_mvm': [_vp, _vp, _vp, _i, _vp],

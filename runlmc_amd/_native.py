@@ -82,6 +82,16 @@ class GridOp:
         self.lib.call('rl_gridop_form', self._h, ctypes.byref(r), ctypes.byref(n))
         return r.value, n.value
 
+    def top_forms(self):
+        """(forms, structured): per top row 0 = transform kernels, 1 =
+        polynomial-subspace form, 2 = recursive filter (csrc/rl_filter.h);
+        structured is True when operator products above the batch gate need
+        no transform."""
+        forms = (ctypes.c_int * max(self.Q, 1))()
+        st = ctypes.c_int()
+        self.lib.call('rl_gridop_top_forms', self._h, forms, ctypes.byref(st))
+        return [forms[q] for q in range(self.Q)], bool(st.value)
+
     def set_form_gate(self, min_elements):
         """Smallest batch (nvec*D*m elements) run in the polynomial form;
         0 = every batch, negative = the library default."""

@@ -228,7 +228,7 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
 }
 
 // ---------------------------------------------------------------------------
-// k_lr_expand<R>: Y[row][n] = sum_j q_j(n) Zhat[row][j]  (Zhat carries nu).
+// k_lr_expand<R>: Y[row][n] (+)= sum_j q_j(n) Zhat[row][j]  (Zhat carries nu).
 //   grid (ceil(slots / 256), ceil(nrows / rows_per_block))   block 256
 // A thread owns one slot (a grid point and its mirror): the R basis values of
 // the point (recurrence, once) stay in registers for all the rows of the block;
@@ -241,7 +241,7 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
 template <int R>
 __global__ void __launch_bounds__(256)
 k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __restrict__ beta,
-            int rows_per_block, double* __restrict__ Y) {
+            int rows_per_block, double* __restrict__ Y, int accumulate) {
     const int slots = lr_slots(m);
     // workgroups are numbered with the ROW block fastest: consecutive workgroups
     // write the same columns of different rows (measured at C5: 204-215 us against
@@ -275,8 +275,12 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
             ev = fma(z[j], p[j], ev);
             od = fma(z[j + 1], p[j + 1], od);
         }
-        if (live) Y[(size_t)row * m + nc] = ev + od;
-        if (pair) Y[(size_t)row * m + mir] = ev - od;
+        // (accumulate: the operator's filter part has written Y already, rl_filter.h)
+        double* y0 = Y + (size_t)row * m + nc;
+        double* y1 = Y + (size_t)row * m + mir;
+        const double o0 = accumulate && live ? *y0 : 0.0, o1 = accumulate && pair ? *y1 : 0.0;
+        if (live) *y0 = (ev + od) + o0;
+        if (pair) *y1 = (ev - od) + o1;
     }
 }
 

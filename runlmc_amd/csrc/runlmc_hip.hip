@@ -14,6 +14,7 @@
 #include "rl_kernels2.h"
 #include "rl_kernels3.h"
 #include "rl_lowrank.h"
+#include "rl_filter.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -251,9 +252,10 @@ struct rl_gridop {
     // polynomial-subspace form for smooth kernels (rl_lowrank.h)
     bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
     bool lr_ok = false;         // verified against the FFT path for the current parameters
-    int lr_rejects = 0;         // consecutive parameter sets the verification rejected: after
-                                // three the handle stops trying (Matern fits would pay the
-                                // set-time work at every optimiser step for nothing)
+    int lr_rejects = 0;         // consecutive parameter sets with a top the verification rejected
+    int lr_skip = 0;            // parameter updates the verification still sits out (back-off:
+                                // 0, 1, 3 ... 31 updates after 1, 2, 3 ... rejections in a row)
+    double* lr_stat = nullptr;  // dev verdict records of the verification; lr_C lives behind them
     bool lr_dirty = false;      // parameters changed since the last verification: the
                                 // set-time work (lr_setup) runs when the first batch above
                                 // the gate asks for it -- small-batch users never pay it
@@ -275,6 +277,33 @@ struct rl_gridop {
     double* lr_zhat = nullptr;  // mixed coefficients [rows][r]
     size_t lr_zhat_cap = 0;
     double* lr_scr = nullptr;   // set-time scratch: 3 vectors of D*m + partial maxima
+    double* lr_Cc = nullptr;    // dev [max_tops][r][r]: C of the polynomial tops only, contiguous
+    double* lr_Bc = nullptr;    // dev [max_tops][D][D]: their couplings (operators that mix forms)
+    int lr_np = 0;              // polynomial tops among the Q
+    // per-top forms (decided by forms_setup at every parameter update):
+    //   0 transform kernels, 1 polynomial-subspace form, 2 recursive filter (rl_filter.h)
+    std::vector<double> h_tops;     // host copy of the top rows [Q][m]
+    std::vector<int> top_form;
+    bool st_ok = false;         // every top is 1 or 2 and at least one is 2: the operator runs as
+                                // polynomial part + filter part, nothing through the transforms
+    bool sf_try = false;        // eligible for the filter form: 1-D grid, not switched off
+    int sf_n = 0;               // filter tops
+    int sf_nfac = 0;            // rank-one factors that belong to them
+    int sf_ns = 2;              // states per direction the operator's filters need (2 or 3)
+    std::vector<int> sf_slot;   // per top: its place among the filter tops, or -1
+    std::vector<int> sf_top_ns; // per top: 2 or 3
+    SfTop* sf_tops = nullptr;   // dev [max_tops]
+    double* sf_blob = nullptr;  // dev: the filter part's block for k_sf_apply (rl_filter.h)
+    double* sf_blob_top = nullptr;  // dev [max_tops][...]: the same for each top alone (B = I)
+    double* sf_pw = nullptr;    // dev [max_tops][G + 1]
+    double* sf_kappa = nullptr; // dev [max_tops][D]
+    double* sf_facA = nullptr;  // dev [max_fac][D]
+    double* sf_facAW = nullptr; // dev [max_fac][D]
+    int* sf_facJ = nullptr;     // dev [max_fac]
+    double* sf_E = nullptr;     // chunk states [nchunks][rows][NF][2][NS]
+    size_t sf_E_cap = 0;
+    double* sf_Cin = nullptr;   // incoming states [nchunks][nvec][nchan][2][NS]
+    size_t sf_Cin_cap = 0;
     double* mixtab = nullptr;   // dev [D + nfac][L]: dc rows then gs rows (k_mix_tables)
     size_t mixtab_rows = 0;     // rows allocated
     bool mixtab_ok = false;     // tables match the current parameters
@@ -396,6 +425,16 @@ static void set_lds_attrs() {
     set_lds_attr_rows3<10>(); set_lds_attr_rows3<11>(); set_lds_attr_rows3<12>();
     set_lds_attr_rows3<13>(); set_lds_attr_rows3<14>(); set_lds_attr_rows3<15>();
     set_lds_attr_rows3<16>();
+#define RL_SF_ATTR(NS_, XR_)                                                          \
+    (void)hipFuncSetAttribute((const void*)k_sf_apply<NS_, XR_>,                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    RL_SF_ATTR(2, 8); RL_SF_ATTR(2, 16); RL_SF_ATTR(2, 24); RL_SF_ATTR(2, 32);
+    RL_SF_ATTR(3, 8); RL_SF_ATTR(3, 16); RL_SF_ATTR(3, 24); RL_SF_ATTR(3, 32);
+#undef RL_SF_ATTR
+    (void)hipFuncSetAttribute((const void*)k_sf_carries<2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_sf_carries<3>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
 }
 
@@ -545,6 +584,8 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     // (short grids only matter to the solver's opt-in polynomial rounds)
     g->lr_try = m1 == 0 && m >= (getenv("RUNLMC_POLY_ROUND") != nullptr ? 2 * RL_LR_RMAX : 2048) &&
                 getenv("RUNLMC_NO_LOWRANK") == nullptr;
+    // recursive-filter form (rl_filter.h): any 1-D grid; decided per top row from the row
+    g->sf_try = m1 == 0 && m >= 64 && getenv("RUNLMC_NO_FILTER") == nullptr;
     g->lr_min = lr_min_elements();
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
@@ -604,8 +645,10 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     (void)hipSetDevice(g->device);
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
-                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_C, g->lr_M,
-                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr};
+                    g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
+                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_Cc, g->lr_Bc,
+                    g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
+                    g->sf_E, g->sf_Cin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -635,6 +678,18 @@ extern "C" int rl_gridop_form(const rl_gridop* gc, int* rank, long long* min_ele
     if (g->Q >= 1) RL_TRY(lr_ensure(g));
     if (rank) *rank = g->lr_ok ? g->lr_r : 0;
     if (min_elements) *min_elements = (long long)g->lr_min;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_top_forms(const rl_gridop* gc, int* forms, int* structured) {
+    if (!gc) return fail(RL_EINVAL, "gridop is NULL");
+    rl_gridop* g = const_cast<rl_gridop*>(gc);      // (runs the pending verification)
+    if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
+    RL_TRY(lr_ensure(g));
+    if (forms)
+        for (int q = 0; q < g->Q; ++q)
+            forms[q] = q < (int)g->top_form.size() ? g->top_form[q] : 0;
+    if (structured) *structured = (g->lr_ok || g->st_ok) ? 1 : 0;
     return RL_OK;
 }
 
@@ -729,9 +784,6 @@ static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::ve
     return RL_OK;
 }
 
-static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vector<double>& W,
-                    const std::vector<int>& Qi, const std::vector<double>& kap);
-
 static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector<double>& A,
                       const std::vector<double>& W, const std::vector<int>& Qi,
                       const std::vector<double>& kap) {
@@ -741,7 +793,10 @@ static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector
     g->lr_dirty = false;
     int rc = set_common(g, Q, tops);
     if (rc == RL_OK) rc = set_factors(g, A, W, Qi, kap);
-    if (rc == RL_OK && g->lr_try) {
+    g->st_ok = false;
+    g->top_form.assign(Q, 0);
+    if (rc == RL_OK && (g->lr_try || g->sf_try)) {
+        g->h_tops.assign(tops, tops + (size_t)Q * g->m);
         g->lr_A = A;
         g->lr_W = W;
         g->lr_Qi = Qi;
@@ -1184,8 +1239,9 @@ static bool wants_two_streams(const rl_gridop* g) {
 //     b_{j+1} p_{j+1} = s p_j - b_j p_{j-1},   p_0 = 1 / sqrt(m)
 // in long double (the points are symmetric, so the diagonal coefficients vanish).
 // Measured: |Phi^T Phi - I| <= 1e-14 for 48 functions at m = 2048 ... 100 004.
-// Rows RL_LR_RMAX .. RL_LR_RMAX + RL_MAX_D of the function-major copy are zero
+// Rows beyond RL_LR_RMAX + RL_LR_EXTRA of the function-major copy are zero
 // padding (the set-time products read whole vectors of D blocks).
+#define RL_LR_EXTRA 4          // omitted polynomials the verification checks beyond the rank
 static int lr_make_basis(rl_gridop* g) {
     const int m = g->m, R = RL_LR_RMAX;
     std::vector<double> phiJ((size_t)(R + 16) * m, 0.0), beta(R), nu(R);
@@ -1193,12 +1249,16 @@ static int lr_make_basis(rl_gridop* g) {
     const long double p0 = 1.0L / sqrtl((long double)m);
     for (int n = 0; n < m; ++n) cur[n] = p0;
     long double bj = 0.0L, nuj = p0;
-    for (int j = 0; j < R; ++j) {
+    // (RL_LR_EXTRA functions beyond the largest rank: the verification looks at what
+    // the operator does to the first polynomials a rank omits)
+    for (int j = 0; j < R + RL_LR_EXTRA; ++j) {
         for (int n = 0; n < m; ++n) phiJ[(size_t)j * m + n] = (double)cur[n];
         // the kernels run the monic recurrence q_{j+1} = s q_j - b_j^2 q_{j-1},
         // Phi_j = nu_j q_j with nu_{j+1} = nu_j / b_{j+1}
-        beta[j] = (double)(bj * bj);
-        nu[j] = (double)nuj;
+        if (j < R) {
+            beta[j] = (double)(bj * bj);
+            nu[j] = (double)nuj;
+        }
         long double nrm = 0.0L;
         for (int n = 0; n < m; ++n) {
             const long double sn = m > 1 ? -1.0L + 2.0L * n / (m - 1) : 0.0L;
@@ -1293,7 +1353,7 @@ static int lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) 
 
 template <int R>
 static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q, const double* Cq,
-                      const double* Bq, hipStream_t st) {
+                      const double* Bq, hipStream_t st, int accumulate = 0) {
     const int nrows = nvec * g->D;
     const int chunks = lr_project<R>(g, X, nrows, st);
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
@@ -1313,7 +1373,8 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
         rpb = (nrows + nby - 1) / nby;
     }
     RL_LAUNCH((k_lr_expand<R>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
-              st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
+              st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y,
+              accumulate);
 }
 
 // Y = Phi [sum_q B_q (x) C_q] Phi^T X for tops [q0, q0 + Q) with coupling Bq
@@ -1330,29 +1391,351 @@ static int lr_apply(rl_gridop* g, const double* X, double* Y, int nvec, int q0, 
     return RL_OK;
 }
 
+// the same for the polynomial tops of an operator that also has filter tops: ADDS to Y,
+// which the filter part has written (the streaming expansion absorbs the read-modify-write
+// better than the filter kernel's tiles would)
+static int lr_apply_compact(rl_gridop* g, const double* X, double* Y, int nvec, hipStream_t st) {
+    switch (g->lr_r) {
+        case 24: lr_launch<24>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
+        case 32: lr_launch<32>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
+        case 48: lr_launch<48>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
+        default: return fail(RL_EINVAL, "low-rank path: bad basis size");
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, double* Y, int nvec,
                         hipStream_t stream);
 
-// Set-time: build C_q = Phi^T T_q Phi for every top row with the FFT kernels of
-// this handle and ACCEPT the polynomial form only if, for every top row, it
-// reproduces the FFT product of a random vector to RL_LR_TOL of the result's
-// largest entry (the D blocks of the vector are D independent trials).  Tries
-// r = 24, 32, 48; leaves lr_ok = false otherwise.
-static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vector<double>& W,
-                    const std::vector<int>& Qi, const std::vector<double>& kap) {
-    g->lr_ok = false;
-    if (!g->lr_try) return RL_OK;
+// ---------------------------------------------------------------------------
+// recursive-filter form (rl_filter.h): detection of exponential-polynomial top
+// rows on the host, tables, launches
+// ---------------------------------------------------------------------------
+struct SfFit {
+    int deg = 0;
+    long double ah = 0.0L;          // decay per grid step: rho = exp(-ah)
+    long double c[3] = {0.0L, 0.0L, 0.0L};
+};
+
+// sum_i |t_i - (c0 + c1 i + c2 i^2) exp(-ah i)| <= RL_SF_TOL sum_i |t_i| ?  (long double;
+// the power is re-anchored every 256 points; stops at the first excess, so a top
+// row of another kind costs a handful of points)
+static bool sf_check(const double* t, int m, const SfFit& f, long double tot) {
+    const long double budget = (long double)RL_SF_TOL * tot, rho = expl(-f.ah);
+    long double err = 0.0L, pw = 1.0L;
+    for (int i = 0; i < m; ++i) {
+        if ((i & 255) == 0) pw = expl(-f.ah * i);
+        const long double model = (f.c[0] + (f.c[1] + f.c[2] * i) * i) * pw;
+        err += fabsl((long double)t[i] - model);
+        if (!(err <= budget)) return false;
+        pw *= rho;
+    }
+    return true;
+}
+
+// Is the top row t_i = (c0 + c1 i + c2 i^2) rho^i?  The decimated sequence
+// u_k = t_{k j} of such a row satisfies  sum_l binom(p+1, l) (-R)^l u_{p+1-l} = 0
+// with R = rho^j (p: the degree) -- one polynomial equation for R from p + 2
+// samples; j is taken where the row has fallen to about 0.6 of its largest
+// entry, so that the roots are well separated.  Every root in (0, 1] is a
+// candidate; the coefficients follow from the first p + 1 samples; the
+// candidate is accepted by sf_check over the whole row.  Degrees 0, 1, 2 in turn.
+static bool sf_detect(const double* t, int m, SfFit* fit) {
+    if (m < 8) return false;
+    long double tot = 0.0L;
+    double amax = 0.0;
+    int imax = 0;
+    for (int i = 0; i < m; ++i) {
+        if (!std::isfinite(t[i])) return false;
+        const double a = std::fabs(t[i]);
+        tot += a;
+        if (a > amax) {
+            amax = a;
+            imax = i;
+        }
+    }
+    if (amax == 0.0) return false;
+    int below = -1;
+    for (int i = imax; i < m; ++i)
+        if (std::fabs(t[i]) <= 0.6 * amax) {
+            below = i - imax;
+            break;
+        }
+    for (int deg = 0; deg <= 2; ++deg) {
+        const int span = deg + 1, jmax = (m - 1) / span;
+        if (jmax < 1) continue;
+        const int j = below < 0 ? jmax : std::max(1, std::min(below, jmax));
+        long double u[4] = {0.0L, 0.0L, 0.0L, 0.0L}, coef[4];
+        for (int k = 0; k <= span; ++k) u[k] = t[(size_t)k * j];
+        static const int binom[4][4] = {{1, 0, 0, 0}, {1, 1, 0, 0}, {1, 2, 1, 0}, {1, 3, 3, 1}};
+        for (int l = 0; l <= span; ++l) coef[l] = ((l & 1) ? -1.0L : 1.0L) * binom[span][l] * u[span - l];
+        auto f = [&](long double R) {
+            long double v = 0.0L;
+            for (int l = span; l >= 0; --l) v = v * R + coef[l];
+            return v;
+        };
+        std::vector<long double> roots;
+        const int NS_ = 512;
+        long double Ra = 0.0L, fa = f(0.0L);
+        for (int k = 1; k <= NS_; ++k) {
+            const long double Rb = (long double)k / NS_, fb = f(Rb);
+            if (fb == 0.0L) roots.push_back(Rb);
+            else if (fa != 0.0L && ((fa < 0.0L) != (fb < 0.0L))) {
+                long double lo = Ra, hi = Rb, flo = fa;
+                for (int it = 0; it < 80; ++it) {
+                    const long double mid = 0.5L * (lo + hi), fm = f(mid);
+                    if (fm == 0.0L) { lo = hi = mid; break; }
+                    if ((fm < 0.0L) == (flo < 0.0L)) { lo = mid; flo = fm; } else hi = mid;
+                }
+                roots.push_back(0.5L * (lo + hi));
+            }
+            Ra = Rb;
+            fa = fb;
+        }
+        for (long double R : roots) {
+            if (!(R > 0.0L && R <= 1.0L)) continue;
+            SfFit c;
+            c.deg = deg;
+            c.ah = -logl(R) / j;
+            const long double p0 = u[0], p1 = u[1] / R, p2 = u[2] / (R * R), jj = (long double)j;
+            c.c[0] = p0;
+            if (deg == 1) c.c[1] = (p1 - p0) / jj;
+            if (deg == 2) {
+                c.c[2] = (p2 - 2.0L * p1 + p0) / (2.0L * jj * jj);
+                c.c[1] = (p1 - p0) / jj - c.c[2] * jj;
+            }
+            if (sf_check(t, m, c, tot)) {
+                *fit = c;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+static void sf_device_top(const SfFit& f, SfTop* tp, SfBlk* bk, double* pw) {
+    tp->rho = (double)expl(-f.ah);
+    for (int k = 0; k < 3; ++k) tp->c[k] = (double)f.c[k];
+    tp->rG = (double)expl(-f.ah * RL_SF_G);
+    for (int j = 0; j <= RL_SF_G; ++j) pw[j] = (double)expl(-f.ah * j);
+    for (int n = 0; n <= 16; ++n) {
+        const long double r = expl(-f.ah * n), nn = (long double)n;
+        bk->tb[n] = (double)((f.c[0] + (f.c[1] + f.c[2] * nn) * nn) * r);
+        bk->r1[n] = (double)((f.c[1] + 2.0L * f.c[2] * nn) * r);
+        bk->r2[n] = (double)(f.c[2] * r);
+        bk->pw[n] = (double)r;
+        bk->p16[n] = (double)expl(-f.ah * 16 * n);
+    }
+}
+
+static int sf_nchunks(const rl_gridop* g) { return (g->m + RL_SF_G - 1) / RL_SF_G; }
+static size_t sf_need_E(const rl_gridop* g, int nvec, int NF, int NS) {
+    return (size_t)sf_nchunks(g) * nvec * g->D * NF * 2 * NS;
+}
+static size_t sf_need_Cin(const rl_gridop* g, int nvec, int nchan, int NS) {
+    return (size_t)sf_nchunks(g) * nvec * nchan * 2 * NS;
+}
+static bool sf_ready(const rl_gridop* g, int nvec, int NF, int nfac, int NS) {
+    return g->sf_E_cap >= sf_need_E(g, nvec, NF, NS) &&
+           g->sf_Cin_cap >= sf_need_Cin(g, nvec, g->D * NF + nfac, NS);
+}
+static int sf_reserve(rl_gridop* g, int nvec, int NF, int nfac, int NS) {
+    const size_t needE = sf_need_E(g, nvec, NF, NS), needC = sf_need_Cin(g, nvec, g->D * NF + nfac, NS);
+    if (g->sf_E_cap < needE) {
+        if (g->sf_E) RL_HIP(hipFree(g->sf_E));
+        g->sf_E = nullptr;
+        g->sf_E_cap = 0;
+        RL_HIP(hipMalloc((void**)&g->sf_E, needE * sizeof(double)));
+        g->sf_E_cap = needE;
+    }
+    if (g->sf_Cin_cap < needC) {
+        if (g->sf_Cin) RL_HIP(hipFree(g->sf_Cin));
+        g->sf_Cin = nullptr;
+        g->sf_Cin_cap = 0;
+        RL_HIP(hipMalloc((void**)&g->sf_Cin, needC * sizeof(double)));
+        g->sf_Cin_cap = needC;
+    }
+    return RL_OK;
+}
+static size_t sf_apply_lds(int D, int nfac, int NF, int nthr) {
+    size_t b = ((size_t)(D + nfac) * RL_SF_PAD + sf_blob_doubles(NF, nfac, D) +
+                (size_t)(D * NF + nfac) * 2 * 3) * sizeof(double);
+#if defined(RL_EMU)
+    b += (size_t)(nthr / 64) * 128 * sizeof(double);
+#else
+    (void)nthr;
+#endif
+    return b;
+}
+
+// Y (+)= [filter part] X: carries -> scan -> apply
+template <int NS>
+static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const double* X,
+                      double* Y, int nvec, int accumulate, hipStream_t st) {
+    const int D = g->D, nrows = nvec * D, nch = sf_nchunks(g);
+    // rows per carries workgroup: the filter powers are staged once per workgroup
+    const int rpw = nrows >= 16 * 64 ? 64 : 16;
+    RL_LAUNCH((k_sf_carries<NS>), dim3(nch, (nrows + rpw - 1) / rpw), dim3(256),
+              ((size_t)sp.NF * (RL_SF_G + 1) + 256) * sizeof(double), st, X, nrows, g->m, sp.NF,
+              sp.pw, rpw, g->sf_E);
+    const int ncd = 2 * (D * sp.NF + sp.nfac);
+    RL_LAUNCH((k_sf_scan<NS>), dim3((ncd + 15) / 16, nvec), dim3(256), 256 * NS * sizeof(double),
+              st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin);
+    // one wave per row slot at a time; eight waves = two per SIMD, two workgroups per CU at
+    // 128 registers.  (A workgroup of five waves puts two on the first SIMD, and a second
+    // workgroup then finds no room there: measured 2.8 ms per C5 product, one workgroup per CU.)
+    const int waves = 4;
+    // persistent workgroups, two per CU (what their LDS tiles allow at C5), each walking
+    // every (2 x CUs)-th tile with the next tile's loads in flight
+#if defined(RL_EMU)
+    const int ntiles = nch * nvec, resident = 7;            // (so that tests walk several tiles)
+#else
+    const int ntiles = nch * nvec, resident = 2 * RL_LR_CUS;
+#endif
+#define RL_SF_APPLY(XR_)                                                                     \
+    RL_LAUNCH((k_sf_apply<NS, XR_>), dim3(std::min(ntiles, resident)), dim3(64 * waves),        \
+              sf_apply_lds(D, sp.nfac, sp.NF, 64 * waves), st, X, Y, nvec, D, g->m, sp.NF,      \
+              sp.nfac, blob, (const double*)g->sf_Cin, accumulate)
+    if (D <= 4) RL_SF_APPLY(8);
+    else if (D <= 8) RL_SF_APPLY(16);
+    else if (D <= 12) RL_SF_APPLY(24);
+    else RL_SF_APPLY(32);
+#undef RL_SF_APPLY
+}
+
+// the operator's filter part (every filter top with its couplings)
+static int sf_apply_all(rl_gridop* g, const double* X, double* Y, int nvec, int accumulate,
+                        hipStream_t st) {
+    SfParams sp{g->sf_n, g->sf_nfac, g->sf_tops, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW,
+                g->sf_facJ};
+    if (g->sf_ns == 3) sf_launch<3>(g, sp, g->sf_blob, X, Y, nvec, accumulate, st);
+    else sf_launch<2>(g, sp, g->sf_blob, X, Y, nvec, accumulate, st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+// (I_D (x) T_q) X for one filter top
+static int sf_apply_top(rl_gridop* g, int q, const double* X, double* Y, int nvec, hipStream_t st) {
+    const int j = g->sf_slot[q];
+    SfParams sp{1, 0, g->sf_tops + j, g->sf_pw + (size_t)j * (RL_SF_G + 1), g->ones, nullptr,
+                nullptr, nullptr};
+    const double* blob = g->sf_blob_top + (size_t)j * sf_blob_doubles(1, 0, g->D);
+    if (g->sf_top_ns[q] == 3) sf_launch<3>(g, sp, blob, X, Y, nvec, 0, st);
+    else sf_launch<2>(g, sp, blob, X, Y, nvec, 0, st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// set-time work: which form does each top row take?
+// ---------------------------------------------------------------------------
+// small kernels of the polynomial verification (everything stays on the device
+// until ONE copy per rank tried brings the verdicts of all tops back)
+//   C[i][j] = (c_ij + c_ji) / 2,  c_ij = nu_i sum_chunks part[chunk][row j][i]
+__global__ void __launch_bounds__(256)
+k_lr_finish_C(const double* __restrict__ part, int nparts, int nrows, int r,
+              const double* __restrict__ nu, double* __restrict__ C) {
+    for (int e = threadIdx.x; e < r * r; e += 256) {
+        const int i = e / r, j = e - i * r;
+        double a = 0.0, b = 0.0;
+        for (int c = 0; c < nparts; ++c) {
+            a += part[((size_t)c * nrows + j) * r + i];
+            b += part[((size_t)c * nrows + i) * r + j];
+        }
+        C[e] = 0.5 * (nu[i] * a + nu[j] * b);
+    }
+}
+#define RL_LR_NB 64            // workgroups of a comparison
+//   out[b][0] = max |y1 - y2|, out[b][1] = max |y1|, out[b][2] = entries that are not finite
+__global__ void __launch_bounds__(256)
+k_lr_compare(const double* __restrict__ y1, const double* __restrict__ y2, size_t n,
+             double* __restrict__ out) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);       // [3][256]
+    double dmax = 0.0, ymax = 0.0, bad = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double a = y1[i], b = y2[i], d = fabs(a - b);
+        if (!(d <= 1e300)) bad += 1.0;              // (NaN and infinities fail the comparison)
+        else dmax = d > dmax ? d : dmax;
+        ymax = fabs(a) > ymax ? fabs(a) : ymax;
+    }
+    const int tid = threadIdx.x;
+    red[tid] = dmax;
+    red[256 + tid] = ymax;
+    red[512 + tid] = bad;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[tid] = red[tid] > red[tid + s] ? red[tid] : red[tid + s];
+            red[256 + tid] = red[256 + tid] > red[256 + tid + s] ? red[256 + tid] : red[256 + tid + s];
+            red[512 + tid] += red[512 + tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[blockIdx.x * 3 + 0] = red[0];
+        out[blockIdx.x * 3 + 1] = red[256];
+        out[blockIdx.x * 3 + 2] = red[512];
+    }
+}
+//   out[row] = max_i |V[row][i]|   (grid: rows)
+__global__ void __launch_bounds__(256)
+k_lr_rowmax(const double* __restrict__ V, int m, double* __restrict__ out) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const double* v = V + (size_t)blockIdx.x * m;
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const double a = fabs(v[i]);
+        mx = (a > mx || !(a <= 1e300)) ? a : mx;    // (a NaN sticks)
+    }
+    const int tid = threadIdx.x;
+    red[tid] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double o = red[tid + s];
+            if (o > red[tid] || !(o <= 1e300)) red[tid] = o;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = red[0];
+}
+// per-top verdict record on the device: RL_LR_NB x 3 comparison partials, then the
+// row maxima of T Phi_j, j < RL_LR_RMAX + 16
+#define RL_LR_STATW (RL_LR_NB * 3 + RL_LR_RMAX + 16)
+
+// Polynomial verification of the tops with want[q] != 0: builds C_q = Phi^T T_q Phi
+// with the transform kernels of this handle and accepts, per top and rank,
+//   (i)  the product of a fixed random vector through both forms agrees to
+//        RL_LR_TOL of its largest entry (the D blocks are D independent trials),
+//   (ii) the first RL_LR_EXTRA orthonormal polynomials the rank OMITS -- for which
+//        the form returns zero by construction -- have  max|T Phi_{r+k}| <=
+//        RL_LR_TOL max_j max|T Phi_j|: the operator's action outside the subspace
+//        is at roundoff (this is the adversarial input of the form; a random
+//        vector only carries 1/sqrt(m) of its norm in any one direction),
+//   (iii) nothing in either product is NaN or infinite.
+// Tries r = 24, 32, 48: the first rank that every wanted top passes is used; if
+// none, rank 48 with whatever passes.  pass[q] is set for the tops in the form.
+static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<char>* pass) {
     const int D = g->D, m = g->m, Q = g->Q;
     const size_t vec = (size_t)D * m;
+    pass->assign(Q, 0);
     if (!g->lr_phiJ) {
         RL_TRY(lr_make_basis(g));
-        RL_HIP(hipMalloc((void**)&g->lr_C, (size_t)g->max_tops * RL_LR_RMAX * RL_LR_RMAX * sizeof(double)));
+        // verdict records in front of C, so that one copy brings both back
+        double* cs = nullptr;
+        RL_HIP(hipMalloc((void**)&cs, (size_t)g->max_tops * (RL_LR_STATW + RL_LR_RMAX * RL_LR_RMAX) * sizeof(double)));
+        g->lr_stat = cs;
+        g->lr_C = cs + (size_t)g->max_tops * RL_LR_STATW;
+        RL_HIP(hipMalloc((void**)&g->lr_Cc, (size_t)g->max_tops * RL_LR_RMAX * RL_LR_RMAX * sizeof(double)));
         RL_HIP(hipMalloc((void**)&g->lr_B, (size_t)g->max_tops * D * D * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&g->lr_Bc, (size_t)g->max_tops * D * D * sizeof(double)));
         std::vector<double> eye((size_t)D * D, 0.0);
         for (int a = 0; a < D; ++a) eye[(size_t)a * D + a] = 1.0;
         RL_TRY(upload(&g->lr_eye, eye));
         // scratch: a fixed random vector, two results, the packed T Phi block
-        const size_t nvr = (RL_LR_RMAX + D - 1) / D;
+        const size_t nvr = (RL_LR_RMAX + RL_LR_EXTRA + D - 1) / D;
         RL_HIP(hipMalloc((void**)&g->lr_scr, (3 + nvr) * vec * sizeof(double)));
         std::vector<double> xr(vec);
         unsigned long long st = 0x9E3779B97F4A7C15ull;          // fixed seed: same trials every time
@@ -1362,81 +1745,242 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
         }
         RL_HIP(hipMemcpy(g->lr_scr, xr.data(), vec * sizeof(double), hipMemcpyHostToDevice));
     }
-    // dense coupling B_q = sum_{f of q} w_f a_f a_f^T + diag(kappa_q)
-    std::vector<double> B((size_t)Q * D * D, 0.0);
-    for (size_t f = 0; f < W.size(); ++f)
-        for (int a = 0; a < D; ++a)
-            for (int b = 0; b < D; ++b)
-                B[((size_t)Qi[f] * D + a) * D + b] += W[f] * A[f * D + a] * A[f * D + b];
-    for (int q = 0; q < Q; ++q)
-        for (int a = 0; a < D; ++a) B[((size_t)q * D + a) * D + a] += kap[(size_t)q * D + a];
-    RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
-
     double* xr = g->lr_scr;
     double* y1 = xr + vec;
     double* y2 = y1 + vec;
     double* tphi = y2 + vec;
     hipStream_t st = nullptr;
-    std::vector<double> h1(2 * vec), hnu(RL_LR_RMAX);
-    RL_HIP(hipMemcpy(hnu.data(), g->lr_nu, hnu.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> back;
+    std::vector<char> best;
     for (int r : {24, 32, 48}) {
         if (r > 24 && m < 2048) break;      // (short grids: only the solver's rank-24 rounds use the form)
         g->lr_r = r;
-        const int nvr = (r + D - 1) / D;
+        const int nvr = (r + RL_LR_EXTRA + D - 1) / D, nrows = nvr * D;
         RL_TRY(lr_reserve(g, std::max(nvr, 1)));
-        bool ok = true;
-        for (int q = 0; q < Q && ok; ++q) {
+        for (int q = 0; q < Q; ++q) {
+            if (!want[q]) continue;
             MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones,
                          nullptr, nullptr};
+            double* stat = g->lr_stat + (size_t)q * RL_LR_STATW;
             // rows j of tphi = T_q Phi_j (the function-major basis IS a batch of vectors)
             g->lr_bypass = true;
             int rc = mvm_with_mix(g, mp, g->lr_phiJ, tphi, nvr, st);
             g->lr_bypass = false;
             if (rc != RL_OK) return rc;
+            RL_LAUNCH(k_lr_rowmax, dim3(nrows), dim3(256), 256 * sizeof(double), st,
+                      (const double*)tphi, m, stat + RL_LR_NB * 3);
             // C_q[i][j] = Phi_i . (T_q Phi_j): the projection of those rows
-            const int nrows = nvr * D;
             int nparts = 0;
             switch (r) {
                 case 24: nparts = lr_project<24>(g, tphi, nrows, st); break;
                 case 32: nparts = lr_project<32>(g, tphi, nrows, st); break;
                 default: nparts = lr_project<48>(g, tphi, nrows, st); break;
             }
-            std::vector<double> part((size_t)nparts * nrows * r);
-            RL_HIP(hipMemcpy(part.data(), g->lr_part, part.size() * sizeof(double), hipMemcpyDeviceToHost));
-            std::vector<double> C((size_t)r * r, 0.0);
-            for (int c = 0; c < nparts; ++c)
-                for (int j = 0; j < r; ++j)
-                    for (int i = 0; i < r; ++i)
-                        C[(size_t)i * r + j] += hnu[i] * part[((size_t)c * nrows + j) * r + i];
-            for (int i = 0; i < r; ++i)                          // T_q is symmetric
-                for (int j = i + 1; j < r; ++j) {
-                    const double v = 0.5 * (C[(size_t)i * r + j] + C[(size_t)j * r + i]);
-                    C[(size_t)i * r + j] = C[(size_t)j * r + i] = v;
-                }
-            RL_HIP(hipMemcpy(g->lr_C + (size_t)q * r * r, C.data(), C.size() * sizeof(double), hipMemcpyHostToDevice));
-            if (g->lr_hC.size() < (size_t)Q * r * r) g->lr_hC.resize((size_t)Q * r * r);
-            std::copy(C.begin(), C.end(), g->lr_hC.begin() + (size_t)q * r * r);
+            RL_LAUNCH(k_lr_finish_C, dim3(1), dim3(256), 0, st, (const double*)g->lr_part, nparts,
+                      nrows, r, (const double*)g->lr_nu, g->lr_C + (size_t)q * r * r);
             // trial: T_q xr through both forms
             g->lr_bypass = true;
             rc = mvm_with_mix(g, mp, xr, y1, 1, st);
             g->lr_bypass = false;
             if (rc != RL_OK) return rc;
             RL_TRY(lr_apply(g, xr, y2, 1, q, 1, g->lr_eye, st));
-            // (y1 and y2 are neighbours in the scratch buffer: one copy, one round trip)
-            RL_HIP(hipMemcpy(h1.data(), y1, 2 * vec * sizeof(double), hipMemcpyDeviceToHost));
-            double dmax = 0.0, ymax = 0.0;
-            for (size_t i = 0; i < vec; ++i) {
-                dmax = std::max(dmax, std::fabs(h1[i] - h1[vec + i]));
-                ymax = std::max(ymax, std::fabs(h1[i]));
-            }
-            ok = dmax <= RL_LR_TOL * ymax || (ymax == 0.0 && dmax == 0.0);
+            RL_LAUNCH(k_lr_compare, dim3(RL_LR_NB), dim3(256), 3 * 256 * sizeof(double), st,
+                      (const double*)y1, (const double*)y2, vec, stat);
         }
-        if (ok) {
+        RL_HIP(hipGetLastError());
+        // the one round trip of this rank: verdict records of all tops + their C
+        back.resize((size_t)g->max_tops * RL_LR_STATW + (size_t)Q * r * r);
+        RL_HIP(hipMemcpy(back.data(), g->lr_stat, back.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<char> ok(Q, 0);
+        bool all = true;
+        for (int q = 0; q < Q; ++q) {
+            if (!want[q]) continue;
+            const double* stat = back.data() + (size_t)q * RL_LR_STATW;
+            double dmax = 0.0, ymax = 0.0, bad = 0.0;
+            for (int b = 0; b < RL_LR_NB; ++b) {
+                dmax = std::max(dmax, stat[b * 3]);
+                ymax = std::max(ymax, stat[b * 3 + 1]);
+                bad += stat[b * 3 + 2];
+            }
+            const double* rm = stat + RL_LR_NB * 3;
+            double inside = 0.0, outside = 0.0;
+            bool finite = bad == 0.0 && std::isfinite(ymax);
+            for (int j = 0; j < r + RL_LR_EXTRA; ++j) {
+                if (!std::isfinite(rm[j])) finite = false;
+                (j < r ? inside : outside) = std::max(j < r ? inside : outside, rm[j]);
+            }
+            const bool trial = dmax <= RL_LR_TOL * ymax || (ymax == 0.0 && dmax == 0.0);
+            const bool tail = outside <= RL_LR_TOL * inside || (inside == 0.0 && outside == 0.0);
+            ok[q] = finite && trial && tail;
+            all = all && ok[q];
+        }
+        best = ok;
+        if (all) break;
+    }
+    *pass = best;
+    const int r = g->lr_r;
+    g->lr_hC.assign(back.begin() + (size_t)g->max_tops * RL_LR_STATW,
+                    back.begin() + (size_t)g->max_tops * RL_LR_STATW + (size_t)Q * r * r);
+    return RL_OK;
+}
+
+// Decides the form of every top row for the current parameters and builds the
+// tables of the forms in use:
+//   lr_ok  every top is in the polynomial form (rl_lowrank.h) -- as before;
+//   st_ok  every top is in the polynomial or in the filter form and at least one in
+//          the latter: the operator is  [polynomial part] + [filter part];
+//   otherwise operator products run on the transform kernels; single-top products
+//   (rl_gridop_mvm_top: the gradient's dK products) still take each top's own form.
+static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::vector<double>& W,
+                       const std::vector<int>& Qi, const std::vector<double>& kap) {
+    const int D = g->D, m = g->m, Q = g->Q;
+    g->lr_ok = false;
+    g->st_ok = false;
+    g->top_form.assign(Q, 0);
+    g->sf_slot.assign(Q, -1);
+    g->sf_top_ns.assign(Q, 2);
+    g->sf_n = 0;
+    g->sf_nfac = 0;
+    g->lr_np = 0;
+    if (!g->lr_try && !g->sf_try) return RL_OK;
+    // 1. exponential-polynomial tops (host, from the rows themselves)
+    std::vector<SfFit> fits(Q);
+    int nfilt = 0;
+    if (g->sf_try && g->h_tops.size() >= (size_t)Q * m)
+        for (int q = 0; q < Q && nfilt < RL_SF_MAXTOPS; ++q)
+            if (sf_detect(g->h_tops.data() + (size_t)q * m, m, &fits[q])) {
+                g->top_form[q] = 2;
+                g->sf_slot[q] = nfilt++;
+                g->sf_top_ns[q] = fits[q].c[2] != 0.0L ? 3 : 2;
+            }
+    g->sf_n = nfilt;
+    // 2. polynomial verification of the others (device; skipped while backing off
+    //    after rejections in a row: 0, 1, 3, ... 31 parameter updates)
+    std::vector<char> want(Q, 0), pass(Q, 0);
+    int nwant = 0;
+    for (int q = 0; q < Q; ++q)
+        if (g->top_form[q] == 0) {
+            want[q] = 1;
+            ++nwant;
+        }
+    if (nwant && g->lr_try) {
+        if (g->lr_skip > 0) {
+            --g->lr_skip;
+        } else {
+            RL_TRY(lr_verify(g, want, &pass));
+            bool all = true;
+            for (int q = 0; q < Q; ++q)
+                if (want[q]) {
+                    if (pass[q]) g->top_form[q] = 1;
+                    else all = false;
+                }
+            if (all) {
+                g->lr_rejects = 0;
+            } else {
+                g->lr_rejects = std::min(g->lr_rejects + 1, 6);
+                g->lr_skip = (1 << (g->lr_rejects - 1)) - 1;
+            }
+        }
+    }
+    int npoly = 0, nfft = 0;
+    for (int q = 0; q < Q; ++q) {
+        npoly += g->top_form[q] == 1;
+        nfft += g->top_form[q] == 0;
+    }
+    g->lr_np = npoly;
+    // 3. tables.  Filter tops: parameters + powers (single-top products need them
+    //    whatever the operator as a whole does)
+    if (nfilt) {
+        if (!g->sf_tops) {
+            RL_HIP(hipMalloc((void**)&g->sf_tops, (size_t)g->max_tops * sizeof(SfTop)));
+            RL_HIP(hipMalloc((void**)&g->sf_blob, (size_t)sf_blob_doubles(g->max_tops, g->max_fac, D) * sizeof(double)));
+            RL_HIP(hipMalloc((void**)&g->sf_blob_top, (size_t)g->max_tops * sf_blob_doubles(1, 0, D) * sizeof(double)));
+            RL_HIP(hipMalloc((void**)&g->sf_pw, (size_t)g->max_tops * (RL_SF_G + 1) * sizeof(double)));
+            RL_HIP(hipMalloc((void**)&g->sf_kappa, (size_t)g->max_tops * D * sizeof(double)));
+            RL_HIP(hipMalloc((void**)&g->sf_facA, (size_t)g->max_fac * D * sizeof(double)));
+            RL_HIP(hipMalloc((void**)&g->sf_facAW, (size_t)g->max_fac * D * sizeof(double)));
+            RL_HIP(hipMalloc((void**)&g->sf_facJ, (size_t)g->max_fac * sizeof(int)));
+        }
+        std::vector<SfTop> tops(nfilt);
+        std::vector<SfBlk> blks(nfilt);
+        std::vector<double> pw((size_t)nfilt * (RL_SF_G + 1)), kp((size_t)nfilt * D), fa, faw;
+        std::vector<int> fj;
+        int ns = 2;
+        for (int q = 0; q < Q; ++q) {
+            const int j = g->sf_slot[q];
+            if (j < 0) continue;
+            sf_device_top(fits[q], &tops[j], &blks[j], pw.data() + (size_t)j * (RL_SF_G + 1));
+            for (int a = 0; a < D; ++a) kp[(size_t)j * D + a] = kap[(size_t)q * D + a];
+            ns = std::max(ns, g->sf_top_ns[q]);
+        }
+        for (size_t f = 0; f < W.size(); ++f) {
+            const int j = g->sf_slot[Qi[f]];
+            if (j < 0) continue;
+            for (int a = 0; a < D; ++a) {
+                fa.push_back(A[f * D + a]);
+                faw.push_back(W[f] * A[f * D + a]);
+            }
+            fj.push_back(j);
+        }
+        g->sf_ns = ns;
+        g->sf_nfac = (int)fj.size();
+        RL_HIP(hipMemcpy(g->sf_tops, tops.data(), tops.size() * sizeof(SfTop), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(g->sf_pw, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(g->sf_kappa, kp.data(), kp.size() * sizeof(double), hipMemcpyHostToDevice));
+        // the blocks k_sf_apply stages in LDS: the whole filter part, and every top alone
+        {
+            const int nf = (int)fj.size();
+            auto build = [&](int NFb, int nfb, const double* kapb, const double* fab,
+                             const double* fawb, const int* fjb, const SfBlk* bk, double* out) {
+                double* o = out;
+                for (int e = 0; e < NFb * D; ++e) *o++ = kapb[e];
+                for (int e = 0; e < nfb * D; ++e) *o++ = fab[e];
+                for (int e = 0; e < nfb * D; ++e) *o++ = fawb[e];
+                for (int f = 0; f < nfb; ++f) *o++ = (double)fjb[f];
+                for (int a = 0; a < D; ++a)
+                    for (int n = 0; n < 16; ++n) {
+                        long double t = 0.0L;
+                        for (int j = 0; j < NFb; ++j) t += (long double)kapb[(size_t)j * D + a] * bk[j].tb[n];
+                        *o++ = (double)t;
+                    }
+                for (int f = 0; f < nfb; ++f)
+                    for (int n = 0; n < 16; ++n) *o++ = bk[fjb[f]].tb[n];
+                std::memcpy(o, bk, (size_t)NFb * sizeof(SfBlk));
+            };
+            std::vector<double> blob(sf_blob_doubles(nfilt, nf, D));
+            build(nfilt, nf, kp.data(), fa.data(), faw.data(), fj.data(), blks.data(), blob.data());
+            RL_HIP(hipMemcpy(g->sf_blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
+            const int one = sf_blob_doubles(1, 0, D);
+            std::vector<double> tblob((size_t)nfilt * one), ones(D, 1.0);
+            for (int j = 0; j < nfilt; ++j)
+                build(1, 0, ones.data(), nullptr, nullptr, nullptr, &blks[j], tblob.data() + (size_t)j * one);
+            RL_HIP(hipMemcpy(g->sf_blob_top, tblob.data(), tblob.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (!fj.empty()) {
+            RL_HIP(hipMemcpy(g->sf_facA, fa.data(), fa.size() * sizeof(double), hipMemcpyHostToDevice));
+            RL_HIP(hipMemcpy(g->sf_facAW, faw.data(), faw.size() * sizeof(double), hipMemcpyHostToDevice));
+            RL_HIP(hipMemcpy(g->sf_facJ, fj.data(), fj.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    if (nfft > 0) return RL_OK;          // some top needs the transforms: so does the operator
+    // dense couplings B_q = sum_{f of q} w_f a_f a_f^T + diag(kappa_q) of the polynomial tops
+    if (npoly) {
+        std::vector<double> B((size_t)Q * D * D, 0.0);
+        for (size_t f = 0; f < W.size(); ++f)
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b < D; ++b)
+                    B[((size_t)Qi[f] * D + a) * D + b] += W[f] * A[f * D + a] * A[f * D + b];
+        for (int q = 0; q < Q; ++q)
+            for (int a = 0; a < D; ++a) B[((size_t)q * D + a) * D + a] += kap[(size_t)q * D + a];
+        const int r = g->lr_r;
+        if (nfilt == 0) {
+            RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
             g->lr_ok = true;
-            g->lr_rejects = 0;
             if (r == RL_LR_RS && getenv("RUNLMC_NO_POLY_ROUND") == nullptr) {
                 // the whole coefficient map of the solver's polynomial rounds
                 //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
+                std::vector<double> hnu(RL_LR_RMAX);
+                RL_HIP(hipMemcpy(hnu.data(), g->lr_nu, hnu.size() * sizeof(double), hipMemcpyDeviceToHost));
                 std::vector<double> M((size_t)D * r * D * r, 0.0);
                 for (int q = 0; q < Q; ++q)
                     for (int a = 0; a < D; ++a)
@@ -1458,17 +2002,31 @@ static int lr_setup(rl_gridop* g, const std::vector<double>& A, const std::vecto
             }
             return RL_OK;
         }
+        // polynomial tops next to filter tops: their C and B contiguous
+        std::vector<double> Bc, Cc;
+        for (int q = 0; q < Q; ++q) {
+            if (g->top_form[q] != 1) continue;
+            Bc.insert(Bc.end(), B.begin() + (size_t)q * D * D, B.begin() + (size_t)(q + 1) * D * D);
+            Cc.insert(Cc.end(), g->lr_hC.begin() + (size_t)q * r * r,
+                      g->lr_hC.begin() + (size_t)(q + 1) * r * r);
+        }
+        RL_HIP(hipMemcpy(g->lr_Bc, Bc.data(), Bc.size() * sizeof(double), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(g->lr_Cc, Cc.data(), Cc.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (++g->lr_rejects >= 3) g->lr_try = false;
+    // the filter part's tile (D + nfac rows of RL_SF_PAD doubles) has to fit LDS
+    // (and its incoming states four registers of each of 256 threads)
+    g->st_ok = nfilt > 0 && sf_apply_lds(D, g->sf_nfac, nfilt, 512) <= kLdsHard &&
+               (D * nfilt + g->sf_nfac) * 2 * 3 <= 4 * 256;
     return RL_OK;
 }
 
 static int lr_ensure(rl_gridop* g);
 // before a capture: pending verification and buffers for batches of nvec vectors
 static int lr_prepare(rl_gridop* g, int nvec) {
-    if (!g->lr_try || (size_t)nvec * g->D * g->m < g->lr_min) return RL_OK;
+    if ((!g->lr_try && !g->sf_try) || (size_t)nvec * g->D * g->m < g->lr_min) return RL_OK;
     RL_TRY(lr_ensure(g));
-    if (g->lr_ok) RL_TRY(lr_reserve(g, nvec));
+    if (g->lr_ok || (g->st_ok && g->lr_np)) RL_TRY(lr_reserve(g, nvec));
+    if (g->st_ok) RL_TRY(sf_reserve(g, nvec, g->sf_n, g->sf_nfac, g->sf_ns));
     return RL_OK;
 }
 
@@ -1477,7 +2035,7 @@ static int lr_ensure(rl_gridop* g) {
     if (!g->lr_dirty) return RL_OK;
     g->lr_dirty = false;
     RL_HIP(hipSetDevice(g->device));
-    return lr_setup(g, g->lr_A, g->lr_W, g->lr_Qi, g->lr_kap);
+    return forms_setup(g, g->lr_A, g->lr_W, g->lr_Qi, g->lr_kap);
 }
 
 static bool stream_capturing(hipStream_t stream) {
@@ -1495,26 +2053,45 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_HIP(hipSetDevice(g->device));
-    const bool lr_batch = g->lr_try && !g->lr_bypass && (size_t)nvec * g->D * g->m >= g->lr_min;
+    const bool big = (g->lr_try || g->sf_try) && !g->lr_bypass &&
+                     (size_t)nvec * g->D * g->m >= g->lr_min;
     // (nothing may be allocated or copied inside a capture: a pending verification
     // waits for the next product outside one; the solver runs it before it captures)
-    if (lr_batch && g->lr_dirty && !stream_capturing(stream)) RL_TRY(lr_ensure(g));
-    if (lr_batch && g->lr_ok && !g->lr_dirty) {
-        // smooth kernels, a batch large enough to fill the chip with projection
-        // workgroups: polynomial-subspace form, verified at set time
-        bool ready = g->lr_part_cap >= lr_part_need(g, nvec) &&
-                     g->lr_zhat_cap >= (size_t)nvec * g->D * RL_LR_RMAX;
-        if (!ready && !stream_capturing(stream)) {
-            RL_TRY(lr_reserve(g, nvec));
+    const bool capturing = big && stream_capturing(stream);
+    if (big && g->lr_dirty && !capturing) RL_TRY(lr_ensure(g));
+    if (big && !g->lr_dirty) {
+        // a batch large enough to fill the chip with projection / filter workgroups:
+        // each top row in the form it was found in at set time (forms_setup)
+        const bool single = mp.nfac == 0 && mp.Q == 1 && mp.kappa == g->ones;
+        const int q1 = single ? (int)((mp.spec - g->spec) / g->L) : -1;
+        const int form = single ? g->top_form[q1] : (g->lr_ok ? 1 : (g->st_ok ? 3 : 0));
+        const bool poly_part = form == 1 || (form == 3 && g->lr_np > 0);
+        bool ready = true;
+        if (poly_part)
+            ready = g->lr_part_cap >= lr_part_need(g, nvec) &&
+                    g->lr_zhat_cap >= (size_t)nvec * g->D * RL_LR_RMAX;
+        const int sNF = single ? 1 : g->sf_n, sfac = single ? 0 : g->sf_nfac;
+        const int sNS = single ? (form == 2 ? g->sf_top_ns[q1] : 2) : g->sf_ns;
+        if (form >= 2) ready = ready && sf_ready(g, nvec, sNF, sfac, sNS);
+        if (form != 0 && !ready && !capturing) {
+            if (poly_part) RL_TRY(lr_reserve(g, nvec));
+            if (form >= 2) RL_TRY(sf_reserve(g, nvec, sNF, sfac, sNS));
             ready = true;
         }
-        if (ready) {
-            trace_once("grid product: polynomial-subspace form (k_lr_project / mix / expand)");
-            const bool single = mp.nfac == 0 && mp.Q == 1 && mp.kappa == g->ones;
-            if (single)
-                return lr_apply(g, X, Y, nvec, (int)((mp.spec - g->spec) / g->L), 1, g->lr_eye,
-                                stream);
-            return lr_apply(g, X, Y, nvec, 0, g->Q, g->lr_B, stream);
+        if (form != 0 && ready) {
+            if (form == 1) {
+                trace_once("grid product: polynomial-subspace form (k_lr_project / mix / expand)");
+                if (single) return lr_apply(g, X, Y, nvec, q1, 1, g->lr_eye, stream);
+                return lr_apply(g, X, Y, nvec, 0, g->Q, g->lr_B, stream);
+            }
+            if (form == 2) {
+                trace_once("grid product: recursive-filter form (k_sf_carries / scan / apply)");
+                return sf_apply_top(g, q1, X, Y, nvec, stream);
+            }
+            trace_once("grid product: recursive-filter part + polynomial part");
+            RL_TRY(sf_apply_all(g, X, Y, nvec, 0, stream));
+            if (g->lr_np > 0) RL_TRY(lr_apply_compact(g, X, Y, nvec, stream));
+            return RL_OK;
         }
     }
     if (g->v1p && (nvec >= g->v1p_min || g->D <= 2)) {

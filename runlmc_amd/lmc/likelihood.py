@@ -115,8 +115,7 @@ class ApproxLMCLikelihood(LMCLikelihood):
         term_of = getattr(self.K, 'term_of', None) or {ad: 0 for ad in fk.active_dims}
         nloc = dv.rs_dev.shape[0]
         # alpha rides in a transform pair of its own (last of an odd batch, or
-        # next to a zero row), as in the solves: its Gram terms then carry the
-        # same bits on every rank, whatever probes the rank holds
+        # next to a zero row), as in the solves
         arow = dv.alpha_dev[None, :]
         if nloc % 2 == 0:
             U = torch.cat([dv.inv_rs_dev, arow], dim=0).contiguous()
@@ -163,15 +162,27 @@ class ApproxLMCLikelihood(LMCLikelihood):
             np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int32)).to(dev)
         seg = segment_dots(lib, U, V, offsets, D)          # (nrow, D)
 
-        # alpha terms are identical on every rank; probe sums are reduced
+        # ONE all-reduce: the probe sums of every rank and, from rank 0 only,
+        # the alpha terms (alpha is the same vector everywhere, but the batch
+        # it rides in differs from rank to rank and with it the kernels and
+        # summation orders; taking rank 0's terms makes the assembled
+        # gradient the same bits on every rank)
+        from ..util.dist import rank_world
+        rank0 = rank_world(dv._group)[0] == 0
+        aP, aseg = P[:, ia].reshape(-1), seg[ia].reshape(-1)
+        if not rank0:
+            aP, aseg = torch.zeros_like(aP), torch.zeros_like(aseg)
         probe = torch.cat([P[:, probe_rows].sum(dim=1).reshape(-1),
-                           seg[probe_rows].sum(dim=0).reshape(-1)])
+                           seg[probe_rows].sum(dim=0).reshape(-1), aP, aseg])
         all_reduce_sum_(probe, dv._group)
         N = dv._n_it
-        Psum = probe[:ntops * D * D].reshape(ntops, D, D)
-        ssum = probe[ntops * D * D:]
-        Gall = (0.5 * (P[:, ia] - Psum / N)).cpu().numpy()
-        noise = (0.5 * (seg[ia] - ssum / N)).cpu().numpy()
+        nP = ntops * D * D
+        Psum = probe[:nP].reshape(ntops, D, D)
+        ssum = probe[nP:nP + D]
+        Pa = probe[nP + D:2 * nP + D].reshape(ntops, D, D)
+        sa = probe[2 * nP + D:]
+        Gall = (0.5 * (Pa - Psum / N)).cpu().numpy()
+        noise = (0.5 * (sa - ssum / N)).cpu().numpy()
         G = [None] * Q
         Gd = [[None] * len(self.materialized_grads[q]) for q in range(Q)]
         for t, (q, p_) in enumerate(owner):

@@ -11,7 +11,7 @@ import torch
 
 from .derivative import Derivative
 from ..approx.iterative import Iterative
-from ..util.dist import rank_world, shard_rows, all_reduce_sum_
+from ..util.dist import rank_world, shard_rows, all_reduce_sum_, broadcast_
 
 
 class StochasticDerivService:
@@ -42,11 +42,18 @@ class StochasticDerivService:
             raise ValueError('probes must have shape {}'.format((self._n_it, n)))
         mine = shard_rows(self._n_it, self._group)
         dev = K.device
-        # Two right-hand sides share one complex transform, so a vector's
-        # roundoff depends on its batch neighbour.  y is therefore given a
-        # transform of its own on EVERY rank -- last in an odd batch, or next to
-        # a zero vector -- and alpha comes out bit-identical everywhere: the
-        # ranks assemble identical gradients without any broadcast.
+        # Every rank solves for alpha next to its own probes (no rank waits
+        # for another during the solve); y rides in a transform pair of its
+        # own -- last in an odd batch, or next to a zero vector -- so that its
+        # roundoff does not depend on a probe.  That alone does not make the
+        # bits equal across ranks: which kernels a batch runs on (polynomial /
+        # filter forms above a batch gate, fused products below a size,
+        # projection chunk lengths) depends on the batch size, and ranks
+        # whose probe counts differ by one carry batches that differ by two.
+        # Rank 0's alpha is therefore BROADCAST after the solve (n doubles,
+        # one collective) and its Gram terms ride in the gradient's one
+        # all-reduce (likelihood.py): every rank ends the step with the same
+        # bits by construction, whatever the shard sizes.
         yrow = np.asarray(y, dtype=np.float64)[None, :]
         probes = rs[mine].astype(np.float64)
         if len(mine) % 2 == 0:
@@ -72,6 +79,7 @@ class StochasticDerivService:
             self.metrics.iterations.append(float(stats[0]) / (self._n_it + 1))
             self.metrics.solv_error.append(float(stats[1]) / (self._n_it + 1))
         alpha = X[0].clone()
+        broadcast_(alpha, src=0, group=self._group)        # (no-op in a world of one)
         return StochasticDeriv(alpha, B[1:], X[1:], self._n_it, group=self._group,
                                iterations=iters, residuals=resid, istop=istop,
                                lanczos=lanczos)

@@ -4,13 +4,32 @@
 The reference's only parallel axis is the N+1 independent solves mapped over a
 process pool (runlmc/lmc/stochastic_deriv.py:39-52).  Here the N probes are
 dealt round-robin to the ranks, every rank holds a replica of the operator and
-solves for alpha itself -- in a transform pair of its own, so that every rank
-gets the same bits without a broadcast -- and ONE all-reduce of the summed
-gradient partials (a few KB) closes the step.  There is no collective inside
-the solve.  A plain block of right-hand sides is split the same way and put
-together again with one all-gather."""
+solves for alpha next to its probes; rank 0's alpha is broadcast after the solve
+(n doubles) and ONE all-reduce of the summed gradient partials (a few KB, rank
+0's alpha terms among them) closes the step, so that every rank holds the same
+bits whatever its shard size.  There is no collective inside the solve.  A
+plain block of right-hand sides is split the same way and put together again
+with one all-gather.
+
+`force_collectives(True)` makes every helper issue its collective even in a
+world of ONE rank: on a one-GPU box that is the only way to push the step's
+broadcast / all-reduce / all-gather through RCCL itself (bench.py --force-dist,
+tests/test_gpu_multi_rank.py)."""
 import torch
 import torch.distributed as dist
+
+_FORCE = False
+
+
+def force_collectives(on=True):
+    """Issue collectives even when the world has one rank (needs an
+    initialised process group)."""
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def _skip(world):
+    return world == 1 and not (_FORCE and dist.is_available() and dist.is_initialized())
 
 
 def rank_world(group=None):
@@ -28,7 +47,7 @@ def shard_rows(count, group=None):
 def broadcast_(t, src=0, group=None):
     """In-place broadcast from rank `src`; no-op for one rank."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _skip(world):
         return t
     backend = dist.get_backend(group)
     if backend == 'gloo' and t.device.type != 'cpu':
@@ -45,7 +64,7 @@ def all_reduce_sum_(flat, group=None):
     Moves through host memory when the backend cannot take the tensor's
     device (gloo with a GPU tensor)."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _skip(world):
         return flat
     backend = dist.get_backend(group)
     if backend == 'gloo' and flat.device.type != 'cpu':
@@ -68,7 +87,7 @@ def all_gather_rows(local, counts, group=None):
     sends its own rows once instead of reducing a world-sized zero-padded
     block.  Returns a (sum(counts), width) tensor on `local`'s device."""
     rank, world = rank_world(group)
-    if world == 1:
+    if _skip(world):
         return local
     width = local.shape[1]
     most = max(counts)

@@ -824,6 +824,201 @@ def check_polynomial_form():
                 os.environ[kn] = saved[kn]
 
 
+def _matern32(x, gamma):
+    s = np.sqrt(3) * gamma * x
+    return (1 + s) * np.exp(-s)
+
+
+def _d_matern32(x, gamma):
+    """d/d gamma of the Matern-3/2 row (reference kern/matern32.py:50-55)."""
+    return -3.0 * gamma * x * x * np.exp(-np.sqrt(3) * gamma * x)
+
+
+def check_filter_form():
+    """Exponential-polynomial top rows -- the reference's Matern-3/2 kernel on a
+    regular grid, its derivative, a plain exponential -- run as a two-sided
+    recursive filter (rl_filter.h) once the batch is above the gate.  Checked:
+    (1) which tops are detected (forms 2 / 1 / 0 for Matern / RBF / a kinked
+    non-exponential row) and that detection follows parameter updates;
+    (2) an all-Matern operator (LMC factors of rank 1 and 2, dense B, an odd
+    batch, a grid that is no multiple of the 512-point chunk, more outputs than
+    one pass of row slots) against the oracle and against the transform kernels
+    of the same handle (batch below the gate) to 1e-12;
+    (3) single-top products of a Matern row and of its derivative row (three
+    states per direction) -- the gradient's dK products;
+    (4) an operator that MIXES polynomial and filter tops (the reference
+    benchmark's 'mix' family: rbf, periodic, matern) and one with a top that
+    needs the transform kernels (the whole operator then runs there, single-top
+    products keep their own forms);
+    (5) RUNLMC_NO_FILTER keeps a handle off the form."""
+    from runlmc_amd._native import GridOp
+    knobs = ('RUNLMC_NO_FILTER',)
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    rng = np.random.RandomState(77)
+    try:
+        # (20011 points: 40 chunks, so that the chunk scan's segments hold several)
+        for D, Q, m, k in ((3, 2, 2500, 3), (2, 3, 4101, 2), (5, 2, 700, 2), (2, 2, 20011, 2)):
+            x = np.linspace(0, 1, m)
+            gam = np.logspace(0, 1, Q) * (1.0 if m > 1000 else 3.0)
+            mat = np.array([_matern32(x, g_) for g_ in gam])
+            A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+            kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+            Bs = ops.coreg_mats(A, kap)
+            X = rng.randn(k, D * m)
+            X[-1] = np.cos(5 * np.tile(x, D)) + 1.0          # a coherent input
+
+            def oracle(tops, rows=X, Bs_=Bs):
+                toeps = [ops.BTTBOracle(t) for t in tops]
+                return np.array([ops.grid_sum_matvec(Bs_, toeps, r) for r in rows])
+
+            g = GridOp(D, m, Q)
+            g.set_lmc(mat, A, kap)
+            forms, structured = g.top_forms()
+            assert forms == [2] * Q and structured, (forms, structured)
+            assert g.form()[0] == 0                  # (not the polynomial form)
+            ref = oracle(mat)
+            fft = g.matmat_host(X)                   # below the gate: transform kernels
+            _close(fft, ref)
+            flt = _poly_product(g, X)
+            _close(flt, ref)
+            _close(flt, fft, 1e-12)
+            g.set_dense(mat, np.array(Bs))
+            _close(_poly_product(g, X), ref)
+            # single tops: a Matern row, then the handle the gradient uses (k and dk/dgamma)
+            one = _poly_product(g, X[:1], top=Q - 1)[0]
+            _close(one, np.concatenate([ops.BTTBOracle(mat[Q - 1]).matvec(r)
+                                        for r in X[0].reshape(D, m)]))
+            gt = np.array([mat[0], _d_matern32(x, gam[0]), np.exp(-3.0 * x)])
+            gg = GridOp(D, m, 3)
+            gg.set_lmc(gt, [None] * 3, [np.zeros(D)] * 3)
+            assert gg.top_forms()[0] == [2, 2, 2]
+            for t in range(3):
+                got = _poly_product(gg, X, top=t)
+                want = np.array([np.concatenate([ops.BTTBOracle(gt[t]).matvec(r)
+                                                 for r in v.reshape(D, m)]) for v in X])
+                _close(got, want)
+            if m < 2048:
+                continue
+            # the 'mix' family: rbf + periodic + matern (+ a second rbf)
+            mix = np.array([np.exp(-0.5 * x ** 2), np.exp(-0.5 * np.sin(np.pi * x) ** 2),
+                            _matern32(x, 1.0), np.exp(-0.5 * x ** 2)][:max(Q, 3)])
+            Qm = len(mix)
+            Am = [rng.randn(1, D) for _ in range(Qm)]
+            km = [np.abs(rng.randn(D)) + 0.1 for _ in range(Qm)]
+            Bm = ops.coreg_mats(Am, km)
+            gm = GridOp(D, m, Qm)
+            gm.set_lmc(mix, Am, km)
+            forms, structured = gm.top_forms()
+            assert forms == [1, 1, 2, 1][:Qm] and structured, forms
+            refm = oracle(mix, Bs_=Bm)
+            _close(gm.matmat_host(X), refm)
+            got = _poly_product(gm, X)
+            _close(got, refm)
+            _close(got, gm.matmat_host(X), 1e-12)
+            # a kinked row that is no exponential polynomial: transform kernels for the
+            # operator, own forms for the single tops
+            bad = mix.copy()
+            bad[0] = 1.0 / (1.0 + 30.0 * x)
+            gm.set_lmc(bad, Am, km)
+            forms, structured = gm.top_forms()
+            assert forms[0] == 0 and forms[2] == 2 and not structured, forms
+            _close(_poly_product(gm, X), oracle(bad, Bs_=Bm))
+            _close(_poly_product(gm, X[:1], top=2)[0],
+                   np.concatenate([ops.BTTBOracle(bad[2]).matvec(r) for r in X[0].reshape(D, m)]))
+            gm.set_lmc(mix, Am, km)             # and back
+            assert gm.top_forms()[1]
+            _close(_poly_product(gm, X), refm)
+        os.environ['RUNLMC_NO_FILTER'] = '1'
+        g1 = GridOp(2, 2500, 1)
+        g1.set_lmc(_matern32(np.linspace(0, 1, 2500), 2.0)[None], [rng.randn(1, 2)], [np.ones(2)])
+        assert g1.top_forms() == ([0], False)
+    finally:
+        for kn in knobs:
+            os.environ.pop(kn, None)
+            if saved[kn] is not None:
+                os.environ[kn] = saved[kn]
+
+
+def _orthonormal_polynomials(m, count):
+    """The first `count` orthonormal polynomials on m equispaced points (QR of a
+    Legendre Vandermonde matrix; columns ordered by degree)."""
+    s_ = np.linspace(-1.0, 1.0, m)
+    V = np.polynomial.legendre.legvander(s_, count - 1)
+    Qm, _ = np.linalg.qr(V)
+    return Qm.T
+
+
+def _lanczos_vector(matvec, v0, steps):
+    """The Lanczos vector after `steps` steps of the symmetric operator."""
+    v = v0 / np.linalg.norm(v0)
+    v_prev, beta = np.zeros_like(v), 0.0
+    for _ in range(steps):
+        w = matvec(v) - beta * v_prev
+        alpha = w.dot(v)
+        w = w - alpha * v
+        beta = np.linalg.norm(w)
+        v_prev, v = v, w / beta
+    return v
+
+
+def check_polynomial_gate_boundary(m=5004, factor=1.3):
+    """The polynomial form's acceptance gate AT ITS BOUNDARY.  The kernel is made
+    rougher step by step (RBF: inverse length scale up by `factor`; periodic:
+    period down) until rl_gridop_form reports the transform kernels; at the LAST
+    accepted parameter of every rank (24 / 32 / 48) the polynomial product is held
+    against the oracle on the inputs that are worst for it:
+      (i)   random vectors,
+      (ii)  the first four orthonormal polynomials the rank omits (the form
+            returns zero for them by construction),
+      (iii) a Lanczos vector of the operator after 50 steps (what MINRES feeds it),
+    each to 1e-11 of ||T||_2 ||x||_2."""
+    from runlmc_amd._native import GridOp
+    rng = np.random.RandomState(5)
+    x = np.linspace(0, 1, m)
+    phi = _orthonormal_polynomials(m, 52)
+    families = {
+        'rbf': lambda t: np.exp(-0.5 * t * x ** 2),
+        # reference std_periodic.py:44-48 with inverse length scale 1, period 1 / t
+        'periodic': lambda t: np.exp(-0.5 * np.sin(np.pi * x * t) ** 2),
+    }
+    report = {}
+    for name, top_of in families.items():
+        g = GridOp(1, m, 1)
+        last = {}                       # rank -> last accepted parameter
+        t, seen_reject = 1.0, 0
+        while seen_reject < 2 and t < 1e7:
+            g.set_lmc(top_of(t)[None], [None], [np.ones(1)])
+            r = g.form()[0]
+            if r > 0:
+                last[r] = t
+                seen_reject = 0
+            else:
+                seen_reject += 1        # (one back-off step may follow a rejection)
+            t *= factor
+        assert last, 'no parameter of the %s family was accepted' % name
+        assert set(last) <= {24, 32, 48}, last
+        report[name] = dict(last)
+        for r, tb in sorted(last.items()):
+            top = top_of(tb)
+            g = GridOp(1, m, 1)
+            g.set_lmc(top[None], [None], [np.ones(1)])
+            assert g.form()[0] == r, (name, r, tb, g.form())
+            T = ops.BTTBOracle(top)
+            v = rng.randn(m)
+            for _ in range(8):          # ||T||_2 from below (power iteration)
+                v = T.matvec(v / np.linalg.norm(v))
+            tnorm = np.linalg.norm(v)
+            inputs = [rng.randn(m) for _ in range(2)]
+            inputs += [phi[r + k] for k in range(4) if r + k < len(phi)]
+            inputs += [_lanczos_vector(T.matvec, rng.randn(m), 50)]
+            X = np.array(inputs)
+            got = _poly_product(g, X)
+            for xi, yi in zip(X, got):
+                err = np.linalg.norm(yi - T.matvec(xi)) / (tnorm * np.linalg.norm(xi))
+                assert err < 1e-11, (name, r, tb, err)
+    return report
+
+
 def _poly_product(g, X, top=None):
     """g.matmat_host with the batch gate lifted for this call."""
     g.set_form_gate(0)

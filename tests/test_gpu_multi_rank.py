@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ['--config', 'c2', '--steps', '20', '--warmup', '3', '--no-cpu', '--no-sweep',
-          '--no-extra']
+          '--no-extra', '--no-families']
 
 
 def _free_port():
@@ -56,9 +56,61 @@ def test_bench_two_ranks_one_gpu():
         a, b = j1[key], j2[key]
         assert b['scaling'] == 'strong' and b['probes_per_rank'] == 8
         assert b['n_probes_global'] == a['n_probes_global'] == 16
+        # alpha and the assembled gradient: the same BITS on both ranks (checked inside
+        # the run over the ranks' checksums); against the one-rank run the batching
+        # differs, hence solver-level noise
+        assert b['bits_equal_across_ranks'] == {'alpha': True, 'gradient': True}
         g1, g2 = np.array(a['grad_sample']), np.array(b['grad_sample'])
         assert np.abs(g1 - g2).max() <= 1e-4 * np.abs(g1).max(), (g1, g2)
         assert abs(a['grad_norm'] - b['grad_norm']) <= 1e-4 * a['grad_norm']
+
+
+def test_collectives_through_rccl_in_a_world_of_one():
+    """One rank, process group on backend nccl (= RCCL), collectives forced: the
+    step's alpha broadcast and gradient all-reduce run on RCCL itself on a
+    one-GPU box, and the step's numbers equal the plain one-rank run's bit for
+    bit (a world of one changes no arithmetic)."""
+    env = dict(os.environ, OMP_NUM_THREADS='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()))
+    args = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + COMMON
+    plain = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                           timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    forced = subprocess.run(args + ['--force-dist', '--dist-backend', 'nccl'],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                            timeout=900)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    j0, j1 = _last_json(plain.stdout), _last_json(forced.stdout)
+    assert j1['collectives']['backend'] == 'nccl' and j1['collectives']['forced_in_world_of_one']
+    for key in ('nll_grad', 'nll_grad_eps1'):
+        assert j0[key]['grad_sample'] == j1[key]['grad_sample'], (j0[key], j1[key])
+        assert j0[key]['grad_norm'] == j1[key]['grad_norm']
+
+
+def test_sharded_block_through_rccl_in_a_world_of_one():
+    """Iterative.solve_sharded's all-gather on RCCL with one rank."""
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from runlmc_amd.util import dist as rdist, synth\n"
+        "rdist.force_collectives(True)\n"
+        "from runlmc_amd.lmc.grid_kernel import gen_grid_kernel\n"
+        "from runlmc_amd.approx.iterative import Iterative\n"
+        "p = synth.make_problem(3, 2, 1, 400, eps=1.0)\n"
+        "fk = synth.functional_kernel(p)\n"
+        "K, _ = gen_grid_kernel(fk, {(0,): p.grid_dists}, {(0,): (p.W, p.WT)}, p.lens)\n"
+        "B = np.random.RandomState(0).randn(5, p.n)\n"
+        "a = Iterative.solve_sharded(K, B, tol=1e-4, group=dist.group.WORLD)[0]\n"
+        "b = Iterative.solve(K, B, tol=1e-4)\n"
+        "assert np.array_equal(np.asarray(a), np.asarray(b))\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n") % (ROOT, ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-3000:]
 
 
 def test_bench_refuses_wrong_world_size():

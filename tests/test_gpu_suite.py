@@ -138,5 +138,14 @@ def test_polynomial_form():
     ps.check_polynomial_form()
 
 
+def test_filter_form():
+    ps.check_filter_form()
+
+
+def test_polynomial_gate_boundary():
+    ps.check_polynomial_gate_boundary()
+
+
 def test_polynomial_rounds():
     ps.check_polynomial_rounds()
+
