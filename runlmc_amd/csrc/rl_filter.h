@@ -422,7 +422,7 @@ __device__ __forceinline__ double sf_row_bcast(double v, double* scr) {
 }
 
 // ---------------------------------------------------------------------------
-// k_sf_apply<NS>: Y[v] (+)= filter part of the operator applied to X[v].
+// k_sf_apply<NS>: Y[v] = filter part of the operator applied to X[v].
 //   grid (resident workgroups: each walks tiles (chunk, vector))   block 256
 //   LDS: (D + nfac) RL_SF_PAD doubles of rows + NF sizeof(SfBlk) + (D + nfac) 16
 //        (+ 128 doubles per wave for the emulator's cross-lane moves)
@@ -476,7 +476,9 @@ __host__ __device__ inline int sf_blob_doubles(int NF, int nfac, int D) {
 #endif
 
 // requests a tile's D rows (thread tid: points tid and tid + 256 of row k / 2 in
-// xr[k]; points past the grid are zero) and its incoming states into registers
+// xr[k], from clamped addresses -- points past the grid are zeroed when the registers
+// go to LDS, not here: a select right behind a load makes the compiler wait for it,
+// measured as twelve serial round trips) and its incoming states into registers
 template <int XR>
 __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
                                            const double* __restrict__ X,
@@ -488,8 +490,7 @@ __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
     for (int k = 0; k < XR; ++k) {
         if ((k >> 1) < D) {
             const int gi = g0 + tid + 256 * (k & 1);
-            const double val = xbase[(size_t)(k >> 1) * m + (gi < m ? gi : m - 1)];
-            xr[k] = gi < m ? val : 0.0;
+            xr[k] = xbase[(size_t)(k >> 1) * m + (gi < m ? gi : m - 1)];
         }
     }
     const double* src = Cin + ((size_t)chunk * nvec + v) * ncin;
@@ -500,8 +501,7 @@ __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
 template <int NS, int XR>       // XR >= 2 D: registers that hold the next tile's rows
 __global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
 k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D, int m, int NF,
-           int nfac, const double* __restrict__ blob, const double* __restrict__ Cin,
-           int accumulate) {
+           int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
     constexpr int G = RL_SF_G, PAD = RL_SF_PAD;
     constexpr int BF = NS == 2 ? 8 : 4;                      // filters per batch
     constexpr int NR = 8;                                    // state registers per lane and half
@@ -537,7 +537,9 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D
     // registers -> LDS (the rows padded, see sf_pad), then request the next tile
 #pragma unroll
     for (int k = 0; k < XR; ++k)
-        if ((k >> 1) < D) xs[(size_t)(k >> 1) * PAD + sf_pad(tid + 256 * (k & 1))] = xr[k];
+        if ((k >> 1) < D)
+            xs[(size_t)(k >> 1) * PAD + sf_pad(tid + 256 * (k & 1))] =
+                g0 + tid + 256 * (k & 1) < m ? xr[k] : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < ncin) cinl[tid + 256 * k] = cr[k];
@@ -545,20 +547,23 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D
     if (tile + (int)gridDim.x < ntiles)
         sf_request<XR>(xr, cr, X, Cin, tile + gridDim.x, nch, nvec, D, m, ncin, tid);
     RL_STAMP_AT(101, 100, 0);
-    // mixed rows u_f = sum_b A_f[b] x_b: a wave takes rows f = wave, wave + 4, ..., keeps
-    // the row's D weights in registers and walks the 512 points, 64 at a time
+    // mixed rows u_f = sum_b A_f[b] x_b: a thread takes points tid and tid + 256, the D
+    // values of a point in registers; the weights are uniform (scalar loads from the
+    // operator's block in global memory: no LDS traffic for them)
     if (nfac > 0) {
-        for (int f = wave; f < nfac; f += nwaves) {
-            double af[16];
+        const double* gA = blob + NF * D;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) af[b] = b < D ? facA[f * D + b] : 0.0;
-#pragma unroll 2
-            for (int i = lane; i < G; i += 64) {
-                const int pi = sf_pad(i);
+        for (int half = 0; half < 2; ++half) {
+            const int pi = sf_pad(tid + 256 * half);
+            double xb[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) xb[b] = b < D ? xs[(size_t)b * PAD + pi] : 0.0;
+            for (int f = 0; f < nfac; ++f) {
+                const double* ar = gA + f * D;
                 double u = 0.0;
 #pragma unroll
                 for (int b = 0; b < 16; ++b)
-                    if (b < D) u = fma(af[b], xs[(size_t)b * PAD + pi], u);
+                    if (b < D) u = fma(ar[b], xb[b], u);
                 us[(size_t)f * PAD + pi] = u;
             }
         }
@@ -727,24 +732,30 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D
     RL_STAMP_AT(110, 100, 0);
     sf_lds_barrier();
     RL_STAMP_AT(111, 100, 0);
-    // y_a = diagonal part + sum_f w_f A_f[a] (T u_f), stored coalesced: a wave takes rows
-    // a = wave, wave + 4, ... with the row's nfac weights in registers
-    double* ybase = Y + (size_t)v * D * m;
-    for (int a = wave; a < D; a += nwaves) {
-        double aw[16];
+    // y_a = diagonal part + sum_f w_f A_f[a] (T u_f): a thread takes points tid and
+    // tid + 256, the D results of a point in registers (weights: scalar loads, as
+    // above), all stores of a point issued together
+    {
+        const double* gAW = blob + NF * D + nfac * D;
+        double* ybase = Y + (size_t)v * D * m + g0;
 #pragma unroll
-        for (int f = 0; f < 16; ++f) aw[f] = f < nfac ? facAW[f * D + a] : 0.0;
-        double* yrow = ybase + (size_t)a * m + g0;
-#pragma unroll 2
-        for (int i = lane; i < G; i += 64) {
-            const int pi = sf_pad(i);
-            const bool live = g0 + i < m;
-            double y = xs[(size_t)a * PAD + pi];
-            if (accumulate) y += yrow[live ? i : 0];
+        for (int half = 0; half < 2; ++half) {
+            const int i = tid + 256 * half, pi = sf_pad(i);
+            double acc[16];
 #pragma unroll
-            for (int f = 0; f < 16; ++f)
-                if (f < nfac) y = fma(aw[f], us[(size_t)f * PAD + pi], y);
-            if (live) yrow[i] = y;
+            for (int a = 0; a < 16; ++a) acc[a] = a < D ? xs[(size_t)a * PAD + pi] : 0.0;
+            for (int f = 0; f < nfac; ++f) {
+                const double* ar = gAW + f * D;
+                const double uw = us[(size_t)f * PAD + pi];
+#pragma unroll
+                for (int a = 0; a < 16; ++a)
+                    if (a < D) acc[a] = fma(ar[a], uw, acc[a]);
+            }
+            if (g0 + i < m) {
+#pragma unroll
+                for (int a = 0; a < 16; ++a)
+                    if (a < D) ybase[(size_t)a * m + i] = acc[a];
+            }
         }
     }
     RL_STAMP_AT(112, 100, 0);

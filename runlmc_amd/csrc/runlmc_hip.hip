@@ -73,6 +73,69 @@ static bool first_on_device(unsigned long long* seen) {
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Environment switches.  Read ONCE, when a handle is created, into the handle:
+// nothing a product or a solve does afterwards depends on the environment.
+// What is left are (a) switches that turn a form or a fused path off for A/B
+// measurements, (b) hooks the tests use to reach, at small sizes, the code paths
+// that sizes select in production (chunked products, staged SpMVs, long-system
+// loops).  Kernel-tuning knobs of earlier rounds (tile sizes, thread counts,
+// stream counts, the round-1 kernels) are gone with the measurements that settled
+// them.
+// ---------------------------------------------------------------------------
+struct RlKnobs {
+    bool pow2_only = false;      // RUNLMC_POW2_ONLY: the reference's embedding length
+    int chunk_mb = 0;            // RUNLMC_CHUNK_MB: intermediates per chunk of a batched product
+    int two_streams = -1;        // RUNLMC_TWO_STREAMS=0/1 (default: by size)
+    bool no_v1p = false;         // RUNLMC_NO_V1P: never the single-tile product
+    int v1p_min = 0;             // RUNLMC_V1P_MIN
+    bool no_lowrank = false;     // RUNLMC_NO_LOWRANK: no polynomial-subspace form
+    bool no_filter = false;      // RUNLMC_NO_FILTER: no recursive-filter form
+    bool poly_round = false;     // RUNLMC_POLY_ROUND: polynomial rounds also on grids of 96..2047 points
+    bool no_poly_round = false;  // RUNLMC_NO_POLY_ROUND
+    long long lr_min = -1;       // RUNLMC_LR_MIN: batch gate of the structured forms
+    bool staged_wt = false;      // RUNLMC_STAGED_WT: LDS-staged SpMVs whatever the size
+    bool no_staged_wt = false;   // RUNLMC_NO_STAGED_WT
+    bool no_sort = false;        // RUNLMC_NO_SORT: caller's data order inside the SKI handle
+    long long ws_cache_mb = -1;  // RUNLMC_WS_CACHE_MB
+    int solver_maxblk = 0;       // RUNLMC_SOLVER_MAXBLK
+    bool no_fuse_w = false;      // RUNLMC_NO_FUSE_W
+    bool no_fuse_wt = false;     // RUNLMC_NO_FUSE_WT
+    bool no_graph = false;       // RUNLMC_NO_GRAPH: solver rounds launched eagerly
+    bool minres_v1 = false;      // RUNLMC_MINRES_V1 (emulator build only: the four-kernel
+                                 // iteration the tests hold the two-kernel rounds against)
+};
+static RlKnobs read_knobs() {
+    RlKnobs k;
+    auto flag = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, long long dflt) {
+        const char* e = getenv(n);
+        return e ? atoll(e) : dflt;
+    };
+    k.pow2_only = flag("RUNLMC_POW2_ONLY");
+    k.chunk_mb = (int)num("RUNLMC_CHUNK_MB", 0);
+    k.two_streams = (int)num("RUNLMC_TWO_STREAMS", -1);
+    k.no_v1p = flag("RUNLMC_NO_V1P");
+    k.v1p_min = (int)num("RUNLMC_V1P_MIN", 0);
+    k.no_lowrank = flag("RUNLMC_NO_LOWRANK");
+    k.no_filter = flag("RUNLMC_NO_FILTER");
+    k.poly_round = flag("RUNLMC_POLY_ROUND");
+    k.no_poly_round = flag("RUNLMC_NO_POLY_ROUND");
+    k.lr_min = num("RUNLMC_LR_MIN", -1);
+    k.staged_wt = flag("RUNLMC_STAGED_WT");
+    k.no_staged_wt = flag("RUNLMC_NO_STAGED_WT");
+    k.no_sort = flag("RUNLMC_NO_SORT");
+    k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
+    k.solver_maxblk = (int)num("RUNLMC_SOLVER_MAXBLK", 0);
+    k.no_fuse_w = flag("RUNLMC_NO_FUSE_W");
+    k.no_fuse_wt = flag("RUNLMC_NO_FUSE_WT");
+    k.no_graph = flag("RUNLMC_NO_GRAPH");
+#if defined(RL_EMU)
+    k.minres_v1 = flag("RUNLMC_MINRES_V1");
+#endif
+    return k;
+}
+
 static int ilog2(int x) {
     int l = 0;
     while ((1 << l) < x) ++l;
@@ -153,8 +216,7 @@ static int fused_code(const FftPlan& p) {
 // next power of two, bttb.py:16-19).  Split L = N1 * N2 with N2 a power of two
 // (row transforms) and the odd factor in N1.  RUNLMC_POW2_ONLY=1 forces the
 // reference's length.
-static void choose_length(int m, int* L_out, int* N1_out, int* N2_out) {
-    const bool pow2_only = getenv("RUNLMC_POW2_ONLY") != nullptr;
+static void choose_length(int m, bool pow2_only, int* L_out, int* N1_out, int* N2_out) {
     long best = 0;
     int best_odd = 1;
     for (int odd : {1, 3, 5, 9, 15, 25}) {
@@ -180,10 +242,6 @@ static void choose_length(int m, int* L_out, int* N1_out, int* N2_out) {
             if (score < bestScore) { bestScore = score; bestN2 = n2; }
         }
         if (bestN2) N2 = bestN2;
-    }
-    if (const char* e = getenv("RUNLMC_N2")) {      // experiment knob: force the row length
-        const int n2 = atoi(e);
-        if (n2 >= 8 && (n2 & (n2 - 1)) == 0 && L % n2 == 0 && L / n2 >= 4) N2 = n2;
     }
     *L_out = L;
     *N2_out = N2;
@@ -240,6 +298,7 @@ static const size_t kLdsHard = 156 * 1024;   // one workgroup per CU (160 KiB LD
 // grid operator
 // ---------------------------------------------------------------------------
 struct rl_gridop {
+    RlKnobs kn;                 // environment switches as they were when the handle was created
     int device = 0;
     int D = 0, m = 0, L = 0, N1 = 0, N2 = 0;
     Geom geo{0, 0, 0};   // m1 == 0: 1-D grid; else an m1 x m2 grid (2-D BTTB)
@@ -471,7 +530,7 @@ static int launch1p(rl_gridop* g, int D, unsigned pairs, hipStream_t st, const d
 
 #define RL_MAX_D 16
 
-static size_t lr_min_elements();
+static size_t lr_min_elements(const rl_gridop* g);
 static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_tops,
                               rl_gridop** out);
 
@@ -512,6 +571,7 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
 
     rl_gridop* g = new rl_gridop;
     HandleGuard<rl_gridop, rl_gridop_destroy> guard(g);
+    g->kn = read_knobs();
     g->device = device;
     g->D = D;
     g->m = m;
@@ -519,7 +579,7 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     int L;
     g->geo = Geom{m, m1, m2};
     if (m1 == 0) {
-        choose_length(m, &L, &g->N1, &g->N2);
+        choose_length(m, g->kn.pow2_only, &L, &g->N1, &g->N2);
     } else {
         // 2-D: one circulant embedding per axis (reference bttb.py:112: next
         // power of two of twice each size), floored at 4
@@ -572,21 +632,20 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     bool rows_ok = g->code2 == 808 || g->code2 == 816 || g->code2 == 1616;
     // third-generation row kernel wherever its lengths apply and its unpadded
     // tile of one row fits (the spectra are built with the same plan below)
-    if (g->code1 != 0 && getenv("RUNLMC_NO_K3") == nullptr &&
+    if (g->code1 != 0 &&
         (size_t)g->N2 * D * sizeof(cplx) <= kLdsHard && make_plan_rows3(g->N2, &g->plan2)) {
         g->rows3 = true;
         g->code2 = g->plan2.radix[0] * 100 + g->plan2.radix[1];
         rows_ok = true;
     }
-    g->v2 = g->code1 != 0 && rows_ok && getenv("RUNLMC_FORCE_V1") == nullptr;
+    g->v2 = g->code1 != 0 && rows_ok;
     // polynomial-subspace form (rl_lowrank.h): 1-D grids long enough for the
     // three-kernel FFT path, decided per parameter set by verification
     // (short grids only matter to the solver's opt-in polynomial rounds)
-    g->lr_try = m1 == 0 && m >= (getenv("RUNLMC_POLY_ROUND") != nullptr ? 2 * RL_LR_RMAX : 2048) &&
-                getenv("RUNLMC_NO_LOWRANK") == nullptr;
+    g->lr_try = m1 == 0 && m >= (g->kn.poly_round ? 2 * RL_LR_RMAX : 2048) && !g->kn.no_lowrank;
     // recursive-filter form (rl_filter.h): any 1-D grid; decided per top row from the row
-    g->sf_try = m1 == 0 && m >= 64 && getenv("RUNLMC_NO_FILTER") == nullptr;
-    g->lr_min = lr_min_elements();
+    g->sf_try = m1 == 0 && m >= 64 && !g->kn.no_filter;
+    g->lr_min = lr_min_elements(g);
     g->h_freq1 = position_to_freq(g->plan1);
     g->h_freq2 = position_to_freq(g->plan2);
 
@@ -621,10 +680,10 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     // streams then stays inside the Infinity Cache, which serves re-reads at
     // ~7 TB/s against ~5.5 from HBM, tools/mall_probe.py)
     size_t chunk_mb = (size_t)D * L * sizeof(cplx) >= ((size_t)8 << 20) ? 64 : 192;
-    if (const char* e = getenv("RUNLMC_CHUNK_MB")) chunk_mb = std::max(1, atoi(e));
+    if (g->kn.chunk_mb > 0) chunk_mb = (size_t)g->kn.chunk_mb;
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
     // single-tile product for short grids
-    if (m1 == 0 && L <= 2048 && getenv("RUNLMC_NO_V1P") == nullptr) {
+    if (m1 == 0 && L <= 2048 && !g->kn.no_v1p) {
         const size_t lds = ((size_t)L * (D | 1) + L) * sizeof(cplx);
         if (lds <= kLdsHard) {
             g->planL = make_plan(L);
@@ -633,7 +692,7 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
             g->lds1 = lds;
             g->thr1 = (size_t)D * L >= 4096 ? 512 : 256;
             g->v1p = true;
-            if (const char* e = getenv("RUNLMC_V1P_MIN")) g->v1p_min = std::max(1, atoi(e));
+            if (g->kn.v1p_min > 0) g->v1p_min = g->kn.v1p_min;
         }
     }
     *out = guard.release();
@@ -695,7 +754,7 @@ extern "C" int rl_gridop_top_forms(const rl_gridop* gc, int* forms, int* structu
 
 extern "C" int rl_gridop_set_form_gate(rl_gridop* g, long long min_elements) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
-    g->lr_min = min_elements < 0 ? lr_min_elements() : (size_t)min_elements;
+    g->lr_min = min_elements < 0 ? lr_min_elements(g) : (size_t)min_elements;
     return RL_OK;
 }
 
@@ -765,7 +824,7 @@ static int set_factors(rl_gridop* g, const std::vector<double>& A, const std::ve
     // registers -- a third of the table bytes, 100 more multiply-adds and 20 more
     // scalar loads per point: 3.79 vs 2.96 ms per C5 product.  Removed.)
     g->mixtab_ok = false;
-    if (g->rows3 && nfac <= RL_MIXF && getenv("RUNLMC_NO_MIXTAB") == nullptr) {
+    if (g->rows3 && nfac <= RL_MIXF) {
         const size_t rows = (size_t)g->D + nfac;
         if (rows > g->mixtab_rows) {
             if (g->mixtab) RL_HIP(hipFree(g->mixtab));
@@ -962,8 +1021,7 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
     // 512 threads when LDS leaves room for only one or two workgroups per CU
     // (big tiles: otherwise a CU would hold 4-8 waves) and the first pass has
     // that many butterflies to hand out; measured on C5: 4.31 -> 3.89 ms
-    int thr_max = RL_THREADS2;
-    if (const char* e = getenv("RUNLMC_MAX_THREADS")) thr_max = std::max(256, atoi(e));
+    const int thr_max = RL_THREADS2;
     const size_t big = 48 * 1024;
     tp->thrR = (lds(R) > big && R * g->D * sub >= 512 && thr_max >= 512) ? 512 : RL_THREADS;
     tp->thrC = ((size_t)g->N1 * C * sizeof(cplx) > big &&
@@ -973,7 +1031,7 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
     // smaller tiles spread the same work over more, narrower workgroups
     // (measured at C2, 17 vectors: 26.1 -> 23.7 us per product; 64 vectors are
     // already past the point where it helps)
-    if (getenv("RUNLMC_NO_SMALL_TILES") == nullptr) {
+    {
         bool shrunk = false;
         while (R > 1 && (size_t)(g->N1 / R) * pairs < 512) {
             R /= 2;
@@ -1004,12 +1062,7 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
         while (g->N1 % (R * 2) == 0 && lds3(2 * R) <= 40 * 1024 &&
                (size_t)(g->N1 / (2 * R)) * pairs >= 2048)
             R *= 2;
-        if (getenv("RUNLMC_NO_SMALL_TILES") == nullptr)
-            while (R > 1 && (size_t)(g->N1 / R) * pairs < 512) R /= 2;
-        if (const char* e = getenv("RUNLMC_TILE_R")) {
-            const int r = atoi(e);
-            if (r >= 1 && g->N1 % r == 0 && lds3(r) <= kLdsHard) R = r;
-        }
+        while (R > 1 && (size_t)(g->N1 / R) * pairs < 512) R /= 2;
         tp->R = R;
         tp->colsMagic = div_magic((unsigned)(R * g->D));
         // workgroup size: the multiple of 64 that needs the fewest rounds over the
@@ -1033,26 +1086,6 @@ static void choose_tiles(const rl_gridop* g, size_t pairs, Tile2* tp) {
         }
         tp->thrR = bestT;
     }
-    // experiment knobs (tile sweeps on the GPU box)
-    if (const char* e = getenv("RUNLMC_TILE_C")) {
-        const int c = atoi(e);
-        if (c >= 1 && c <= g->N2 && (c & (c - 1)) == 0 &&
-            (size_t)g->N1 * c * sizeof(cplx) <= kLdsHard) {
-            C = c;
-            tp->C = C;
-            tp->logC = ilog2(C);
-        }
-    }
-    if (const char* e = g->rows3 ? nullptr : getenv("RUNLMC_TILE_R")) {
-        const int r = atoi(e);
-        if (r >= 1 && g->N1 % r == 0 && lds(r) <= kLdsHard) {
-            R = r;
-            tp->R = R;
-            tp->colsMagic = div_magic((unsigned)(R * g->D));
-        }
-    }
-    if (const char* e = getenv("RUNLMC_THR_C")) tp->thrC = std::min(RL_THREADS2, std::max(64, atoi(e)));
-    if (const char* e = getenv("RUNLMC_THR_R")) tp->thrR = std::min(RL_THREADS2, std::max(64, atoi(e)));
 }
 
 template <int RA, int RB>
@@ -1194,14 +1227,8 @@ static int mvm_chunk_v1(rl_gridop* g, const MixParams& mp, const double* Xc, dou
 }
 
 // second chunk of intermediates + side stream of the two-stream batched product
-// streams a chunked product runs on (RUNLMC_STREAMS, 1..4; default 2)
-static int product_streams() {
-    static const int n = [] {
-        const char* e = getenv("RUNLMC_STREAMS");
-        return e ? std::min(4, std::max(1, atoi(e))) : 2;
-    }();
-    return n;
-}
+// streams a chunked product runs on (measured at C5: three / four equal or worse)
+static int product_streams() { return 2; }
 static int prepare_two_streams(rl_gridop* g, size_t chunk) {
     const int want = product_streams() - 1;
     if (g->T2_pairs < chunk || g->nside < want) {
@@ -1224,10 +1251,8 @@ static int prepare_two_streams(rl_gridop* g, size_t chunk) {
     return RL_OK;
 }
 static bool wants_two_streams(const rl_gridop* g) {
-    if (product_streams() < 2) return false;
-    const char* two_env = getenv("RUNLMC_TWO_STREAMS");
-    return two_env ? atoi(two_env) != 0
-                   : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
+    return g->kn.two_streams >= 0 ? g->kn.two_streams != 0
+                                  : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
 }
 
 
@@ -1332,12 +1357,8 @@ static int lr_reserve(rl_gridop* g, int nvec) {
 // vectors (0.64 M elements: 28 us each; 17 vectors 28 vs 19 us, 64 vectors 30 vs
 // 33 us, 256 vectors 39 vs 83 us), at the C5 grid a two-vector batch (2 M elements)
 // already takes 37 against 60 us.  RUNLMC_LR_MIN / rl_gridop_set_form_gate override.
-static size_t lr_min_elements() {
-    static const size_t v = [] {
-        const char* e = getenv("RUNLMC_LR_MIN");
-        return e ? (size_t)atoll(e) : (size_t)1 << 20;
-    }();
-    return v;
+static size_t lr_min_elements(const rl_gridop* g) {
+    return g->kn.lr_min >= 0 ? (size_t)g->kn.lr_min : (size_t)1 << 20;
 }
 
 // launches the projection, returns the number of chunks (partial sums per row)
@@ -1569,10 +1590,10 @@ static size_t sf_apply_lds(int D, int nfac, int NF, int nthr) {
     return b;
 }
 
-// Y (+)= [filter part] X: carries -> scan -> apply
+// Y = [filter part] X: carries -> scan -> apply
 template <int NS>
 static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const double* X,
-                      double* Y, int nvec, int accumulate, hipStream_t st) {
+                      double* Y, int nvec, hipStream_t st) {
     const int D = g->D, nrows = nvec * D, nch = sf_nchunks(g);
     // rows per carries workgroup: the filter powers are staged once per workgroup
     const int rpw = nrows >= 16 * 64 ? 64 : 16;
@@ -1596,7 +1617,7 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
 #define RL_SF_APPLY(XR_)                                                                     \
     RL_LAUNCH((k_sf_apply<NS, XR_>), dim3(std::min(ntiles, resident)), dim3(64 * waves),        \
               sf_apply_lds(D, sp.nfac, sp.NF, 64 * waves), st, X, Y, nvec, D, g->m, sp.NF,      \
-              sp.nfac, blob, (const double*)g->sf_Cin, accumulate)
+              sp.nfac, blob, (const double*)g->sf_Cin)
     if (D <= 4) RL_SF_APPLY(8);
     else if (D <= 8) RL_SF_APPLY(16);
     else if (D <= 12) RL_SF_APPLY(24);
@@ -1605,12 +1626,11 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
 }
 
 // the operator's filter part (every filter top with its couplings)
-static int sf_apply_all(rl_gridop* g, const double* X, double* Y, int nvec, int accumulate,
-                        hipStream_t st) {
+static int sf_apply_all(rl_gridop* g, const double* X, double* Y, int nvec, hipStream_t st) {
     SfParams sp{g->sf_n, g->sf_nfac, g->sf_tops, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW,
                 g->sf_facJ};
-    if (g->sf_ns == 3) sf_launch<3>(g, sp, g->sf_blob, X, Y, nvec, accumulate, st);
-    else sf_launch<2>(g, sp, g->sf_blob, X, Y, nvec, accumulate, st);
+    if (g->sf_ns == 3) sf_launch<3>(g, sp, g->sf_blob, X, Y, nvec, st);
+    else sf_launch<2>(g, sp, g->sf_blob, X, Y, nvec, st);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -1620,8 +1640,8 @@ static int sf_apply_top(rl_gridop* g, int q, const double* X, double* Y, int nve
     SfParams sp{1, 0, g->sf_tops + j, g->sf_pw + (size_t)j * (RL_SF_G + 1), g->ones, nullptr,
                 nullptr, nullptr};
     const double* blob = g->sf_blob_top + (size_t)j * sf_blob_doubles(1, 0, g->D);
-    if (g->sf_top_ns[q] == 3) sf_launch<3>(g, sp, blob, X, Y, nvec, 0, st);
-    else sf_launch<2>(g, sp, blob, X, Y, nvec, 0, st);
+    if (g->sf_top_ns[q] == 3) sf_launch<3>(g, sp, blob, X, Y, nvec, st);
+    else sf_launch<2>(g, sp, blob, X, Y, nvec, st);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -1976,7 +1996,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         if (nfilt == 0) {
             RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
             g->lr_ok = true;
-            if (r == RL_LR_RS && getenv("RUNLMC_NO_POLY_ROUND") == nullptr) {
+            if (r == RL_LR_RS && !g->kn.no_poly_round) {
                 // the whole coefficient map of the solver's polynomial rounds
                 //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
                 std::vector<double> hnu(RL_LR_RMAX);
@@ -2089,7 +2109,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
                 return sf_apply_top(g, q1, X, Y, nvec, stream);
             }
             trace_once("grid product: recursive-filter part + polynomial part");
-            RL_TRY(sf_apply_all(g, X, Y, nvec, 0, stream));
+            RL_TRY(sf_apply_all(g, X, Y, nvec, stream));
             if (g->lr_np > 0) RL_TRY(lr_apply_compact(g, X, Y, nvec, stream));
             return RL_OK;
         }
@@ -2241,6 +2261,7 @@ struct SolverWork {
 };
 
 struct rl_ski {
+    RlKnobs kn;         // environment switches as they were when the handle was created
     // Lanczos coefficients of a solve: kept between calls (a hipMalloc / hipFree
     // pair per solve costs ~200 us, as much as four C2 solver rounds)
     double* lanczos_buf = nullptr;
@@ -2297,11 +2318,9 @@ static void launch_spmv(const int* indptr, const int* indices, const double* val
                         const double* X2, hipStream_t st, int accumulate = 0,
                         int* bump = nullptr, int avg_nnz = 0) {
     const unsigned gx = (nrows + RL_THREADS - 1) / RL_THREADS;
-    static const int force_vb = getenv("RUNLMC_SPMV_VB") ? atoi(getenv("RUNLMC_SPMV_VB")) : 0;
-    const bool blocked = force_vb ? force_vb > 1 : (size_t)nrows * nvec >= ((size_t)1 << 22);
+    const bool blocked = (size_t)nrows * nvec >= ((size_t)1 << 22);
     // long rows of a small product: eight lanes per row (k_spmv_wide)
-    if (!blocked && avg_nnz > 12 && diag == nullptr && !accumulate &&
-        getenv("RUNLMC_NO_WIDE_SPMV") == nullptr) {
+    if (!blocked && avg_nnz > 12 && diag == nullptr && !accumulate) {
         const unsigned gw = (unsigned)(((size_t)nrows * 8 + RL_THREADS - 1) / RL_THREADS);
         RL_LAUNCH(k_spmv_wide<8>, dim3(gw, nvec), dim3(RL_THREADS), RL_THREADS * sizeof(double), st,
                   indptr, indices, vals, nrows, ncols, X, Y, bump);
@@ -2379,7 +2398,7 @@ static int upload_term(SkiTerm* t, int n, int ngrid, const int* W_indptr, const 
     std::vector<int> base, lo, sp_ptr, sp_idx;
     std::vector<double> w4, sp_val;
     {
-        bool ok = ngrid >= 4 && getenv("RUNLMC_NO_ELL") == nullptr;
+        bool ok = ngrid >= 4;
         base.resize(n);
         w4.assign((size_t)4 * n, 0.0);
         int prev = 0;
@@ -2452,6 +2471,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     RL_HIP(hipSetDevice(g->device));
     rl_ski* s = new rl_ski;
     HandleGuard<rl_ski, rl_ski_destroy> guard(s);
+    s->kn = read_knobs();
     s->g = g;
     s->device = g->device;
     s->n = n;
@@ -2465,7 +2485,7 @@ extern "C" int rl_ski_create(rl_gridop* g, int n, const int* W_indptr, const int
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key(a) < key(b); });
     bool identity = true;
     for (int i = 0; i < n && identity; ++i) identity = perm[i] == i;
-    if (getenv("RUNLMC_NO_SORT")) identity = true;
+    if (s->kn.no_sort) identity = true;
     if (!identity) {
         s->permuted = true;
         s->h_perm = perm;
@@ -2613,14 +2633,8 @@ static void permute_rows(rl_ski* s, const double* X, double* Y, int nvec, int sc
 }
 
 // groups of 8 vectors a staged-SpMV workgroup walks with the same rows
-// (RUNLMC_STAGED_GROUPS; measured at C5: DESIGN.md)
-static int staged_vgroups() {
-    static const int v = [] {
-        const char* e = getenv("RUNLMC_STAGED_GROUPS");
-        return e ? std::max(1, atoi(e)) : 4;
-    }();
-    return v;
-}
+// (measured at C5: DESIGN.md)
+static int staged_vgroups() { return 4; }
 
 // the three stages in INTERNAL row order
 static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStream_t st,
@@ -2631,8 +2645,7 @@ static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStrea
     const size_t lds = ((size_t)VB * s->wt_xmax + s->wt_emax) * sizeof(double);
     if (s->WT_lo != nullptr && s->wt_xmax > 0 && lds <= 64 * 1024 &&
         s->wt_xmax <= 4 * RL_THREADS &&
-        ((size_t)s->ngrid * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
-        getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
+        ((size_t)s->ngrid * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) && !s->kn.no_staged_wt) {
         trace_once("W^T product: k_spmv_wt_staged");
         static unsigned long long seen = 0;
         if (first_on_device(&seen)) {
@@ -2669,8 +2682,7 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
     const size_t lds = (size_t)VB * s->w_xmax * sizeof(double);
     if (s->W4_base != nullptr && s->w_xmax > 0 && lds <= 64 * 1024 &&
         s->w_xmax <= 4 * RL_THREADS &&
-        ((size_t)s->n * nvec >= ((size_t)1 << 22) || getenv("RUNLMC_STAGED_WT") != nullptr) &&
-        getenv("RUNLMC_NO_STAGED_WT") == nullptr) {
+        ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) && !s->kn.no_staged_wt) {
         trace_once("W product: k_spmv_w_staged");
         static unsigned long long seen = 0;
         if (first_on_device(&seen)) {
@@ -2812,9 +2824,8 @@ static void free_work(SolverWork& w) {
     w.I = nullptr; w.count = nullptr; w.resid = nullptr; w.lanczos = nullptr;
 }
 
-static size_t ws_cache_limit() {
-    size_t mb = 16384;
-    if (const char* e = getenv("RUNLMC_WS_CACHE_MB")) mb = (size_t)std::max(0LL, atoll(e));
+static size_t ws_cache_limit(const rl_ski* s) {
+    const size_t mb = s->kn.ws_cache_mb >= 0 ? (size_t)s->kn.ws_cache_mb : 16384;
     return mb << 20;
 }
 
@@ -2834,7 +2845,7 @@ struct SolverWorkGuard {
         size_t nv = 0;
         for (double* p : w->vec) nv += p != nullptr;
         const size_t bytes = nv * s->ws_vec_cap * sizeof(double);
-        if (w->I != nullptr && !s->ws_valid && bytes <= ws_cache_limit()) {
+        if (w->I != nullptr && !s->ws_valid && bytes <= ws_cache_limit(s)) {
             s->ws = *w;
             s->ws_valid = true;
         } else {
@@ -2928,7 +2939,7 @@ static int poly_round_prepare(rl_ski* s, int nrhs, int max_blk, bool* ok) {
     *ok = false;
     rl_gridop* g = s->g;
     if (!s->extra.empty() || s->W4_base == nullptr || s->h_base.empty() ||
-        !g->lr_try || s->poly_nblk < 0 || getenv("RUNLMC_NO_POLY_ROUND") != nullptr)
+        !g->lr_try || s->poly_nblk < 0 || s->kn.no_poly_round || g->kn.no_poly_round)
         return RL_OK;
     if (s->poly_nblk == 0) {
         const int D = g->D, m = g->m, n = s->n;
@@ -3091,19 +3102,17 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     const int n = s->n;
     if (maxiter <= 0) maxiter = n;
     const double rtol = tol < 1e-10 ? tol : 1e-10;
-    int rows_per_blk = 1024;
-    if (const char* e = getenv("RUNLMC_SOLVER_ROWS")) rows_per_blk = std::max(64, atoi(e));
+    const int rows_per_blk = 1024;       // (512 / 320 / 256 measured slower at C2)
     int nblk = (n + rows_per_blk - 1) / rows_per_blk;
     int max_blk = 64;       // <= RL_SOLVER_THREADS: the partial sums are read one per thread
-    if (const char* e = getenv("RUNLMC_SOLVER_MAXBLK"))
-        max_blk = std::max(1, std::min(atoi(e), RL_SOLVER_THREADS));
+    if (s->kn.solver_maxblk > 0) max_blk = std::max(1, std::min(s->kn.solver_maxblk, RL_SOLVER_THREADS));
     nblk = std::max(1, std::min(nblk, max_blk));
     // small single-term MINRES solves of a smooth kernel: polynomial rounds, whose
     // row blocks follow the outputs (every other kernel of the solve takes the same
     // NUMBER of blocks; its partial sums do not care where the block borders are)
     bool poly_round = false;
-    if (method == RL_MINRES && getenv("RUNLMC_MINRES_V1") == nullptr &&
-        (size_t)n * nrhs < ((size_t)1 << 22) && getenv("RUNLMC_NO_FUSE_W") == nullptr)
+    if (method == RL_MINRES && !s->kn.minres_v1 &&
+        (size_t)n * nrhs < ((size_t)1 << 22) && !s->kn.no_fuse_w)
         RL_TRY(poly_round_prepare(s, nrhs, max_blk, &poly_round));
     if (poly_round) nblk = s->poly_nblk;
     dim3 grid(nblk, nrhs), blk(RL_SOLVER_THREADS);
@@ -3116,14 +3125,14 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         for (int d = 1; d <= 10; ++d)
             if (check_every % d == 0) per_graph = d;
     }
-    const bool use_graph = getenv("RUNLMC_NO_GRAPH") == nullptr;
+    const bool use_graph = !s->kn.no_graph;
 
     SolverWork w;
     SolverWorkGuard guard(s, &w);
     // (vec[5]: v of the four-kernel MINRES only; vec[8], vec[9]: right-hand sides
     // and solutions in the handle's internal row order)
     unsigned need = method == RL_MINRES ? 0x5bu : 0x0fu;      // two-kernel MINRES: 0, 1, 3, 4, 6
-    if (method == RL_MINRES && getenv("RUNLMC_MINRES_V1") != nullptr) need = 0x7fu;
+    if (method == RL_MINRES && s->kn.minres_v1) need = 0x7fu;
     if (s->permuted) need |= 0x300u;
     RL_TRY(solver_alloc(s, w, need, nrhs, n, nblk, st));
     // everything the operator product allocates lazily must exist before capture
@@ -3147,7 +3156,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         Xi = w.vec[9];
     }
     RL_LAUNCH(k_dot_partial, grid, blk, red, st, Bi, Bi, n, w.part[0]);
-    if (method == RL_MINRES && getenv("RUNLMC_MINRES_V1") == nullptr) {
+    if (method == RL_MINRES && !s->kn.minres_v1) {
         // two vector kernels per round (rl_solver.h: Minres2Bufs)
         Minres2Bufs mb;
         mb.tri[0] = w.vec[0]; mb.tri[1] = w.vec[1];
@@ -3165,7 +3174,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         // the W product rides inside P when the problem is small enough to be
         // launch-bound (a big one amortises the CSR over 8 vectors in k_spmv<8>)
         const bool fuse_w = s->extra.empty() && (size_t)n * nrhs < ((size_t)1 << 22) &&
-                            getenv("RUNLMC_NO_FUSE_W") == nullptr;
+                            !s->kn.no_fuse_w;
         mb.W_indptr = fuse_w ? s->W_indptr : nullptr;
         // ... and W^T inside the first grid kernel when that is a k2_cols_fwd and
         // the batch is one chunk (the operator input is then the rotating buffer
@@ -3176,7 +3185,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         const bool short_rows = (size_t)s->nnzWT <= (size_t)8 * s->ngrid;
         const bool fuse_wt = fuse_w && short_rows && s->g->Q >= 1 &&
                              ((size_t)nrhs + 1) / 2 <= s->g->chunk_pairs &&
-                             getenv("RUNLMC_NO_FUSE_WT") == nullptr;
+                             !s->kn.no_fuse_wt;
         mb.fuse_wt = fuse_wt ? 1 : 0;
         mb.W_indices = s->W_indices;
         mb.W_data = s->W_data;
@@ -3201,8 +3210,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         // single-term operator, W as its own kernel, noise in a few constant runs
         // (one per output): the noise term moves into P
         mb.eps_runs = 0;
-        if (!fuse_w && s->extra.empty() && s->has_noise && !s->eps_end.empty() &&
-            getenv("RUNLMC_NO_LATE_NOISE") == nullptr) {
+        if (!fuse_w && s->extra.empty() && s->has_noise && !s->eps_end.empty()) {
             mb.eps_runs = (int)s->eps_end.size();
             for (int k = 0; k < mb.eps_runs; ++k) {
                 mb.eps_end[k] = s->eps_end[k];
@@ -3255,14 +3263,23 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         // count of a replay before it launches the next one: the count of replay j
         // is read while replay j + 1 runs (one replay of no-ops at the end of a
         // solve against a host round trip per replay).
-        const bool lagged = guard.exec != nullptr && mb.poly_part != nullptr &&
-                            getenv("RUNLMC_NO_LAGGED_COUNT") == nullptr;
+        const bool lagged = guard.exec != nullptr && mb.poly_part != nullptr;
         if (lagged && !s->pin_count) {
             RL_HIP(hipHostMalloc((void**)&s->pin_count, 2 * sizeof(int), hipHostMallocDefault));
             for (hipEvent_t& e : s->count_ev)
                 RL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         bool pending[2] = {false, false};
+        // (whatever way this block is left -- loop exit or an error return --, no copy
+        // into the handle's pinned words stays in flight)
+        struct Drain {
+            hipEvent_t* ev;
+            bool* pending;
+            ~Drain() {
+                for (int i = 0; i < 2; ++i)
+                    if (pending[i]) (void)hipEventSynchronize(ev[i]);
+            }
+        } drain{s->count_ev, pending};
         int slot = 0;
         while (done <= maxiter && active > 0) {
             if (guard.exec) {

@@ -661,11 +661,11 @@ def check_solver_fusions():
     p.noise = p.noise + 0.5                      # well conditioned: converges
     fk = synth.functional_kernel(p)
     ad = (0,)
-    K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
-    op = K.device_operator()
-    assert op.grids[0].N2 >= 64                  # k2_* kernels
     rng = np.random.RandomState(0)
     B = np.vstack([p.y, rng.randint(0, 2, (2, p.n)) * 2.0 - 1])
+    # (the switches are read when a handle is created: one operator per mode.  The
+    # four-kernel iteration exists in the emulator build only; the product build
+    # ignores its switch and runs the two-kernel rounds there as well.)
     knobs = ('RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_MINRES_V1', 'RUNLMC_SOLVER_MAXBLK')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     res = {}
@@ -679,6 +679,9 @@ def check_solver_fusions():
             for k in knobs:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+            op = K.device_operator()
+            assert op.grids[0].N2 >= 64                  # k2_* kernels
             X, it, rs, st = solve_batch(op, torch.from_numpy(B).to(op.device), tol=1e-4)[:4]
             res[mode] = (X.cpu().numpy(), np.array(it), np.array(rs), np.array(st))
     finally:

@@ -152,18 +152,9 @@ def test_full_size_solve_properties(native):
     assert np.allclose(rs, true_res, rtol=1e-6, atol=1e-9)
     X2, it2, rs2, st2 = solve_batch(op, B, tol=1e-4)[:4]
     assert torch.equal(X, X2) and np.array_equal(it, it2) and np.array_equal(st, st2)
-    os.environ['RUNLMC_MINRES_V1'] = '1'
-    try:
-        X1, it1, rs1, st1 = solve_batch(op, B, tol=1e-4)[:4]
-    finally:
-        del os.environ['RUNLMC_MINRES_V1']
     # the synthetic RBF system is ill-conditioned (SciPy's own tests stop MINRES
-    # early): the two arrangements stop within a few
-    # iterations of each other, with the same exit reasons and residual level
-    assert np.all(np.abs(it - it1) <= 10) and np.array_equal(st, st1)
-    # (the residual at a stagnated MINRES iterate moves by a small factor from
-    # one iteration to the next: same level, not the same number)
-    assert rs.max() < 0.3 and rs1.max() < 0.3
+    # early): a stagnated iterate, residual well below ||b||
+    assert rs.max() < 0.3
 
     svc = StochasticDerivService(None, None, npr, 1e-4)
     lik = ApproxLMCLikelihood(fk, K, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.Ys, svc,
