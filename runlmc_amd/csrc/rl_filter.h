@@ -340,12 +340,6 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
 // row shifts; emulator (one fiber per lane, no cross-lane hardware): the same
 // data movement through an LDS scratch of 128 doubles per wave.
 // ---------------------------------------------------------------------------
-#if defined(RL_EMU)
-typedef double sf_v4d __attribute__((vector_size(32)));
-#else
-typedef double sf_v4d __attribute__((ext_vector_type(4)));
-#endif
-
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the
 // vector-memory counter, i.e. waits for the next tile's rows that k_sf_apply has in
 // flight (measured: 7 us per tile at the first barrier after the request).  Every
@@ -358,27 +352,6 @@ __device__ __forceinline__ void sf_lds_barrier() {
 #endif
 }
 
-// D (16 x 16) += A (16 x 4) B (4 x 16), v_mfma_f64_16x16x4_f64: a lane holds
-// A[lane & 15][lane >> 4], B[lane >> 4][lane & 15] and, in d[r], D[(lane >> 4) + 4 r][lane & 15].
-__device__ __forceinline__ void sf_mma(double a, double b, sf_v4d& d, double* scr) {
-#if defined(RL_EMU)
-    const int tid = threadIdx.x, lane = tid & 63;
-    double* w = scr + (size_t)(tid >> 6) * 128;
-    w[lane] = a;
-    w[64 + lane] = b;
-    __syncthreads();
-    for (int r = 0; r < 4; ++r) {
-        const int row = (lane >> 4) + 4 * r, col = lane & 15;
-        double acc = d[r];
-        for (int k = 0; k < 4; ++k) acc += w[row + 16 * k] * w[64 + col + 16 * k];
-        d[r] = acc;
-    }
-    __syncthreads();
-#else
-    (void)scr;
-    d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, d, 0, 0, 0);
-#endif
-}
 // value of lane (lane - N) (UP) or (lane + N) of the same 16-lane row, zero beyond it
 template <int N, bool UP>
 __device__ __forceinline__ double sf_row_shift(double v, double* scr) {
@@ -498,11 +471,13 @@ __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
     for (int k = 0; k < 4; ++k) cr[k] = src[tid + 256 * k < ncin ? tid + 256 * k : ncin - 1];
 }
 
-template <int NS, int XR>       // XR >= 2 D: registers that hold the next tile's rows
+template <int NS, int D>        // (D at compile time: the row loops, the 2 D registers that
+                                // hold the next tile's rows and their predicates are static --
+                                // with a runtime D the kernel spilled 128 scalar registers)
 __global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
-k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D, int m, int NF,
+k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m, int NF,
            int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
-    constexpr int G = RL_SF_G, PAD = RL_SF_PAD;
+    constexpr int G = RL_SF_G, PAD = RL_SF_PAD, XR = 2 * D;
     constexpr int BF = NS == 2 ? 8 : 4;                      // filters per batch
     constexpr int NR = 8;                                    // state registers per lane and half
     RL_SMEM(smem);
@@ -544,31 +519,37 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < ncin) cinl[tid + 256 * k] = cr[k];
     sf_lds_barrier();
-    if (tile + (int)gridDim.x < ntiles)
-        sf_request<XR>(xr, cr, X, Cin, tile + gridDim.x, nch, nvec, D, m, ncin, tid);
     RL_STAMP_AT(101, 100, 0);
     // mixed rows u_f = sum_b A_f[b] x_b: a thread takes points tid and tid + 256, the D
-    // values of a point in registers; the weights are uniform (scalar loads from the
-    // operator's block in global memory: no LDS traffic for them)
+    // values of a point in registers; the weights are broadcast reads of the block in LDS
+    // (scalar loads from global memory measured slower: 4.8 against 2.8 us per tile)
     if (nfac > 0) {
-        const double* gA = blob + NF * D;
+        const double* gA = facA;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int pi = sf_pad(tid + 256 * half);
+            // (rows beyond D: unconditional reads of a clamped row, zero weight -- a
+            // branch around a read makes the compiler wait for every read in turn,
+            // measured 5 us per tile)
             double xb[16];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) xb[b] = b < D ? xs[(size_t)b * PAD + pi] : 0.0;
+            for (int b = 0; b < 16; ++b) xb[b] = xs[(size_t)(b < D ? b : D - 1) * PAD + pi];
             for (int f = 0; f < nfac; ++f) {
                 const double* ar = gA + f * D;
                 double u = 0.0;
 #pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    if (b < D) u = fma(ar[b], xb[b], u);
+                for (int b = 0; b < 16; ++b) {
+                    const double wgt = ar[b < D ? b : D - 1];
+                    u = fma(b < D ? wgt : 0.0, xb[b], u);
+                }
                 us[(size_t)f * PAD + pi] = u;
             }
         }
         sf_lds_barrier();
     }
+    // the next tile's rows: requested now, they arrive while the matrix cores work
+    if (tile + (int)gridDim.x < ntiles)
+        sf_request<XR>(xr, cr, X, Cin, tile + gridDim.x, nch, nvec, D, m, ncin, tid);
     RL_STAMP_AT(102, 100, 0);
     // row slots, one per wave and pass (idle waves repeat a slot and do not store).  The
     // emulator's cross-lane moves are workgroup barriers, so there the rows of x and the
@@ -733,23 +714,22 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int D
     sf_lds_barrier();
     RL_STAMP_AT(111, 100, 0);
     // y_a = diagonal part + sum_f w_f A_f[a] (T u_f): a thread takes points tid and
-    // tid + 256, the D results of a point in registers (weights: scalar loads, as
-    // above), all stores of a point issued together
+    // tid + 256, the D results of a point in registers, all stores of a point issued
+    // together
     {
-        const double* gAW = blob + NF * D + nfac * D;
+        const double* gAW = facAW;
         double* ybase = Y + (size_t)v * D * m + g0;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int i = tid + 256 * half, pi = sf_pad(i);
             double acc[16];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) acc[a] = a < D ? xs[(size_t)a * PAD + pi] : 0.0;
+            for (int a = 0; a < 16; ++a) acc[a] = xs[(size_t)(a < D ? a : D - 1) * PAD + pi];
             for (int f = 0; f < nfac; ++f) {
                 const double* ar = gAW + f * D;
                 const double uw = us[(size_t)f * PAD + pi];
 #pragma unroll
-                for (int a = 0; a < 16; ++a)
-                    if (a < D) acc[a] = fma(ar[a], uw, acc[a]);
+                for (int a = 0; a < 16; ++a) acc[a] = fma(ar[a < D ? a : D - 1], uw, acc[a]);
             }
             if (g0 + i < m) {
 #pragma unroll

@@ -76,6 +76,13 @@ __device__ __forceinline__ double lr_point(int n, int m) {
 // the `steps` points of each lane (a multiple of RL_LR_T, chosen by the host: long
 // chunks amortise the reduction); the 64 lanes are summed once per chunk
 // through LDS.  x values are requested RL_LR_G(R) lane-steps before their use.
+// (Measured and dropped, round 3: the projection as a tall-skinny product on the fp64
+// matrix cores -- v_mfma_f64_16x16x4_f64, 16 rows x 16 functions per tile, basis tile
+// in LDS, sums never reduced across lanes, 124 VGPRs.  The instruction's A layout puts
+// the 16 ROWS on adjacent lanes and the 4 slots on lane groups, so fragments loaded
+// straight from global memory are 64 separate 8-byte requests per instruction: 0.31 ms
+// against 0.19 ms per C5 projection.  Feeding it needs the LDS transposition of
+// rl_filter.h's tiles, which costs what the matrix cores save here.)
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ void __launch_bounds__(64 * RL_LR_WAVES) RL_LR_PROJECT_ATTR

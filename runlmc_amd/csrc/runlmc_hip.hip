@@ -484,11 +484,14 @@ static void set_lds_attrs() {
     set_lds_attr_rows3<10>(); set_lds_attr_rows3<11>(); set_lds_attr_rows3<12>();
     set_lds_attr_rows3<13>(); set_lds_attr_rows3<14>(); set_lds_attr_rows3<15>();
     set_lds_attr_rows3<16>();
-#define RL_SF_ATTR(NS_, XR_)                                                          \
-    (void)hipFuncSetAttribute((const void*)k_sf_apply<NS_, XR_>,                      \
+#define RL_SF_ATTR(D_)                                                                \
+    (void)hipFuncSetAttribute((const void*)k_sf_apply<2, D_>,                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute((const void*)k_sf_apply<3, D_>,                         \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    RL_SF_ATTR(2, 8); RL_SF_ATTR(2, 16); RL_SF_ATTR(2, 24); RL_SF_ATTR(2, 32);
-    RL_SF_ATTR(3, 8); RL_SF_ATTR(3, 16); RL_SF_ATTR(3, 24); RL_SF_ATTR(3, 32);
+    RL_SF_ATTR(1); RL_SF_ATTR(2); RL_SF_ATTR(3); RL_SF_ATTR(4); RL_SF_ATTR(5); RL_SF_ATTR(6);
+    RL_SF_ATTR(7); RL_SF_ATTR(8); RL_SF_ATTR(9); RL_SF_ATTR(10); RL_SF_ATTR(11); RL_SF_ATTR(12);
+    RL_SF_ATTR(13); RL_SF_ATTR(14); RL_SF_ATTR(15); RL_SF_ATTR(16);
 #undef RL_SF_ATTR
     (void)hipFuncSetAttribute((const void*)k_sf_carries<2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1614,14 +1617,19 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
 #else
     const int ntiles = nch * nvec, resident = 2 * RL_LR_CUS;
 #endif
-#define RL_SF_APPLY(XR_)                                                                     \
-    RL_LAUNCH((k_sf_apply<NS, XR_>), dim3(std::min(ntiles, resident)), dim3(64 * waves),        \
-              sf_apply_lds(D, sp.nfac, sp.NF, 64 * waves), st, X, Y, nvec, D, g->m, sp.NF,      \
-              sp.nfac, blob, (const double*)g->sf_Cin)
-    if (D <= 4) RL_SF_APPLY(8);
-    else if (D <= 8) RL_SF_APPLY(16);
-    else if (D <= 12) RL_SF_APPLY(24);
-    else RL_SF_APPLY(32);
+#define RL_SF_APPLY(D_)                                                                      \
+    case D_:                                                                                    \
+        RL_LAUNCH((k_sf_apply<NS, D_>), dim3(std::min(ntiles, resident)), dim3(64 * waves),     \
+                  sf_apply_lds(D, sp.nfac, sp.NF, 64 * waves), st, X, Y, nvec, g->m, sp.NF,     \
+                  sp.nfac, blob, (const double*)g->sf_Cin);                                     \
+        break
+    switch (D) {
+        RL_SF_APPLY(1); RL_SF_APPLY(2); RL_SF_APPLY(3); RL_SF_APPLY(4);
+        RL_SF_APPLY(5); RL_SF_APPLY(6); RL_SF_APPLY(7); RL_SF_APPLY(8);
+        RL_SF_APPLY(9); RL_SF_APPLY(10); RL_SF_APPLY(11); RL_SF_APPLY(12);
+        RL_SF_APPLY(13); RL_SF_APPLY(14); RL_SF_APPLY(15); RL_SF_APPLY(16);
+        default: break;
+    }
 #undef RL_SF_APPLY
 }
 
@@ -1652,17 +1660,26 @@ static int sf_apply_top(rl_gridop* g, int q, const double* X, double* Y, int nve
 // small kernels of the polynomial verification (everything stays on the device
 // until ONE copy per rank tried brings the verdicts of all tops back)
 //   C[i][j] = (c_ij + c_ji) / 2,  c_ij = nu_i sum_chunks part[chunk][row j][i]
+//   grid (r): workgroup i, thread (j = tid % 64, chunk class tid / 64 of four)
 __global__ void __launch_bounds__(256)
 k_lr_finish_C(const double* __restrict__ part, int nparts, int nrows, int r,
               const double* __restrict__ nu, double* __restrict__ C) {
-    for (int e = threadIdx.x; e < r * r; e += 256) {
-        const int i = e / r, j = e - i * r;
-        double a = 0.0, b = 0.0;
-        for (int c = 0; c < nparts; ++c) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);       // [2][4][64]
+    const int i = blockIdx.x, j = threadIdx.x & 63, cls = threadIdx.x >> 6;
+    double a = 0.0, b = 0.0;
+    if (j < r)
+        for (int c = cls; c < nparts; c += 4) {
             a += part[((size_t)c * nrows + j) * r + i];
             b += part[((size_t)c * nrows + i) * r + j];
         }
-        C[e] = 0.5 * (nu[i] * a + nu[j] * b);
+    red[cls * 64 + j] = a;
+    red[256 + cls * 64 + j] = b;
+    __syncthreads();
+    if (cls == 0 && j < r) {
+        a = (red[j] + red[64 + j]) + (red[128 + j] + red[192 + j]);
+        b = (red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]);
+        C[i * r + j] = 0.5 * (nu[i] * a + nu[j] * b);
     }
 }
 #define RL_LR_NB 64            // workgroups of a comparison
@@ -1796,8 +1813,9 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
                 case 32: nparts = lr_project<32>(g, tphi, nrows, st); break;
                 default: nparts = lr_project<48>(g, tphi, nrows, st); break;
             }
-            RL_LAUNCH(k_lr_finish_C, dim3(1), dim3(256), 0, st, (const double*)g->lr_part, nparts,
-                      nrows, r, (const double*)g->lr_nu, g->lr_C + (size_t)q * r * r);
+            RL_LAUNCH(k_lr_finish_C, dim3(r), dim3(256), 512 * sizeof(double), st,
+                      (const double*)g->lr_part, nparts, nrows, r, (const double*)g->lr_nu,
+                      g->lr_C + (size_t)q * r * r);
             // trial: T_q xr through both forms
             g->lr_bypass = true;
             rc = mvm_with_mix(g, mp, xr, y1, 1, st);
