@@ -399,7 +399,7 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2):
                         residual_max=float(np.max(lik.deriv.residuals)),
                         residual_median=float(np.median(lik.deriv.residuals)),
                         grad_norm=float(np.sqrt(sum(np.sum(np.square(x)) for x in
-                                                    g[0] + g[1] + [np.array(g[2])] + [g[3]]))),
+                                                    g[0] + g[1] + [np.hstack(g[2])] + [g[3]]))),
                         # a few entries, so that runs can be compared with each other
                         grad_sample=[float(v) for v in np.concatenate(
                             [np.ravel(g[3]), np.ravel(g[1][0]), np.ravel(g[0][0])])[:12]])
@@ -407,7 +407,7 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2):
         # the same BITS on every rank?  (64-bit checksums of alpha and of the gradient,
         # max and min over the ranks)
         import torch.distributed as tdist
-        flat = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.array(g[2])] + [g[3]]])
+        flat = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.hstack(g[2])] + [g[3]]])
         sums = torch.stack([lik.deriv.alpha_dev.view(torch.int64).sum(),
                             torch.from_numpy(flat.copy()).view(torch.int64).sum().to(
                                 lik.deriv.alpha_dev.device)])

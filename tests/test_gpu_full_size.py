@@ -281,7 +281,7 @@ def test_c5_gradient_at_fixed_iterations_both_forms(native, c5):
                                   Fixed(X, op.device))
         g = (lik.coreg_vec_gradients(), lik.coreg_diags_gradients(), lik.kernel_gradients(),
              lik.noise_gradient())
-        grads[form] = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.array(g[2])] + [g[3]]])
+        grads[form] = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.hstack(g[2])] + [g[3]]])
         alphas[form] = X[0].cpu().numpy()
     gn = np.linalg.norm(grads['fft'])
     diff = np.linalg.norm(grads['poly'] - grads['fft']) / gn
