@@ -78,6 +78,11 @@ int main(void) {
     rl_gridop* g = NULL;
     CHECK_RL(rl_gridop_create(0, D, M, 1, &g));
     CHECK_RL(rl_gridop_set_lmc(g, 1, top, ranks, a, kappa));
+    /* which form the top row's products take (0 transform kernels, 1 polynomial, 2 filter;
+     * on a grid this short every batch stays on the transform kernels) */
+    int forms[1] = {-1}, structured = -1;
+    CHECK_RL(rl_gridop_top_forms(g, forms, &structured));
+    printf("top-row form %d, structured %d\n", forms[0], structured);
 
     /* data on the grid points: W = identity (CSR), so K~ = K_UU + diag(eps) */
     int indptr[N + 1], indices[N];

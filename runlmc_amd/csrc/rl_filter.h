@@ -294,6 +294,8 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
     double st[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) st[k] = 0.0;
+    // (the chunk states do not depend on the chain: four steps' loads are requested together)
+#pragma unroll 4
     for (int p = p0; p < p1; ++p) {
         const int c = dir == 0 ? p : nchunks - 1 - p;
         double e[NS];
@@ -320,6 +322,7 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
         for (int k = 0; k < NS; ++k) st[k] = e[k];
     }
     // the segment again, from the right state
+#pragma unroll 4
     for (int p = p0; p < p1; ++p) {
         const int c = dir == 0 ? p : nchunks - 1 - p;
         if (live) {
@@ -471,6 +474,23 @@ __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
     for (int k = 0; k < 4; ++k) cr[k] = src[tid + 256 * k < ncin ? tid + 256 * k : ncin - 1];
 }
 
+// A fragment of the states product: state id = 16 mt + col is register R = id / 4 of the
+// lane row id % 4 -> filter fb = id % 4 + 4 (R / (2 NS)) of the batch (j0 + fb, or the one
+// filter jbase of a mixed row), direction (R / NS) % 2, power R % NS; point k = 4 kk + lg
+template <int NS>
+__device__ __forceinline__ double sf_state_weight(const SfBlk* bl, int mt, int kk, int col, int lg,
+                                                  int nfb, int jbase, bool batch) {
+    const int id = 16 * mt + col, R = id >> 2;
+    const int fb = (id & 3) + 4 * (R / (2 * NS)), dir = (R / NS) & 1, ks = R % NS;
+    const bool on = fb < nfb;
+    const int jf = batch ? jbase + (on ? fb : 0) : jbase;
+    const int k = 4 * kk + lg, n = dir == 0 ? 15 - k : k;
+    double w = bl[jf].pw[n];
+    if (ks >= 1) w *= (double)n;
+    if (ks >= 2) w *= (double)n;
+    return on ? w : 0.0;
+}
+
 template <int NS, int D>        // (D at compile time: the row loops, the 2 D registers that
                                 // hold the next tile's rows and their predicates are static --
                                 // with a runtime D the kernel spilled 128 scalar registers)
@@ -479,7 +499,6 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
            int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
     constexpr int G = RL_SF_G, PAD = RL_SF_PAD, XR = 2 * D;
     constexpr int BF = NS == 2 ? 8 : 4;                      // filters per batch
-    constexpr int NR = 8;                                    // state registers per lane and half
     RL_SMEM(smem);
     const int nslots = D + nfac, nchan = D * NF + nfac, nblob = sf_blob_doubles(NF, nfac, D);
     double* xs = reinterpret_cast<double*>(smem);            // [D][PAD]: x, then the rows of y
@@ -498,6 +517,13 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     RL_CENSUS_ENTER(120);
     // the operator's block -> LDS, once per workgroup
     for (int e = tid; e < nblob; e += nthr) tab[e] = blob[e];
+    sf_lds_barrier();
+    double wstx[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            wstx[mt][kk] = sf_state_weight<NS>(bl, mt, kk, col, lg, NF < BF ? NF : BF, 0, true);
     // A workgroup walks tiles (chunk, vector) tile0, tile0 + gridDim.x, ...; the NEXT
     // tile's rows and incoming states are requested into registers before the current
     // tile is worked on, so that the memory round trip hides behind the matrix work.
@@ -587,24 +613,31 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
             const int nfb = nf_slot - j0 < BF ? nf_slot - j0 : BF;
             const bool two = nfb > 4 || NS == 3;             // second tile of states in use
             // --- S = Wst X.  A fragment: state id = 16 mt + col -> lane row id % 4, register id / 4
+            // (rows of x with all their filters in one batch: the weights do not depend on
+            // the row and were computed once, before the first tile)
             sf_v4d S[2][2];
             S[0][0] = S[0][1] = S[1][0] = S[1][1] = sf_v4d{0.0, 0.0, 0.0, 0.0};
+            double wst[2][4];
+            if (xrow && NF <= BF) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) wst[mt][kk] = wstx[mt][kk];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        wst[mt][kk] = sf_state_weight<NS>(bl, mt, kk, col, lg, nfb, xrow ? j0 : jfix,
+                                                          xrow);
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 if (mt == 1 && !two) break;
-                const int id = 16 * mt + col, R = id >> 2;
-                const int fb = (id & 3) + 4 * (R / (2 * NS)), dir = (R / NS) & 1, ks = R % NS;
-                const bool on = fb < nfb;
-                const int jf = xrow ? j0 + (on ? fb : 0) : jfix;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * kk + lg, n = dir == 0 ? 15 - k : k;
-                    double w = bl[jf].pw[n];
-                    if (ks >= 1) w *= (double)n;
-                    if (ks >= 2) w *= (double)n;
-                    w = on ? w : 0.0;
-                    sf_mma(w, XB[0][kk], S[0][mt], scr);
-                    sf_mma(w, XB[1][kk], S[1][mt], scr);
+                    sf_mma(wst[mt][kk], XB[0][kk], S[0][mt], scr);
+                    sf_mma(wst[mt][kk], XB[1][kk], S[1][mt], scr);
                 }
             }
             if (j0 == 0) {
@@ -618,8 +651,8 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                     sf_mma(ta, XB[1][kk], OUT[1], scr);
                 }
             }
-            // --- scan of S over the 32 columns, in place: afterwards register R of a lane holds
-            // the state its block STARTS from.  This lane's filters: fb = lg (+ 4)
+            // --- scan of S over the 32 columns: the state each block STARTS from (register
+            // R = NS (2 fs + dir) + k of a lane).  This lane's filters: fb = lg (+ 4)
 #pragma unroll
             for (int fs = 0; fs < (NS == 2 ? 2 : 1); ++fs) {
                 if (fs == 1 && !two) break;
@@ -640,6 +673,17 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                         cin[k] = on ? cinl[(chan * 2 + dir) * NS + k] : 0.0;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) V[h][k] = S[h][(R0 + k) >> 2][(R0 + k) & 3];
+                    }
+                    // (response weights of the group: what a state entering a block contributes at
+                    // point col of it -- n = col + 1 steps on for the causal state, 16 - col for
+                    // the anti-causal one; requested before the scan)
+                    double wr[NS];
+                    {
+                        const int n = dir == 0 ? col + 1 : 16 - col;
+                        const double kw = on ? (xrow ? kap[jf * D + slot] : 1.0) : 0.0;
+                        wr[0] = kw * bl[jf].tb[n];
+                        wr[1] = kw * bl[jf].r1[n];
+                        if constexpr (NS == 3) wr[2] = kw * bl[jf].r2[n];
                     }
                     // inclusive scan inside each half (zeros shift in at the row's end)
 #define RL_SF_SCAN_STEP(N_, r_)                                                              \
@@ -679,27 +723,15 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                         sf_carry<NS>(Xh[1], cin, rpB, 16.0 * stepsB);
                         sf_carry<NS>(Xh[0], T, rpB, 16.0 * stepsB);
                     }
+                    // --- OUT += Rsp C for this group's registers R0 .. R0 + NS - 1, at once:
+                    // the matrix cores work on it while the next group's scan runs on the
+                    // vector pipe.  A fragment: point col, state id = 4 R + lg
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        S[0][(R0 + k) >> 2][(R0 + k) & 3] = Xh[0][k];
-                        S[1][(R0 + k) >> 2][(R0 + k) & 3] = Xh[1][k];
+                        sf_mma(wr[k], Xh[0][k], OUT[0], scr);
+                        sf_mma(wr[k], Xh[1][k], OUT[1], scr);
                     }
                 }
-            }
-            // --- OUT += Rsp S.  A fragment: point col, state id = 4 R + lg
-#pragma unroll
-            for (int R = 0; R < NR; ++R) {
-                if (R >= 2 * NS && !two) break;
-                if (NS == 3 && R >= 6) break;
-                const int fb = lg + 4 * (R / (2 * NS)), dir = (R / NS) & 1, ks = R % NS;
-                const bool on = fb < nfb;
-                const int jf = xrow ? j0 + (on ? fb : 0) : jfix;
-                const int n = dir == 0 ? col + 1 : 16 - col;
-                double w = ks == 0 ? bl[jf].tb[n] : (ks == 1 ? bl[jf].r1[n] : bl[jf].r2[n]);
-                if (xrow) w *= kap[jf * D + slot];
-                w = on ? w : 0.0;
-                sf_mma(w, S[0][R >> 2][R & 3], OUT[0], scr);
-                sf_mma(w, S[1][R >> 2][R & 3], OUT[1], scr);
             }
         }
         // the slot's result replaces the row: point lg + 4 r of column col

@@ -243,7 +243,9 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
 // and the odd degrees are summed separately, y(n) is their sum and y(mirror)
 // their difference.  (Measured and dropped: two slots per thread 318 vs 250 us
 // at C5, two rows of coefficients in flight 324 -- the scalar registers run
-// out --, non-temporal stores 271 vs 243.)
+// out --, non-temporal stores 271 vs 243.  Round 3: the expansion of the larger
+// ranks on the fp64 matrix cores -- Zhat fragments in registers, the chunk's basis in
+// LDS, 16 rows x 16 slots per tile, 128-byte stores: 555 vs 330-370 us at rank 48.)
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ void __launch_bounds__(256)

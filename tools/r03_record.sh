@@ -29,7 +29,13 @@ cp $root/profiles/r03/traffic.json $out/traffic.json
 python3 $root/tools/families.py c5 > $out/families_c5.txt 2>/dev/null; cat $out/families_c5.txt
 python3 $root/tools/families.py c2 > $out/families_c2.txt 2>/dev/null
 python3 $root/tools/families.py c2 1024 > $out/families_c2_1024.txt 2>/dev/null
+python3 $root/tools/setup_time.py 2>/dev/null > $out/setup_time.txt; cat $out/setup_time.txt
+python3 $root/examples/published_microbench.py 2>/dev/null > $out/published_microbench.txt; cat $out/published_microbench.txt
 if [ "$1" != "quick" ]; then
+  python3 $root/tools/sweep.py rbf 2>/dev/null > $out/sweep_dqm_rbf.txt
+  python3 $root/tools/sweep.py matern 2>/dev/null > $out/sweep_dqm_matern.txt
+  tail -9 $out/sweep_dqm_matern.txt
+  for fam in periodic matern mix; do $root/tools/bench_family.sh $fam; done
   (cd $root && python3 tests/report_iteration_parity.py c5) > $out/iteration_parity_c5.txt 2> $out/iteration_parity_c5.err
   cat $out/iteration_parity_c5.txt
 fi
