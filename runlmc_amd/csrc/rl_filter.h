@@ -48,7 +48,12 @@
 #pragma once
 #include "rl_device.h"
 
-#define RL_SF_G 512                        // grid points per chunk
+#define RL_SF_G 512                        // grid points per chunk (256 or 512: one or two
+                                           // 16-block halves per row in k_sf_apply; measured
+                                           // at C5 Matern, 256 with three workgroups per CU at
+                                           // 160 registers: apply 0.77 vs 0.76 ms, carries
+                                           // 0.30 vs 0.26, scan 0.17 vs 0.08 -- 512 kept)
+#define RL_SF_NH (RL_SF_G / 256)
 #define RL_SF_S 16                         // points per block
 #define RL_SF_LPR (RL_SF_G / RL_SF_S)      // blocks per row of a chunk
 #define RL_SF_PAD (RL_SF_G + RL_SF_LPR)    // doubles per LDS row: one pad per block
@@ -448,10 +453,14 @@ __host__ __device__ inline int sf_blob_doubles(int NF, int nfac, int D) {
 #define RL_SF_APPLY_ATTR
 #else
 // two workgroups per CU = two waves per SIMD: 256 registers, the next tile's rows among them
+#if RL_SF_G == 256
+#define RL_SF_APPLY_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#else
 #define RL_SF_APPLY_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
+#endif
 
-// requests a tile's D rows (thread tid: points tid and tid + 256 of row k / 2 in
+// requests a tile's D rows (thread tid: point tid + 256 (k % NH) of row k / NH in
 // xr[k], from clamped addresses -- points past the grid are zeroed when the registers
 // go to LDS, not here: a select right behind a load makes the compiler wait for it,
 // measured as twelve serial round trips) and its incoming states into registers
@@ -464,9 +473,9 @@ __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
     const double* xbase = X + (size_t)v * D * m;
 #pragma unroll
     for (int k = 0; k < XR; ++k) {
-        if ((k >> 1) < D) {
-            const int gi = g0 + tid + 256 * (k & 1);
-            xr[k] = xbase[(size_t)(k >> 1) * m + (gi < m ? gi : m - 1)];
+        if (k / RL_SF_NH < D) {
+            const int gi = g0 + tid + 256 * (k % RL_SF_NH);
+            xr[k] = xbase[(size_t)(k / RL_SF_NH) * m + (gi < m ? gi : m - 1)];
         }
     }
     const double* src = Cin + ((size_t)chunk * nvec + v) * ncin;
@@ -497,7 +506,7 @@ template <int NS, int D>        // (D at compile time: the row loops, the 2 D re
 __global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
 k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m, int NF,
            int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
-    constexpr int G = RL_SF_G, PAD = RL_SF_PAD, XR = 2 * D;
+    constexpr int G = RL_SF_G, PAD = RL_SF_PAD, NH = RL_SF_NH, XR = NH * D;
     constexpr int BF = NS == 2 ? 8 : 4;                      // filters per batch
     RL_SMEM(smem);
     const int nslots = D + nfac, nchan = D * NF + nfac, nblob = sf_blob_doubles(NF, nfac, D);
@@ -527,7 +536,7 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     // A workgroup walks tiles (chunk, vector) tile0, tile0 + gridDim.x, ...; the NEXT
     // tile's rows and incoming states are requested into registers before the current
     // tile is worked on, so that the memory round trip hides behind the matrix work.
-    // (256 threads: thread tid holds points tid and tid + 256 of every row)
+    // (256 threads: thread tid holds point tid (and tid + 256) of every row)
     const int nch = (m + G - 1) / G, ntiles = nch * nvec, ncin = nchan * 2 * NS;
     double xr[XR], cr[4];
     int tile = blockIdx.x;
@@ -538,9 +547,9 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     // registers -> LDS (the rows padded, see sf_pad), then request the next tile
 #pragma unroll
     for (int k = 0; k < XR; ++k)
-        if ((k >> 1) < D)
-            xs[(size_t)(k >> 1) * PAD + sf_pad(tid + 256 * (k & 1))] =
-                g0 + tid + 256 * (k & 1) < m ? xr[k] : 0.0;
+        if (k / NH < D)
+            xs[(size_t)(k / NH) * PAD + sf_pad(tid + 256 * (k % NH))] =
+                g0 + tid + 256 * (k % NH) < m ? xr[k] : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < ncin) cinl[tid + 256 * k] = cr[k];
@@ -552,7 +561,7 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     if (nfac > 0) {
         const double* gA = facA;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NH; ++half) {
             const int pi = sf_pad(tid + 256 * half);
             // (rows beyond D: unconditional reads of a clamped row, zero weight -- a
             // branch around a read makes the compiler wait for every read in turn,
@@ -600,13 +609,14 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
         const int jfix = xrow ? 0 : (int)facJ[xrow ? 0 : slot - D];    // the mixed row's filter
         double* row = (xrow ? xs + (size_t)slot * PAD : us + (size_t)(slot - D) * PAD);
         // B fragments of X: point 4 kk + lg of column col (+ 16 per half)
-        double XB[2][4];
+        double XB[NH][4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) XB[h][kk] = row[(16 * h + col) * 17 + 4 * kk + lg];
-        sf_v4d OUT[2];
-        OUT[0] = OUT[1] = sf_v4d{0.0, 0.0, 0.0, 0.0};
+        sf_v4d OUT[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) OUT[h] = sf_v4d{0.0, 0.0, 0.0, 0.0};
         // filters of the slot, in batches of BF
         const int nf_slot = xrow ? NF : 1;
         for (int j0 = 0; j0 < nf_slot; j0 += BF) {
@@ -615,8 +625,9 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
             // --- S = Wst X.  A fragment: state id = 16 mt + col -> lane row id % 4, register id / 4
             // (rows of x with all their filters in one batch: the weights do not depend on
             // the row and were computed once, before the first tile)
-            sf_v4d S[2][2];
-            S[0][0] = S[0][1] = S[1][0] = S[1][1] = sf_v4d{0.0, 0.0, 0.0, 0.0};
+            sf_v4d S[NH][2];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) S[h][0] = S[h][1] = sf_v4d{0.0, 0.0, 0.0, 0.0};
             double wst[2][4];
             if (xrow && NF <= BF) {
 #pragma unroll
@@ -636,8 +647,8 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                 if (mt == 1 && !two) break;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    sf_mma(wst[mt][kk], XB[0][kk], S[0][mt], scr);
-                    sf_mma(wst[mt][kk], XB[1][kk], S[1][mt], scr);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) sf_mma(wst[mt][kk], XB[h][kk], S[h][mt], scr);
                 }
             }
             if (j0 == 0) {
@@ -647,8 +658,8 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k = 4 * kk + lg, dd = col > k ? col - k : k - col;
                     const double ta = tcomb[slot * 16 + dd];
-                    sf_mma(ta, XB[0][kk], OUT[0], scr);
-                    sf_mma(ta, XB[1][kk], OUT[1], scr);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) sf_mma(ta, XB[h][kk], OUT[h], scr);
                 }
             }
             // --- scan of S over the 32 columns: the state each block STARTS from (register
@@ -667,12 +678,12 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
 #pragma unroll
                 for (int dir = 0; dir < 2; ++dir) {
                     const int R0 = NS * (2 * fs + dir);
-                    double V[2][NS], cin[NS];
+                    double V[NH][NS], cin[NS];
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
                         cin[k] = on ? cinl[(chan * 2 + dir) * NS + k] : 0.0;
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) V[h][k] = S[h][(R0 + k) >> 2][(R0 + k) & 3];
+                        for (int h = 0; h < NH; ++h) V[h][k] = S[h][(R0 + k) >> 2][(R0 + k) & 3];
                     }
                     // (response weights of the group: what a state entering a block contributes at
                     // point col of it -- n = col + 1 steps on for the causal state, 16 - col for
@@ -688,48 +699,55 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                     // inclusive scan inside each half (zeros shift in at the row's end)
 #define RL_SF_SCAN_STEP(N_, r_)                                                              \
     {                                                                                        \
-        double Sv[2][NS];                                                                    \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                        \
+        double Sv[NH][NS];                                                                   \
+        _Pragma("unroll") for (int h = 0; h < NH; ++h)                                       \
             _Pragma("unroll") for (int k = 0; k < NS; ++k)                                   \
                 Sv[h][k] = dir == 0 ? sf_row_shift<N_, true>(V[h][k], scr)                   \
                                     : sf_row_shift<N_, false>(V[h][k], scr);                 \
-        sf_carry<NS>(V[0], Sv[0], r_, 16.0 * N_);                                            \
-        sf_carry<NS>(V[1], Sv[1], r_, 16.0 * N_);                                            \
+        _Pragma("unroll") for (int h = 0; h < NH; ++h)                                       \
+            sf_carry<NS>(V[h], Sv[h], r_, 16.0 * N_);                                        \
     }
                     RL_SF_SCAN_STEP(1, r1_)
                     RL_SF_SCAN_STEP(2, r2_)
                     RL_SF_SCAN_STEP(4, r4_)
                     RL_SF_SCAN_STEP(8, r8_)
 #undef RL_SF_SCAN_STEP
-                    // exclusive value, the near half's total, the far half's carry
-                    double Xh[2][NS], T[NS];
+                    // exclusive value; with two halves: the near half's total, carried into the
+                    // far half with the chunk's incoming state 256 points on
+                    double Xh[NH][NS];
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        Xh[0][k] = dir == 0 ? sf_row_shift<1, true>(V[0][k], scr)
-                                            : sf_row_shift<1, false>(V[0][k], scr);
-                        Xh[1][k] = dir == 0 ? sf_row_shift<1, true>(V[1][k], scr)
-                                            : sf_row_shift<1, false>(V[1][k], scr);
-                        // causal: total of half 0 (its lane 15); anti-causal: of half 1 (lane 0)
-                        T[k] = dir == 0 ? sf_row_bcast<true>(V[0][k], scr)
-                                        : sf_row_bcast<false>(V[1][k], scr);
-                    }
-                    // state entering the far half = near half's total + chunk state 256 points on
-                    sf_carry<NS>(T, cin, r16_, 256.0);
+                    for (int k = 0; k < NS; ++k)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h)
+                            Xh[h][k] = dir == 0 ? sf_row_shift<1, true>(V[h][k], scr)
+                                                : sf_row_shift<1, false>(V[h][k], scr);
                     // (blocks between the half's edge and this one: col / 15 - col)
-                    if (dir == 0) {
-                        sf_carry<NS>(Xh[0], cin, rpF, 16.0 * stepsF);
-                        sf_carry<NS>(Xh[1], T, rpF, 16.0 * stepsF);
+                    if constexpr (NH == 2) {
+                        double T[NS];
+#pragma unroll
+                        for (int k = 0; k < NS; ++k)
+                            // causal: total of half 0 (its lane 15); anti-causal: of half 1 (lane 0)
+                            T[k] = dir == 0 ? sf_row_bcast<true>(V[0][k], scr)
+                                            : sf_row_bcast<false>(V[NH - 1][k], scr);
+                        sf_carry<NS>(T, cin, r16_, 256.0);
+                        if (dir == 0) {
+                            sf_carry<NS>(Xh[0], cin, rpF, 16.0 * stepsF);
+                            sf_carry<NS>(Xh[NH - 1], T, rpF, 16.0 * stepsF);
+                        } else {
+                            sf_carry<NS>(Xh[NH - 1], cin, rpB, 16.0 * stepsB);
+                            sf_carry<NS>(Xh[0], T, rpB, 16.0 * stepsB);
+                        }
                     } else {
-                        sf_carry<NS>(Xh[1], cin, rpB, 16.0 * stepsB);
-                        sf_carry<NS>(Xh[0], T, rpB, 16.0 * stepsB);
+                        if (dir == 0) sf_carry<NS>(Xh[0], cin, rpF, 16.0 * stepsF);
+                        else sf_carry<NS>(Xh[0], cin, rpB, 16.0 * stepsB);
                     }
                     // --- OUT += Rsp C for this group's registers R0 .. R0 + NS - 1, at once:
                     // the matrix cores work on it while the next group's scan runs on the
                     // vector pipe.  A fragment: point col, state id = 4 R + lg
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        sf_mma(wr[k], Xh[0][k], OUT[0], scr);
-                        sf_mma(wr[k], Xh[1][k], OUT[1], scr);
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) sf_mma(wr[k], Xh[h][k], OUT[h], scr);
                     }
                 }
             }
@@ -737,7 +755,7 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
         // the slot's result replaces the row: point lg + 4 r of column col
         if (sraw < send) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) row[(16 * h + col) * 17 + lg + 4 * r] = OUT[h][r];
         }
@@ -752,7 +770,7 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
         const double* gAW = facAW;
         double* ybase = Y + (size_t)v * D * m + g0;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NH; ++half) {
             const int i = tid + 256 * half, pi = sf_pad(i);
             double acc[16];
 #pragma unroll

@@ -1615,7 +1615,10 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
 #if defined(RL_EMU)
     const int ntiles = nch * nvec, resident = 7;            // (so that tests walk several tiles)
 #else
-    const int ntiles = nch * nvec, resident = 2 * RL_LR_CUS;
+    // (resident workgroups per CU: what the tile's LDS allows, at most three)
+    const size_t tile_lds = sf_apply_lds(D, sp.nfac, sp.NF, 256);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / tile_lds));
+    const int ntiles = nch * nvec, resident = per_cu * RL_LR_CUS;
 #endif
 #define RL_SF_APPLY(D_)                                                                      \
     case D_:                                                                                    \
