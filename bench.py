@@ -442,7 +442,10 @@ def time_full_operator(g, p, batch, gen, steps, world, dev, alg):
             'steps': fsteps, 'n': p.n,
             'roofline_frac': full_alg / (fwall * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'algorithmic_bytes_per_step': full_alg,
-            'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors' % batch}
+            'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors, in the CALLER\'s row '
+                    'order: the two row permutations of the batch (caller <-> grid-sorted order) '
+                    'are inside this time -- about half of it at C5 -- and a solve pays them '
+                    'once, not per round (DESIGN.md section 3, item 6)' % batch}
 
 
 FORM_NAMES = {0: 'transform', 1: 'polynomial', 2: 'filter'}

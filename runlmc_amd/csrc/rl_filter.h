@@ -173,6 +173,22 @@ __device__ __forceinline__ int sf_wave_sums(const double (&acc)[NV], double* red
 // filters: 2 NS multiply-adds per value and filter, weights from LDS shared by
 // the four rows.
 // ---------------------------------------------------------------------------
+// requests RB rows' share of a chunk (lane: points lane + 64 k) from clamped addresses
+template <int NK, int RB>
+__device__ __forceinline__ void sf_request_rows(double (&xv)[NK][RB], const double* __restrict__ X,
+                                                int nrows, int m, int r0, int g0, int lane) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int row = r0 + r;
+        const double* xr = X + (size_t)(row < nrows ? row : nrows - 1) * m;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int gi = g0 + lane + 64 * k;
+            xv[k][r] = xr[gi < m ? gi : m - 1];
+        }
+    }
+}
+
 template <int NS>
 __global__ void __launch_bounds__(256)
 k_sf_carries(const double* __restrict__ X, int nrows, int m, int NF, const double* __restrict__ pw,
@@ -185,19 +201,21 @@ k_sf_carries(const double* __restrict__ X, int nrows, int m, int NF, const doubl
     const int chunk = blockIdx.x, rbase = blockIdx.y * rows_per_wg, g0 = chunk * G;
     for (int e = tid; e < NF * (G + 1); e += 256) pwl[e] = pw[e];
     __syncthreads();
+    // (the next four rows are requested before the current four are worked on: the wave's
+    // loads overlap its sums)
+    double xn[NK][RB];
+    sf_request_rows<NK, RB>(xn, X, nrows, m, rbase + wave * RB, g0, lane);
     for (int r0 = rbase + wave * RB; r0 < rbase + rows_per_wg; r0 += 4 * RB) {
         double xv[NK][RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int row = r0 + r;
-            const double* xr = X + (size_t)(row < nrows ? row : nrows - 1) * m;
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const int gi = g0 + lane + 64 * k;
-                const double live = (row < nrows && gi < m) ? 1.0 : 0.0;
-                xv[k][r] = xr[gi < m ? gi : m - 1] * live;
+                const double live = (r0 + r < nrows && g0 + lane + 64 * k < m) ? 1.0 : 0.0;
+                xv[k][r] = xn[k][r] * live;
             }
-        }
+        if (r0 + 4 * RB < rbase + rows_per_wg)
+            sf_request_rows<NK, RB>(xn, X, nrows, m, r0 + 4 * RB, g0, lane);
         for (int q = 0; q < NF; ++q) {
             const double* p = pwl + (size_t)q * (G + 1);
             double acc[NV];
@@ -246,12 +264,12 @@ k_sf_carries(const double* __restrict__ X, int nrows, int m, int NF, const doubl
 // Channels of a vector: (output a, top j) -> a NF + j for the diagonal part, then
 // one per rank-one factor f, whose chunk states are  sum_b A_f[b] E(row b)  by
 // linearity.
-//   grid (ceil(2 nchan / 16), nvec)   block 256 = 16 (channel, direction) x 16 segments
-// The chunks of a (channel, direction) are cut into 16 segments: a thread chains
-// its segment from a zero state, the 16 segment totals are chained through LDS,
-// and the thread walks its segment again from the right state -- 2 nchunks / 16
+//   grid (ceil(2 nchan / 8), nvec)   block 256 = 8 (channel, direction) x 32 segments
+// The chunks of a (channel, direction) are cut into 32 segments: a thread chains
+// its segment from a zero state, the 32 segment totals are chained through LDS,
+// and the thread walks its segment again from the right state -- 2 nchunks / 32
 // dependent steps instead of nchunks (C5: 196 chunks; one thread per channel
-// took 3 ms, every step a memory round trip).
+// took 3 ms, every step a memory round trip; 16 segments 80 us).
 // ---------------------------------------------------------------------------
 template <int NS>
 __device__ __forceinline__ void sf_chunk_state(const double* __restrict__ E, const SfParams& sp,
@@ -279,10 +297,11 @@ __global__ void __launch_bounds__(256)
 k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams sp,
           double* __restrict__ Cin) {
     RL_SMEM(smem);
-    double* agg = reinterpret_cast<double*>(smem);       // [16 segments][16][NS]
+    constexpr int NCD = 8, NSEG = 32;
+    double* agg = reinterpret_cast<double*>(smem);       // [NSEG][NCD][NS]
     const int NF = sp.NF, nchan = D * NF + sp.nfac, ncd = 2 * nchan;
-    const int tid = threadIdx.x, cdl = tid & 15, seg = tid >> 4, v = blockIdx.y;
-    const int cdr = blockIdx.x * 16 + cdl;
+    const int tid = threadIdx.x, cdl = tid & (NCD - 1), seg = tid / NCD, v = blockIdx.y;
+    const int cdr = blockIdx.x * NCD + cdl;
     const bool live = cdr < ncd;
     const int cd = live ? cdr : ncd - 1;
     const int dir = cd & 1, chan = cd >> 1;
@@ -292,7 +311,7 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
     const int a = diag ? chan / NF : 0;
     const double rG = sp.tops[j].rG, n = (double)RL_SF_G;
     const int nrows = nvec * D, row0 = v * D;
-    const int seglen = (nchunks + 15) / 16;
+    const int seglen = (nchunks + NSEG - 1) / NSEG;
     const int p0 = seg * seglen < nchunks ? seg * seglen : nchunks;
     const int p1 = p0 + seglen < nchunks ? p0 + seglen : nchunks;
     // the segment alone
@@ -310,7 +329,7 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
         for (int k = 0; k < NS; ++k) st[k] = e[k];
     }
 #pragma unroll
-    for (int k = 0; k < NS; ++k) agg[(seg * 16 + cdl) * NS + k] = st[k];
+    for (int k = 0; k < NS; ++k) agg[(seg * NCD + cdl) * NS + k] = st[k];
     __syncthreads();
     // the segments before this one (all of them full: seglen chunks each)
     double rL = 1.0;
@@ -321,7 +340,7 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
     for (int s = 0; s < seg; ++s) {
         double e[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) e[k] = agg[(s * 16 + cdl) * NS + k];
+        for (int k = 0; k < NS; ++k) e[k] = agg[(s * NCD + cdl) * NS + k];
         sf_carry<NS>(e, st, rL, nL);
 #pragma unroll
         for (int k = 0; k < NS; ++k) st[k] = e[k];
@@ -396,6 +415,26 @@ __device__ __forceinline__ double sf_row_bcast(double v, double* scr) {
     (void)scr;
     // ds_swizzle, bit-mask mode inside groups of 32: lane' = (lane & 0x10) | (LAST ? 0x0f : 0)
     constexpr int pat = 0x10 | ((LAST ? 0x0F : 0x00) << 5);
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
+    return __hiloint2double(hi, lo);
+#endif
+}
+
+// value of the lane 16 further / nearer (lane ^ 16): the partner lane row of a pair
+__device__ __forceinline__ double sf_row_partner(double v, double* scr) {
+#if defined(RL_EMU)
+    const int tid = threadIdx.x, lane = tid & 63;
+    double* w = scr + (size_t)(tid >> 6) * 128;
+    w[lane] = v;
+    __syncthreads();
+    const double r = w[lane ^ 16];
+    __syncthreads();
+    return r;
+#else
+    (void)scr;
+    // ds_swizzle, bit-mask mode: and 0x1f, or 0, xor 0x10
+    constexpr int pat = 0x1F | (0x10 << 10);
     const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
     return __hiloint2double(hi, lo);
@@ -532,7 +571,9 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            wstx[mt][kk] = sf_state_weight<NS>(bl, mt, kk, col, lg, NF < BF ? NF : BF, 0, true);
+            wstx[mt][kk] = sf_state_weight<NS>(
+                bl, mt, kk, col, lg, (NS == 2 && (NF & 3) == 1) ? (NF < 4 ? NF : 4) : (NF < BF ? NF : BF), 0,
+                true);
     // A workgroup walks tiles (chunk, vector) tile0, tile0 + gridDim.x, ...; the NEXT
     // tile's rows and incoming states are requested into registers before the current
     // tile is worked on, so that the memory round trip hides behind the matrix work.
@@ -618,10 +659,102 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
 #pragma unroll
         for (int h = 0; h < NH; ++h) OUT[h] = sf_v4d{0.0, 0.0, 0.0, 0.0};
         // filters of the slot, in batches of BF
+        // (NS == 2 and one filter over a multiple of four: batches of four, and the last
+        // filter alone in the PACKED layout below)
         const int nf_slot = xrow ? NF : 1;
-        for (int j0 = 0; j0 < nf_slot; j0 += BF) {
-            const int nfb = nf_slot - j0 < BF ? nf_slot - j0 : BF;
+        const int bf = (NS == 2 && (nf_slot & 3) == 1) ? 4 : BF;
+        for (int j0 = 0; j0 < nf_slot; j0 += bf) {
+            const int nfb = nf_slot - j0 < bf ? nf_slot - j0 : bf;
             const bool two = nfb > 4 || NS == 3;             // second tile of states in use
+            if (NS == 2 && nfb == 1) {
+                // ---- ONE filter, packed: its four states (F0, F1, H0, H1) sit on the four
+                // lane rows of a single register -- state lg of column col --, so the scan
+                // below moves one value per lane (all 64 lanes busy) instead of pairs on a
+                // quarter of the lanes, and the response is one matrix instruction per half.
+                const int jf = xrow ? j0 : jfix;
+                const int pdir = lg >> 1, pks = lg & 1;
+                sf_v4d SP[NH];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) SP[h] = sf_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    // A fragment: state id = col (< 4), point k = 4 kk + lg
+                    const int k = 4 * kk + lg, adir = (col >> 1) & 1, aks = col & 1;
+                    const int n = adir == 0 ? 15 - k : k;
+                    double w = bl[jf].pw[n];
+                    if (aks) w *= (double)n;
+                    w = col < 4 ? w : 0.0;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) sf_mma(w, XB[h][kk], SP[h], scr);
+                }
+                if (j0 == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + lg, dd = col > k ? col - k : k - col;
+                        const double ta = tcomb[slot * 16 + dd];
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) sf_mma(ta, XB[h][kk], OUT[h], scr);
+                    }
+                }
+                const int chan = xrow ? slot * NF + jf : D * NF + (slot - D);
+                const double* p16 = bl[jf].p16;
+                const double c0 = cinl[(chan * 2 + pdir) * NS], c1 = cinl[(chan * 2 + pdir) * NS + 1];
+                const int steps = pdir == 0 ? col : 15 - col;
+                const double rp = p16[steps], np = 16.0 * steps;
+                const double kw = xrow ? kap[jf * D + slot] : 1.0;
+                const int nr = pdir == 0 ? col + 1 : 16 - col;
+                const double wr = kw * (pks == 0 ? bl[jf].tb[nr] : bl[jf].r1[nr]);
+                // scalar first-order scans: the second state rides as  q = F1 -/+ 16 c F0
+                // (F1(c) = Q(c) + 16 c F0(c) causal, H1(c) = Q(c) - 16 c H0(c) anti-causal)
+                double v[NH], x[NH];
+                const double cpre = pks ? (pdir == 0 ? -16.0 * col : 16.0 * col) : 0.0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    v[h] = SP[h][0];
+                    v[h] = fma(cpre, sf_row_partner(v[h], scr), v[h]);
+                }
+#define RL_SF_PSCAN(N_)                                                                      \
+    _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                         \
+        const double up_ = sf_row_shift<N_, true>(v[h], scr);                                \
+        const double dn_ = sf_row_shift<N_, false>(v[h], scr);                               \
+        v[h] = fma(p16[N_], pdir == 0 ? up_ : dn_, v[h]);                                    \
+    }
+                RL_SF_PSCAN(1)
+                RL_SF_PSCAN(2)
+                RL_SF_PSCAN(4)
+                RL_SF_PSCAN(8)
+#undef RL_SF_PSCAN
+                // exclusive values, back to true states: X1 = q +/- 16 (c -/+ 1) X0
+                const double cpost = pks ? (pdir == 0 ? 16.0 * (col - 1) : -16.0 * (col + 1)) : 0.0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const double up_ = sf_row_shift<1, true>(v[h], scr);
+                    const double dn_ = sf_row_shift<1, false>(v[h], scr);
+                    x[h] = pdir == 0 ? up_ : dn_;
+                    const double edge = pdir == 0 ? (col == 0 ? 0.0 : 1.0) : (col == 15 ? 0.0 : 1.0);
+                    x[h] = fma(cpost * edge, sf_row_partner(x[h], scr), x[h]);
+                }
+                // what enters from outside: the chunk's state (c0, c1), carried `steps` blocks
+                // on -- a lane takes its own component of  rho^n (s0, s1 + n s0)
+                const double cnear = rp * (pks ? fma(np, c0, c1) : c0);
+                if constexpr (NH == 2) {
+                    // near half's total (true state) + the chunk's state 256 points on
+                    double t = pdir == 0 ? sf_row_bcast<true>(v[0], scr) : sf_row_bcast<false>(v[1], scr);
+                    double tp = sf_row_partner(t, scr);
+                    if (pdir == 0 && pks) t = fma(240.0, tp, t);        // (column 15: Q + 16 * 15 F0)
+                    t = fma(p16[16], pks ? fma(256.0, c0, c1) : c0, t);
+                    tp = sf_row_partner(t, scr);
+                    const double cfar = rp * (pks ? fma(np, tp, t) : t);
+                    x[0] += pdir == 0 ? cnear : cfar;
+                    x[1] += pdir == 0 ? cfar : cnear;
+                } else {
+                    x[0] += cnear;
+                }
+                // response: A fragment = point col, state id = lg
+#pragma unroll
+                for (int h = 0; h < NH; ++h) sf_mma(wr, x[h], OUT[h], scr);
+                continue;
+            }
             // --- S = Wst X.  A fragment: state id = 16 mt + col -> lane row id % 4, register id / 4
             // (rows of x with all their filters in one batch: the weights do not depend on
             // the row and were computed once, before the first tile)
@@ -629,7 +762,7 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
 #pragma unroll
             for (int h = 0; h < NH; ++h) S[h][0] = S[h][1] = sf_v4d{0.0, 0.0, 0.0, 0.0};
             double wst[2][4];
-            if (xrow && NF <= BF) {
+            if (xrow && j0 == 0) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

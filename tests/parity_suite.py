@@ -860,7 +860,9 @@ def check_filter_form():
     rng = np.random.RandomState(77)
     try:
         # (20011 points: 40 chunks, so that the chunk scan's segments hold several)
-        for D, Q, m, k in ((3, 2, 2500, 3), (2, 3, 4101, 2), (5, 2, 700, 2), (2, 2, 20011, 2)):
+        # (five tops: a batch of four filters and a fifth alone, the layouts of C5's family)
+        for D, Q, m, k in ((3, 2, 2500, 3), (2, 3, 4101, 2), (5, 2, 700, 2), (2, 2, 20011, 2),
+                           (3, 5, 2200, 2)):
             x = np.linspace(0, 1, m)
             gam = np.logspace(0, 1, Q) * (1.0 if m > 1000 else 3.0)
             mat = np.array([_matern32(x, g_) for g_ in gam])
@@ -903,7 +905,10 @@ def check_filter_form():
             if m < 2048:
                 continue
             # the 'mix' family: rbf + periodic + matern (+ a second rbf)
-            mix = np.array([np.exp(-0.5 * x ** 2), np.exp(-0.5 * np.sin(np.pi * x) ** 2),
+            # (periodic with period 3: rank 24 or 32.  The benchmark's period-1 kernel needs
+            # rank 48, and with fewer than eight outputs a rank-48 polynomial part next to a
+            # filter part is handed to the transform kernels -- checked below)
+            mix = np.array([np.exp(-0.5 * x ** 2), np.exp(-0.5 * np.sin(np.pi * x / 3.0) ** 2),
                             _matern32(x, 1.0), np.exp(-0.5 * x ** 2)][:max(Q, 3)])
             Qm = len(mix)
             Am = [rng.randn(1, D) for _ in range(Qm)]
@@ -931,6 +936,13 @@ def check_filter_form():
             gm.set_lmc(mix, Am, km)             # and back
             assert gm.top_forms()[1]
             _close(_poly_product(gm, X), refm)
+            p1 = mix.copy()
+            p1[1] = np.exp(-0.5 * np.sin(np.pi * x) ** 2)       # period 1: rank 48
+            gm.set_lmc(p1, Am, km)
+            forms, structured = gm.top_forms()
+            assert forms == [1, 1, 2, 1][:Qm] and gm.lib is not None
+            assert structured or D < 8, (forms, structured)      # (rank 48 at D < 8: transforms)
+            _close(_poly_product(gm, X), oracle(p1, Bs_=Bm))
         os.environ['RUNLMC_NO_FILTER'] = '1'
         g1 = GridOp(2, 2500, 1)
         g1.set_lmc(_matern32(np.linspace(0, 1, 2500), 2.0)[None], [rng.randn(1, 2)], [np.ones(2)])
