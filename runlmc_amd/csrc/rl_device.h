@@ -26,6 +26,7 @@
 
 #include <stdint.h>
 
+
 // RL_TIMING (experiment builds only: python -m runlmc_amd.build --timing):
 // kernels stamp s_memtime at their phase boundaries into a global buffer that
 // rl_debug_timing() reads back -- the only way to see where a latency-bound

@@ -76,6 +76,9 @@ __device__ __forceinline__ double lr_point(int n, int m) {
 // the `steps` points of each lane (a multiple of RL_LR_T, chosen by the host: long
 // chunks amortise the reduction); the 64 lanes are summed once per chunk
 // through LDS.  x values are requested RL_LR_G(R) lane-steps before their use.
+// (Round 3: non-temporal loads for x, A/B in ONE job, three alternations: 0.45 / 0.45 /
+// 0.42 ms per C5 product with plain loads, 0.47 / 0.49 / 0.43 with non-temporal ones -- no
+// gain, and the run-to-run spread on one box is as large as the box-to-box one.)
 // (Measured and dropped, round 3: the projection as a tall-skinny product on the fp64
 // matrix cores -- v_mfma_f64_16x16x4_f64, 16 rows x 16 functions per tile, basis tile
 // in LDS, sums never reduced across lanes, 124 VGPRs.  The instruction's A layout puts
