@@ -23,12 +23,32 @@ def choose_ktype(spec, active_dim=(0,)):
     return 'slfm' if tot_rank + spec.D < spec.D ** 2 + correction else 'bt'
 
 
+def slfm_identity_terms(spec, active_dim=(0,)):
+    """How many IDENTITY matrices the reference's 'slfm' representation puts on
+    the grid in the place of parts the model does not have (reference
+    grid_kernel.py:87-88: no coregionalised kernel in the set -> Identity(m)
+    instead of the coregionalised part; :104-105: neither LMC nor independent
+    kernels -> Identity(m) instead of the diagonal part).  Pinned by
+    tests/golden/slfm_quirk.npz (the reference's own GridKernel)."""
+    kidxs = spec.active_dims[active_dim]
+    count = 0
+    if not spec.filter_non_indep_idxs(kidxs):
+        count += 1
+    if spec.num_lmc[active_dim] == 0 and spec.num_indep[active_dim] == 0:
+        count += 1
+    return count
+
+
 class LMCOperatorOracle:
     """K~ = W K_UU W^T + diag(eps) in one of the three representations
-    (reference grid_kernel.py:22-74)."""
+    (reference grid_kernel.py:22-74).  `reference_slfm_identity=True` reproduces
+    the 'slfm' representation's identity terms (slfm_identity_terms) instead of
+    the mathematical sum_q B_q (x) K_q."""
 
     def __init__(self, spec, grid_dists, W, WT, lens, ktype=None,
-                 active_dim=(0,)):
+                 active_dim=(0,), reference_slfm_identity=False):
+        self._eye = (slfm_identity_terms(spec, active_dim)
+                     if reference_slfm_identity else 0)
         self.spec = spec
         self.W, self.WT = W, WT
         self.lens = list(lens)
@@ -49,9 +69,10 @@ class LMCOperatorOracle:
         if self.ktype == 'bt':
             return ops.grid_bt_matvec(self.Bs, self.tops, self.sizes, g)
         if self.ktype == 'slfm':
-            return ops.grid_slfm_matvec(self.spec.coreg_vecs,
-                                        self.spec.coreg_diags, self.tops,
-                                        self.sizes, g)
+            out = ops.grid_slfm_matvec(self.spec.coreg_vecs,
+                                       self.spec.coreg_diags, self.tops,
+                                       self.sizes, g)
+            return out + self._eye * np.asarray(g, dtype=np.float64)
         raise AssertionError(self.ktype)
 
     def matvec(self, x):

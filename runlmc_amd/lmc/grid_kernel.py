@@ -11,7 +11,10 @@ interface compatibility; it does not change the arithmetic performed.
 
 The reference quirk of adding an identity on the grid for pure-SLFM or
 pure-independent models under 'slfm' (grid_kernel.py:87-88,104-105) is NOT
-reproduced: the operator here is the mathematical sum_q B_q (x) K_q.
+reproduced by default: the operator here is the mathematical sum_q B_q (x) K_q.
+``reference_slfm_identity=True`` reproduces it (an extra unit-impulse top row with
+B = I per identity the reference adds), for callers that need the reference's
+numbers bit for bit in those two degenerate model classes.
 """
 import numpy as np
 import torch
@@ -30,6 +33,19 @@ def choose_ktype(fk, active_dim):
     no_diag = (not fk.num_lmc[active_dim]) and (not fk.num_indep[active_dim])
     bonus = fk.D if no_diag else 0
     return 'slfm' if fk.total_rank(active_dim) + fk.D < fk.D ** 2 + bonus else 'bt'
+
+
+def slfm_identity_terms(fk, active_dim):
+    """Identity matrices the reference's 'slfm' representation adds on the grid
+    (grid_kernel.py:87-88: no coregionalised kernel in the set; :104-105:
+    neither LMC nor independent kernels)."""
+    kidx = fk.active_dims[active_dim]
+    count = 0
+    if not fk.filter_non_indep_idxs(kidx):
+        count += 1
+    if fk.num_lmc[active_dim] == 0 and fk.num_indep[active_dim] == 0:
+        count += 1
+    return count
 
 
 class _GridKUU(Matrix):
@@ -85,7 +101,8 @@ class GridKernel(Matrix):
     """W K_UU W^T for the kernels that share one active-dimension set."""
 
     def __init__(self, functional_kernel, grid_dists, interpolant,
-                 interpolantT, ktype, active_dim, device_index=0):
+                 interpolantT, ktype, active_dim, device_index=0,
+                 reference_slfm_identity=False):
         n = interpolant.shape[0]
         super().__init__(n, n)
         if ktype not in ('sum', 'bt', 'slfm'):
@@ -101,10 +118,13 @@ class GridKernel(Matrix):
         tops = as_f64(fk.eval_kernels_fixed_dim(grid_dists, active_dim)
                       ).reshape(len(kidx), -1)
         self._m = tops.shape[1]
-        self._op = GridOp(fk.D, self._m, len(kidx), device_index=device_index,
-                          sizes=grid_dists.shape)
-        self._op.set_lmc(tops, [fk.coreg_vecs[q] for q in kidx],
-                         [fk.coreg_diags[q] for q in kidx])
+        # the reference's identity terms under 'slfm', on request: a unit impulse as
+        # an extra top row (T = I) with B = count * I
+        self._eye = (slfm_identity_terms(fk, active_dim)
+                     if reference_slfm_identity and ktype == 'slfm' else 0)
+        self._op = GridOp(fk.D, self._m, len(kidx) + (1 if self._eye else 0),
+                          device_index=device_index, sizes=grid_dists.shape)
+        self._set(fk, kidx, tops)
         self._skiop = SkiOp(self._op, interpolant, interpolantT)
         self.grid_K = _GridKUU(self._op)
         self.ski = _DeviceSKI(self._skiop, interpolant, interpolantT, self.grid_K)
@@ -116,8 +136,18 @@ class GridKernel(Matrix):
         kidx = fk.active_dims[self.active_dim]
         tops = as_f64(fk.eval_kernels_fixed_dim(np.asarray(grid_dists),
                                                 self.active_dim)).reshape(len(kidx), -1)
-        self._op.set_lmc(tops, [fk.coreg_vecs[q] for q in kidx],
-                         [fk.coreg_diags[q] for q in kidx])
+        self._set(fk, kidx, tops)
+
+    def _set(self, fk, kidx, tops):
+        vecs = [fk.coreg_vecs[q] for q in kidx]
+        diags = [fk.coreg_diags[q] for q in kidx]
+        if self._eye:
+            impulse = np.zeros((1, tops.shape[1]))
+            impulse[0, 0] = 1.0
+            tops = np.vstack([tops, impulse])
+            vecs = vecs + [None]
+            diags = diags + [float(self._eye) * np.ones(fk.D)]
+        self._op.set_lmc(tops, vecs, diags)
 
     @property
     def device(self):
@@ -183,7 +213,7 @@ class LMCOperator(SumMatrix):
 
 
 def gen_grid_kernel(fk, grid_dists, interpolants, lens_per_output,
-                    device_index=0):
+                    device_index=0, reference_slfm_identity=False):
     """(K~, {active_dim: GridKernel}) exactly as the reference returns them
     (grid_kernel.py:49-74): one GridKernel per active-dimension set, summed
     with the noise."""
@@ -192,7 +222,8 @@ def gen_grid_kernel(fk, grid_dists, interpolants, lens_per_output,
         W, WT = interpolants[active_dim]
         grid_kerns[active_dim] = GridKernel(
             fk, grid_dists[active_dim], W, WT, choose_ktype(fk, active_dim),
-            active_dim, device_index=device_index)
+            active_dim, device_index=device_index,
+            reference_slfm_identity=reference_slfm_identity)
     noise = Diag(np.repeat(fk.noise, lens_per_output))
     K = LMCOperator(list(grid_kerns.values()), noise, fk.noise, lens_per_output)
     return K, grid_kerns

@@ -338,7 +338,48 @@ def gen_lmc():
               n_probes=2, dense=False, n_mv=2)
 
 
+def gen_slfm_quirk():
+    """The reference's 'slfm' representation puts an IDENTITY on the grid in the
+    place of a part the model does not have (runlmc/lmc/grid_kernel.py:87-88:
+    no coregionalised kernel -> Identity instead of the coregionalised part;
+    :104-105: neither LMC nor independent kernels -> Identity instead of the
+    diagonal part).  Two small models, the reference's GridKernel in 'slfm' and in
+    'sum' form on the same grid vectors."""
+    from scipy.stats import truncnorm
+    rng = np.random.RandomState(77)
+    D, m = 3, 40
+    grid = np.linspace(0.0, 1.0, m)
+    gd = grid - grid[0]
+    W = __import__('scipy.sparse', fromlist=['identity']).identity(D * m, format='csr')
+    out = dict(D=D, m=m, grid_dists=gd, x=rng.randn(2, D * m))
+    cases = {
+        # pure SLFM: two SLFM kernels, no LMC, no independent kernels
+        'pure_slfm': dict(kd=[('rbf', 2.0), ('rbf', 5.0)], num_lmc=0, num_slfm=2,
+                          vecs=[truncnorm(-1, 1).rvs(size=(1, D), random_state=rng) for _ in range(2)],
+                          diags=[np.zeros(D), np.zeros(D)]),
+        # pure independent: three independent kernels, no coregionalised one
+        'pure_indep': dict(kd=[('rbf', 1.0), ('rbf', 3.0), ('rbf', 6.0)], num_lmc=0, num_slfm=0,
+                           vecs=[np.zeros((1, D)) for _ in range(3)],
+                           diags=[np.eye(D)[d] for d in range(3)]),
+    }
+    for name, c in cases.items():
+        spec = KernelSpec(D, [_kernel_from_desc(k) for k in c['kd']], c['vecs'], c['diags'],
+                          0.1 * np.ones(D), num_lmc=c['num_lmc'], num_slfm=c['num_slfm'])
+        spec.set_input_dim(1)
+        for kt in ('slfm', 'sum'):
+            gk = GridKernel(spec, gd, W, W, kt, (0,))
+            out[f'{name}_{kt}'] = np.array([gk.grid_K.matvec(v) for v in out['x']])
+        out[f'{name}_kdesc'] = np.array([';'.join(str(v) for v in k) for k in c['kd']])
+        out[f'{name}_nums'] = np.array([c['num_lmc'], c['num_slfm']])
+        for q in range(len(c['kd'])):
+            out[f'{name}_A{q}'] = c['vecs'][q]
+            out[f'{name}_kappa{q}'] = c['diags'][q]
+    _save('slfm_quirk.npz', **out)
+
+
 def _main():
+    if '--quirk-only' in sys.argv:
+        return gen_slfm_quirk()
     if '--fit-data-only' in sys.argv:
         gen_fit_data()
         return
@@ -352,6 +393,7 @@ def _main():
         gen_lmc()
         gen_2d()
         gen_split()
+        gen_slfm_quirk()
     gen_datasets()
 
 

@@ -827,6 +827,37 @@ def check_polynomial_form():
                 os.environ[kn] = saved[kn]
 
 
+def check_slfm_identity_quirk(golden_dir=None):
+    """The reference's 'slfm' representation adds an identity on the grid for
+    pure-SLFM and pure-independent models (grid_kernel.py:87-88,104-105;
+    tests/golden/slfm_quirk.npz holds the reference's own GridKernel outputs).
+    Default: the mathematical operator (= the reference's 'sum' form);
+    reference_slfm_identity=True: the reference's 'slfm' numbers."""
+    from runlmc_amd.lmc.functional_kernel import FunctionalKernel
+    from runlmc_amd.lmc.grid_kernel import GridKernel, slfm_identity_terms
+    import scipy.sparse as sp
+    g = np.load(os.path.join(golden_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'), 'slfm_quirk.npz'))
+    D, m = int(g['D']), int(g['m'])
+    W = sp.identity(D * m, format='csr')
+    for name in ('pure_slfm', 'pure_indep'):
+        kerns = [_kernel(str(s_)) for s_ in g[name + '_kdesc']]
+        nl, ns = [int(v) for v in g[name + '_nums']]
+        Q = len(kerns)
+        if name == 'pure_slfm':
+            fk = FunctionalKernel(D=D, slfm_kernels=kerns)
+        else:
+            fk = FunctionalKernel(D=D, indep_gp=kerns, indep_gp_index=list(range(Q)))
+        fk.coreg_vecs = [g[f'{name}_A{q}'] for q in range(Q)]
+        fk.coreg_diags = [g[f'{name}_kappa{q}'] for q in range(Q)]
+        fk.set_input_dim(1)
+        assert slfm_identity_terms(fk, (0,)) == 1
+        for quirk, ref in ((False, g[name + '_sum']), (True, g[name + '_slfm'])):
+            gk = GridKernel(fk, g['grid_dists'], W, W, 'slfm', (0,),
+                            reference_slfm_identity=quirk)
+            got = np.array([gk.grid_K.matvec(v) for v in g['x']])
+            _close(got, ref)
+
+
 def _matern32(x, gamma):
     s = np.sqrt(3) * gamma * x
     return (1 + s) * np.exp(-s)

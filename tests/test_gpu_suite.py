@@ -142,6 +142,10 @@ def test_filter_form():
     ps.check_filter_form()
 
 
+def test_slfm_identity_quirk():
+    ps.check_slfm_identity_quirk()
+
+
 def test_polynomial_gate_boundary():
     ps.check_polynomial_gate_boundary()
 

@@ -182,3 +182,32 @@ def test_reference_solver_wrapper(name):
     assert abs(it - int(c.g['ref_cg_iters'][0])) <= 2
     ref = c.g['ref_cg_x'][0]
     np.testing.assert_allclose(x, ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+
+
+def test_slfm_identity_quirk(golden_dir):
+    """The oracle's statement of the reference's identity terms under 'slfm'
+    (oracle.likelihood.slfm_identity_terms) against the reference's own GridKernel
+    on a pure-SLFM and a pure-independent model (tests/golden/slfm_quirk.npz)."""
+    import os
+    import scipy.sparse as sp
+    from oracle.kernels import KernelSpec, RBFSpec
+    from oracle import likelihood as olik
+    g = np.load(os.path.join(golden_dir, 'slfm_quirk.npz'))
+    D, m = int(g['D']), int(g['m'])
+    W = sp.identity(D * m, format='csr')
+    for name in ('pure_slfm', 'pure_indep'):
+        kd = [str(s_).split(';') for s_ in g[name + '_kdesc']]
+        nl, ns = [int(v) for v in g[name + '_nums']]
+        Q = len(kd)
+        spec = KernelSpec(D, [RBFSpec(float(k[1])) for k in kd],
+                          [g[f'{name}_A{q}'] for q in range(Q)],
+                          [g[f'{name}_kappa{q}'] for q in range(Q)], 0.1 * np.ones(D),
+                          num_lmc=nl, num_slfm=ns)
+        spec.set_input_dim(1)
+        assert olik.slfm_identity_terms(spec) == 1
+        for quirk, key in ((False, '_sum'), (True, '_slfm')):
+            op = olik.LMCOperatorOracle(spec, g['grid_dists'], W, W, [m] * D, ktype='slfm',
+                                        reference_slfm_identity=quirk)
+            got = np.array([op.grid_matvec(v) for v in g['x']])
+            ref = g[name + key]
+            assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
