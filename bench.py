@@ -620,6 +620,17 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
             info['seconds'] = max_over_ranks(info['seconds'], world, dev)
             info.update(n_probes_global=n_probes, scaling='strong', eps=eps,
                         probes_per_rank=-(-n_probes // world))
+            if world == 1 and key == 'nll_grad' and n_probes >= 16 and not args.no_extra:
+                # one rank's share of an 8-way probe split (N / 8 probes + y) timed on THIS
+                # GPU: what the probe sharding can give at most on 8 GPUs -- a projection
+                # (no collective, no second GPU involved), not a measurement of scaling
+                share = n_probes // 8
+                sh = gpu_nll_grad(pe, probes[:share], share, group=None, repeats=1)
+                info['projected_strong_scaling_8gpu'] = {
+                    'kind': 'projection from one GPU', 'probes_per_rank': share,
+                    'seconds_full': info['seconds'], 'seconds_share': sh['seconds'],
+                    'ceiling': info['seconds'] / sh['seconds'],
+                    'iterations_max_share': sh['iterations_max']}
             out[key] = info
     return out
 

@@ -45,6 +45,11 @@ __device__ long long rl_timing_buf[256];
         if (blockIdx.x == (bx) && blockIdx.y == (by) && blockIdx.z == 0 && threadIdx.x == 0) \
             rl_timing_buf[slot] = wall_clock64();                                \
     } while (0)
+// the same under any condition (e.g. one thread of one workgroup at its n-th tile)
+#define RL_STAMP_IF(slot, cond)                                                  \
+    do {                                                                         \
+        if (cond) rl_timing_buf[slot] = wall_clock64();                          \
+    } while (0)
 // census of concurrently resident workgroups of a launch (slot: current count,
 // slot + 1: the most seen): ENTER first thing in the kernel, LEAVE last
 #define RL_CENSUS_ENTER(slot)                                                    \
@@ -61,6 +66,7 @@ __device__ long long rl_timing_buf[256];
 #else
 #define RL_STAMP(slot) do { } while (0)
 #define RL_STAMP_AT(slot, bx, by) do { } while (0)
+#define RL_STAMP_IF(slot, cond) do { } while (0)
 #define RL_CENSUS_ENTER(slot) do { } while (0)
 #define RL_CENSUS_LEAVE(slot) do { } while (0)
 #endif
@@ -108,35 +114,3 @@ struct FftPlan {
     int radix[RL_MAX_PASSES];
 };
 
-// ---------------------------------------------------------------------------
-// fp64 matrix instruction (rl_filter.h, rl_lowrank.h).  GPU: v_mfma_f64_16x16x4_f64;
-// emulator (one fiber per lane, no cross-lane hardware): the same data movement
-// through an LDS scratch of 128 doubles per wave, two workgroup barriers.
-// ---------------------------------------------------------------------------
-#if defined(RL_EMU)
-typedef double sf_v4d __attribute__((vector_size(32)));
-#else
-typedef double sf_v4d __attribute__((ext_vector_type(4)));
-#endif
-
-// D (16 x 16) += A (16 x 4) B (4 x 16), v_mfma_f64_16x16x4_f64: a lane holds
-// A[lane & 15][lane >> 4], B[lane >> 4][lane & 15] and, in d[r], D[(lane >> 4) + 4 r][lane & 15].
-__device__ __forceinline__ void sf_mma(double a, double b, sf_v4d& d, double* scr) {
-#if defined(RL_EMU)
-    const int tid = threadIdx.x, lane = tid & 63;
-    double* w = scr + (size_t)(tid >> 6) * 128;
-    w[lane] = a;
-    w[64 + lane] = b;
-    __syncthreads();
-    for (int r = 0; r < 4; ++r) {
-        const int row = (lane >> 4) + 4 * r, col = lane & 15;
-        double acc = d[r];
-        for (int k = 0; k < 4; ++k) acc += w[row + 16 * k] * w[64 + col + 16 * k];
-        d[r] = acc;
-    }
-    __syncthreads();
-#else
-    (void)scr;
-    d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, d, 0, 0, 0);
-#endif
-}

@@ -25,19 +25,21 @@
 //                  ( state' = rho^G (F0, F1 + G F0, F2 + 2 G F1 + G^2 F0) + chunk ),
 //                  which gives every chunk the state it starts from;
 //   k_sf_apply     per (vector, chunk): the D rows of the chunk in LDS, rank-one
-//                  factors mixed there (u_f = A_f . x); a row is cut into 16-point
-//                  blocks, inside which a filter is a small dense map -- these run
-//                  on the fp64 matrix cores (block Toeplitz part, states a block
-//                  leaves, response to the states it receives), the states are
-//                  chained over the row's 32 blocks with DPP row shifts;
+//                  factors mixed there (u_f = A_f . x); a row is cut into 16 segments
+//                  of 32 points and ONE LANE runs the recurrences of a (row, segment)
+//                  -- every filter of the row, both directions -- over its 32 points
+//                  in registers: once from zero states (what the segment alone
+//                  leaves), these chained over the row's 16 segments with DPP row
+//                  shifts, then again from the right states with the outputs;
 //                  y_a = sum_q kappa_q[a] T_q x_a + sum_f w_f A_f[a] T_q(f) u_f
 //                  assembled in LDS and stored.
 //
-// Every factor a state is multiplied by is a power rho^n that the host computed
-// in long double and rounded once (rho^(16 c) between blocks, rho^G between
-// chunks): no product of 1e5 rounded rho's ever forms, and the form agrees with a
-// long-double evaluation to 1e-15 of |T|_1 |x|_inf (tests; the transform kernels:
-// 1e-13).
+// Every factor a state is carried by ACROSS segments and chunks is a power rho^n
+// that the host computed in long double and rounded once (rho^(32 s) between
+// segments, rho^G between chunks); rho itself is multiplied in at most 32 times in a
+// row (inside a segment): no product of 1e5 rounded rho's ever forms, and the form
+// agrees with a long-double evaluation to a few 1e-15 of |T|_1 |x|_inf (tests; the
+// transform kernels: 1e-13).
 //
 // WHICH tops take this form is decided on the host at set time, from the top row
 // itself (runlmc_hip.hip: sf_detect): the parameters are fitted from four
@@ -48,22 +50,20 @@
 #pragma once
 #include "rl_device.h"
 
-#define RL_SF_G 512                        // grid points per chunk (256 or 512: one or two
-                                           // 16-block halves per row in k_sf_apply; measured
-                                           // at C5 Matern, 256 with three workgroups per CU at
-                                           // 160 registers: apply 0.77 vs 0.76 ms, carries
-                                           // 0.30 vs 0.26, scan 0.17 vs 0.08 -- 512 kept)
+#define RL_SF_G 512                        // grid points per chunk: 16 segments of 32 points,
+                                           // one per lane of a DPP row in k_sf_apply
 #define RL_SF_NH (RL_SF_G / 256)
-#define RL_SF_S 16                         // points per block
-#define RL_SF_LPR (RL_SF_G / RL_SF_S)      // blocks per row of a chunk
-#define RL_SF_PAD (RL_SF_G + RL_SF_LPR)    // doubles per LDS row: one pad per block
+#define RL_SF_S 32                         // points per segment: one lane's share of a row
+#define RL_SF_LPR (RL_SF_G / RL_SF_S)      // segments per row of a chunk (= a DPP row of lanes)
+#define RL_SF_PAD (RL_SF_G + RL_SF_LPR)    // doubles per LDS row: one pad per segment
 #define RL_SF_MAXTOPS 16                   // filter tops per operator at most
 #define RL_SF_TOL 2e-14                    // accepted sum|t - model| / sum|t|
 
-// position of grid point i of a chunk inside its padded LDS row: a block starts
-// 17 doubles after its neighbour, which spreads the 16 columns a matrix fragment
-// reads over the banks (ds_read_b64: (17 * 2 * c) mod 64 are distinct even banks)
-__device__ __forceinline__ int sf_pad(int i) { return i + (i >> 4); }
+// position of grid point i of a chunk inside its padded LDS row: a segment starts
+// 33 doubles after its neighbour and a row 528 after the row before, so that the 32
+// lanes of a half wave -- two rows' 16 segments, each lane at point i of its own
+// segment -- read 32 different banks ((16 a + s + i) mod 32, ds_read_b64)
+__device__ __forceinline__ int sf_pad(int i) { return i + (i >> 5); }
 
 struct SfTop {
     double rho;       // decay per grid step
@@ -96,6 +96,17 @@ __device__ __forceinline__ double sf_step(double (&F)[NS], double rho, double x)
     }
     F[0] = tt + x;
     return tt;
+}
+// the same step on the pair (F0, G = F1 + F0) when NS == 2:  G' = rho G + F0'  -- two
+// instructions instead of three (k_sf_apply; three states: the plain step)
+template <int NS>
+__device__ __forceinline__ void sf_step_sum(double (&F)[NS], double rho, double x) {
+    if constexpr (NS == 2) {
+        F[0] = fma(rho, F[0], x);
+        F[1] = fma(rho, F[1], F[0]);
+    } else {
+        sf_step<NS>(F, rho, x);
+    }
 }
 // V += r M(n) S:  a state S carried n grid steps further (r = rho^n) added to V
 template <int NS>
@@ -363,9 +374,9 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
 }
 
 // ---------------------------------------------------------------------------
-// Cross-lane primitives of k_sf_apply.  GPU: the fp64 matrix instruction and DPP
-// row shifts; emulator (one fiber per lane, no cross-lane hardware): the same
-// data movement through an LDS scratch of 128 doubles per wave.
+// Cross-lane primitives of k_sf_apply.  GPU: DPP row shifts; emulator (one fiber
+// per lane, no cross-lane hardware): the same data movement through an LDS
+// scratch of 128 doubles per wave.
 // ---------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also drains the
 // vector-memory counter, i.e. waits for the next tile's rows that k_sf_apply has in
@@ -400,104 +411,68 @@ __device__ __forceinline__ double sf_row_shift(double v, double* scr) {
     return __hiloint2double(hi, lo);
 #endif
 }
-// value of the LAST (lane 15) or the FIRST (lane 0) lane of the 16-lane row, in every lane of it
-template <bool LAST>
-__device__ __forceinline__ double sf_row_bcast(double v, double* scr) {
-#if defined(RL_EMU)
-    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15;
-    double* w = scr + (size_t)(tid >> 6) * 128;
-    w[lane] = v;
-    __syncthreads();
-    const double r = w[lane - c + (LAST ? 15 : 0)];
-    __syncthreads();
-    return r;
-#else
-    (void)scr;
-    // ds_swizzle, bit-mask mode inside groups of 32: lane' = (lane & 0x10) | (LAST ? 0x0f : 0)
-    constexpr int pat = 0x10 | ((LAST ? 0x0F : 0x00) << 5);
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
-    return __hiloint2double(hi, lo);
-#endif
-}
-
-// value of the lane 16 further / nearer (lane ^ 16): the partner lane row of a pair
-__device__ __forceinline__ double sf_row_partner(double v, double* scr) {
-#if defined(RL_EMU)
-    const int tid = threadIdx.x, lane = tid & 63;
-    double* w = scr + (size_t)(tid >> 6) * 128;
-    w[lane] = v;
-    __syncthreads();
-    const double r = w[lane ^ 16];
-    __syncthreads();
-    return r;
-#else
-    (void)scr;
-    // ds_swizzle, bit-mask mode: and 0x1f, or 0, xor 0x10
-    constexpr int pat = 0x1F | (0x10 << 10);
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), pat);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), pat);
-    return __hiloint2double(hi, lo);
-#endif
-}
 
 // ---------------------------------------------------------------------------
-// k_sf_apply<NS>: Y[v] = filter part of the operator applied to X[v].
+// k_sf_apply<NS, D>: Y[v] = filter part of the operator applied to X[v].
 //   grid (resident workgroups: each walks tiles (chunk, vector))   block 256
-//   LDS: (D + nfac) RL_SF_PAD doubles of rows + NF sizeof(SfBlk) + (D + nfac) 16
-//        (+ 128 doubles per wave for the emulator's cross-lane moves)
+//   LDS: (D + nfac) RL_SF_PAD doubles of rows + the operator's block + the chunk's
+//        incoming states (+ 128 doubles per wave for the emulator's cross-lane moves)
 //
-// A chunk row is a 16 x 32 matrix X (16 consecutive points per column).  Inside
-// a 16-point block everything a filter does is a small dense map, and these maps
-// run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 16 columns at a time:
+// A chunk row of 512 points is cut into 16 SEGMENTS of 32 points, and ONE LANE runs
+// the recurrences of a (row, segment) -- every filter of the row, both directions --
+// over its 32 points held in registers.  The 16 segments of a row sit on the 16
+// lanes of a DPP row:
 //
-//   OUT  = Tblk X                 Tblk[i][k] = sum_j kappa_j[a] t_j(|i - k|): what the
-//                                 block's own points contribute, ALL filters of the
-//                                 row in one 16 x 16 symmetric Toeplitz block;
-//   S    = Wst X                  the 2 NS states per filter the block alone leaves
-//                                 at its last point (causal) / first point (anti-causal);
-//   C    = scan of S over the 32 columns (+ the chunk's incoming states): the state
-//          each block starts from -- DPP row shifts inside the 16 columns of a half,
-//          lane 15 / lane 0 of the row carries it to the other half;
-//   OUT += Rsp C                  Rsp[i][state]: what an incoming state contributes at
-//                                 point i (t_j(n), rho^n (c1 + 2 c2 n), rho^n c2 at
-//                                 n = i + 1 or 16 - i steps, times kappa_j[a]).
+//   A   from zero states: the states each segment alone leaves at its last point
+//       (causal) and at its first point (anti-causal);
+//   B   those states chained over the 16 segments with DPP row shifts (Kogge-Stone,
+//       powers rho^(32 N) from the host) + the chunk's incoming states carried
+//       32 s points on: the state every segment STARTS from;
+//   C   the recurrences again from these states, now with their outputs:
+//       y_i = sum_j kappa_j[a] (c0 (F0 + H0 - x) + c1 (F1 + H1) + c2 (F2 + H2));
+//       one or two filters: both directions in one loop, the 32 results in registers;
+//       five: the causal pass overwrites the row in LDS, the anti-causal one adds to it.
 //
-// The matrix instruction's D layout (row = (lane >> 4) + 4 reg, column = lane & 15)
-// IS its B layout (k = 4 kk + (lane >> 4)): states come out of the second product in
-// the registers the fourth one wants them in, and the scan in between runs along
-// lane & 15 = along DPP rows.  A 16-lane row of lanes owns filter (lane >> 4) of
-// the batch (and filter 4 + (lane >> 4) when NS == 2): registers
-// R = NS (2 (filter / 4) + direction) + k.
-// One wave = one row slot at a time: the D rows of x (every filter, weight
-// kappa_j[a]) and the nfac mixed rows u_f = A_f . x (filter facJ[f], weight 1).
+// At NS = 2 a lane keeps the pair (F0, G = F1 + F0) instead of (F0, F1):
+//   F0' = rho F0 + x,  G' = rho G + F0'   -- two multiply-adds per step, and
+//   c0 F0 + c1 F1 = (c0 - c1) F0 + c1 G   -- two more for the output,
+// so a point costs 2 (A) + 4 (C) vector instructions per filter and direction; no
+// cross-lane traffic but the 16-lane chain in between.  The kernel is bound by the
+// fp64 vector rate (one wave instruction per 2.3 ns and SIMD, tools/valu_rate.hip:
+// 2430 instructions per wave of 64 (row, segment) lanes with five filters), three of
+// the four SIMDs loaded (10 rows x 16 segments = 2.5 waves).
+// (Up to the middle of round 3 the blocks were 16 points and their maps ran on the fp64
+// matrix cores, the chain over 32 blocks per row: 430 matrix instructions of 64 cycles
+// per tile and about as many vector cycles again for the chains -- 0.97 ms per C5
+// Matern product against 0.90 ms for this kernel, which is a third of the code.)
+// Row slots: the D rows of x (every filter, weight kappa_j[a]) and the nfac mixed
+// rows u_f = A_f . x (filter facJ[f], weight 1); y_a = the row's result +
+// sum_f w_f A_f[a] (T u_f), assembled from LDS and stored.
 // ---------------------------------------------------------------------------
 struct SfBlk {                // per filter, staged in LDS
-    double tb[17];            // t(n) = (c0 + c1 n + c2 n^2) rho^n
-    double r1[17];            // rho^n (c1 + 2 c2 n)
-    double r2[17];            // rho^n c2
-    double pw[17];            // rho^n
-    double p16[17];           // rho^(16 c)
+    double rho;               // decay per grid step
+    double c[3];              // t_i = (c0 + c1 i + c2 i^2) rho^i
+    double p32[17];           // rho^(32 s)
 };
 #define RL_SF_BLKD ((int)(sizeof(SfBlk) / sizeof(double)))
 // Everything k_sf_apply needs about the operator, one block of doubles built at
 // set time and copied to LDS by every workgroup:
-//   kappa [NF][D] | facA [nfac][D] | facAW [nfac][D] | facJ [nfac] | block tops
-//   [D + nfac][16] (row slot a: sum_j kappa_j[a] t_j(n); slot D + f: t_facJ[f](n)) | SfBlk [NF]
+//   kappa [NF][D] | facA [nfac][D] | facAW [nfac][D] | facJ [nfac] | SfBlk [NF]
 __host__ __device__ inline int sf_blob_doubles(int NF, int nfac, int D) {
-    return NF * D + 2 * nfac * D + nfac + (D + nfac) * 16 + NF * RL_SF_BLKD;
+    return NF * D + 2 * nfac * D + nfac + NF * RL_SF_BLKD;
 }
 
 #if defined(RL_EMU)
 #define RL_SF_APPLY_ATTR
 #else
-// two workgroups per CU = two waves per SIMD: 256 registers, the next tile's rows among them
-#if RL_SF_G == 256
-#define RL_SF_APPLY_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#else
+// two workgroups per CU = two waves per SIMD: 256 registers (a segment's 32 points,
+// the states of five filters and the next tile's rows among them)
 #define RL_SF_APPLY_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
-#endif
+
+// phase stamps (timing builds): thread 0 of each wave of workgroup 100 at its 21st tile,
+// slots k + 30 wave (tools/sf_phase_timing.py)
+#define RL_SF_STAMP(k) RL_STAMP_IF((k) + 30 * (threadIdx.x >> 6), blockIdx.x == 100 && (threadIdx.x & 63) == 0 && sf_iter == 20)
 
 // requests a tile's D rows (thread tid: point tid + 256 (k % NH) of row k / NH in
 // xr[k], from clamped addresses -- points past the grid are zeroed when the registers
@@ -522,70 +497,185 @@ __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
     for (int k = 0; k < 4; ++k) cr[k] = src[tid + 256 * k < ncin ? tid + 256 * k : ncin - 1];
 }
 
-// A fragment of the states product: state id = 16 mt + col is register R = id / 4 of the
-// lane row id % 4 -> filter fb = id % 4 + 4 (R / (2 NS)) of the batch (j0 + fb, or the one
-// filter jbase of a mixed row), direction (R / NS) % 2, power R % NS; point k = 4 kk + lg
-template <int NS>
-__device__ __forceinline__ double sf_state_weight(const SfBlk* bl, int mt, int kk, int col, int lg,
-                                                  int nfb, int jbase, bool batch) {
-    const int id = 16 * mt + col, R = id >> 2;
-    const int fb = (id & 3) + 4 * (R / (2 * NS)), dir = (R / NS) & 1, ks = R % NS;
-    const bool on = fb < nfb;
-    const int jf = batch ? jbase + (on ? fb : 0) : jbase;
-    const int k = 4 * kk + lg, n = dir == 0 ? 15 - k : k;
-    double w = bl[jf].pw[n];
-    if (ks >= 1) w *= (double)n;
-    if (ks >= 2) w *= (double)n;
-    return on ? w : 0.0;
+// The unrolled recurrences are long straight-line code; left alone the scheduler moves
+// loads and stores across all 32 steps and the allocator then spills hundreds of
+// registers.  A fence every few steps keeps what is live to what the steps need.
+#if defined(RL_EMU)
+#define RL_SF_FENCE(i_)
+#else
+#define RL_SF_FENCE(i_) if (((i_) & 3) == 3) __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// One lane's (row, segment): BF filters j0 .. j0 + BF - 1 of the row over the 32
+// points xv; the result overwrites (FIRST) or adds to cell[0 .. 31].
+//   kw[f * kstride]: weight of filter j0 + f (nullptr: 1);  cin0: the chunk's incoming
+//   states of the row's channels j0 ..., [BF][2][NS];  s: the segment (= lane & 15)
+template <int NS, int BF, bool FIRST>
+__device__ __forceinline__ void sf_task(double* __restrict__ cell, const double (&xv)[RL_SF_S],
+                                        bool live, int s, const SfBlk* __restrict__ bl,
+                                        int j0, const double* __restrict__ kw, int kstride,
+                                        const double* __restrict__ cin0, double* scr) {
+    constexpr int S = RL_SF_S;
+    double rho[BF], cw[BF][NS], F[BF][NS], H[BF][NS], c0sum = 0.0;
+#pragma unroll
+    for (int f = 0; f < BF; ++f) {
+        rho[f] = bl[j0 + f].rho;
+        const double k = kw ? kw[f * kstride] : 1.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            cw[f][q] = k * bl[j0 + f].c[q];
+            F[f][q] = 0.0;
+            H[f][q] = 0.0;
+        }
+        if constexpr (NS == 2) {
+            c0sum += cw[f][0];
+            cw[f][0] -= cw[f][1];       // c0 F0 + c1 F1 = (c0 - c1) F0 + c1 G
+        }
+    }
+    // A: what the segment alone leaves -- the causal states over ascending points and the
+    // anti-causal ones over descending points in the same loop: 2 BF independent chains
+    // (a dependent fp64 instruction issues every 6 ns, an independent one every 2.3:
+    // measured, tools/valu_rate.hip)
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+#pragma unroll
+        for (int f = 0; f < BF; ++f) {
+            sf_step_sum<NS>(F[f], rho[f], xv[i]);
+            sf_step_sum<NS>(H[f], rho[f], xv[S - 1 - i]);
+        }
+        RL_SF_FENCE(i);
+    }
+    // B: chained over the row's 16 segments -> the state the segment starts from
+#pragma unroll
+    for (int f = 0; f < BF; ++f) {
+        const double* p32 = bl[j0 + f].p32;
+        const double r1_ = p32[1], r2_ = p32[2], r4_ = p32[4], r8_ = p32[8];
+        const double rpF = p32[s], rpB = p32[15 - s];
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            double V[NS], cin[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                V[q] = dir == 0 ? F[f][q] : H[f][q];
+                cin[q] = cin0[(f * 2 + dir) * NS + q];
+            }
+            if constexpr (NS == 2) V[1] -= V[0];             // (F0, G) -> (F0, F1)
+#define RL_SF_SCAN_STEP(N_, r_)                                                              \
+    {                                                                                        \
+        double Sv[NS];                                                                       \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q)                                       \
+            Sv[q] = dir == 0 ? sf_row_shift<N_, true>(V[q], scr)                             \
+                             : sf_row_shift<N_, false>(V[q], scr);                           \
+        sf_carry<NS>(V, Sv, r_, (double)(S * N_));                                           \
+    }
+            RL_SF_SCAN_STEP(1, r1_)
+            RL_SF_SCAN_STEP(2, r2_)
+            RL_SF_SCAN_STEP(4, r4_)
+            RL_SF_SCAN_STEP(8, r8_)
+#undef RL_SF_SCAN_STEP
+            double Xh[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q)
+                Xh[q] = dir == 0 ? sf_row_shift<1, true>(V[q], scr) : sf_row_shift<1, false>(V[q], scr);
+            if (dir == 0) sf_carry<NS>(Xh, cin, rpF, (double)(S * s));
+            else sf_carry<NS>(Xh, cin, rpB, (double)(S * (15 - s)));
+            if constexpr (NS == 2) Xh[1] += Xh[0];           // back to (F0, G)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                if (dir == 0) F[f][q] = Xh[q];
+                else H[f][q] = Xh[q];
+            }
+        }
+    }
+    if constexpr (BF <= 2) {
+        // C, few filters: the causal pass (the point itself included) over ascending points
+        // and the anti-causal one (excluded) over descending points, interleaved like A; the
+        // results of the 32 points collect in registers
+        double yv[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) yv[i] = FIRST ? 0.0 : cell[i];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int j = S - 1 - i;
+            double ya = 0.0, yb = 0.0;
+            if constexpr (NS == 2) yb = -c0sum * xv[j];
+#pragma unroll
+            for (int f = 0; f < BF; ++f) {
+                sf_step_sum<NS>(F[f], rho[f], xv[i]);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) ya = fma(cw[f][q], F[f][q], ya);
+                if constexpr (NS == 2) {
+                    // the states AFTER the step hold the point itself: H0' - x and G' - H0' are
+                    // the excluded ones:  c0 (H0' - x) + c1 (G' - H0') = cw0 H0' + cw1 G' - c0 x
+                    sf_step_sum<2>(H[f], rho[f], xv[j]);
+                    yb = fma(cw[f][0], H[f][0], yb);
+                    yb = fma(cw[f][1], H[f][1], yb);
+                } else {
+                    const double tt = sf_step<NS>(H[f], rho[f], xv[j]);
+                    yb = fma(cw[f][0], tt, yb);
+#pragma unroll
+                    for (int q = 1; q < NS; ++q) yb = fma(cw[f][q], H[f][q], yb);
+                }
+            }
+            yv[i] += ya;
+            yv[j] += yb;
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+            if (live) cell[i] = yv[i];
+    } else {
+        // C, five filters (no registers for 32 results): the causal pass writes the row in
+        // LDS, the anti-causal one adds to it; two partial sums per point, so that the
+        // ten accumulations of a step do not form one dependent chain
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            double ya = FIRST ? 0.0 : cell[i], yb = 0.0;
+#pragma unroll
+            for (int f = 0; f < BF; ++f) {
+                sf_step_sum<NS>(F[f], rho[f], xv[i]);
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    if (f & 1) yb = fma(cw[f][q], F[f][q], yb);
+                    else ya = fma(cw[f][q], F[f][q], ya);
+                }
+            }
+            if (live) cell[i] = ya + yb;
+            RL_SF_FENCE(i);
+        }
+#pragma unroll
+        for (int i = S - 1; i >= 0; --i) {
+            double ya = cell[i], yb = 0.0;
+            
+            ya = fma(-c0sum, xv[i], ya);
+#pragma unroll
+            for (int f = 0; f < BF; ++f) {
+                sf_step_sum<2>(H[f], rho[f], xv[i]);
+                if (f & 1) {
+                    yb = fma(cw[f][0], H[f][0], yb);
+                    yb = fma(cw[f][1], H[f][1], yb);
+                } else {
+                    ya = fma(cw[f][0], H[f][0], ya);
+                    ya = fma(cw[f][1], H[f][1], ya);
+                }
+            }
+            if (live) cell[i] = ya + yb;
+            RL_SF_FENCE(S - 1 - i);
+        }
+    }
 }
 
-template <int NS, int D>        // (D at compile time: the row loops, the 2 D registers that
-                                // hold the next tile's rows and their predicates are static --
-                                // with a runtime D the kernel spilled 128 scalar registers)
-__global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
-k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m, int NF,
-           int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
-    constexpr int G = RL_SF_G, PAD = RL_SF_PAD, NH = RL_SF_NH, XR = NH * D;
-    constexpr int BF = NS == 2 ? 8 : 4;                      // filters per batch
-    RL_SMEM(smem);
-    const int nslots = D + nfac, nchan = D * NF + nfac, nblob = sf_blob_doubles(NF, nfac, D);
-    double* xs = reinterpret_cast<double*>(smem);            // [D][PAD]: x, then the rows of y
-    double* us = xs + (size_t)D * PAD;                       // [nfac][PAD]: u_f, then T u_f
-    double* tab = us + (size_t)nfac * PAD;                   // the operator's block (see above)
-    const double* kap = tab;
-    const double* facA = kap + NF * D;
-    const double* facAW = facA + nfac * D;
-    const double* facJ = facAW + nfac * D;
-    const double* tcomb = facJ + nfac;
-    const SfBlk* bl = reinterpret_cast<const SfBlk*>(tcomb + nslots * 16);
-    double* cinl = tab + nblob;                              // [nchan][2][NS]: the chunk's incoming states
-    double* scr = cinl + (size_t)nchan * 2 * NS;             // emulator only
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
-    const int nwaves = nthr >> 6, lg = lane >> 4, col = lane & 15;
-    RL_CENSUS_ENTER(120);
-    // the operator's block -> LDS, once per workgroup
-    for (int e = tid; e < nblob; e += nthr) tab[e] = blob[e];
-    sf_lds_barrier();
-    double wstx[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            wstx[mt][kk] = sf_state_weight<NS>(
-                bl, mt, kk, col, lg, (NS == 2 && (NF & 3) == 1) ? (NF < 4 ? NF : 4) : (NF < BF ? NF : BF), 0,
-                true);
-    // A workgroup walks tiles (chunk, vector) tile0, tile0 + gridDim.x, ...; the NEXT
-    // tile's rows and incoming states are requested into registers before the current
-    // tile is worked on, so that the memory round trip hides behind the matrix work.
-    // (256 threads: thread tid holds point tid (and tid + 256) of every row)
-    const int nch = (m + G - 1) / G, ntiles = nch * nvec, ncin = nchan * 2 * NS;
-    double xr[XR], cr[4];
-    int tile = blockIdx.x;
-    if (tile < ntiles) sf_request<XR>(xr, cr, X, Cin, tile, nch, nvec, D, m, ncin, tid);
-    for (; tile < ntiles; tile += gridDim.x) {
-    const int chunk = tile % nch, v = tile / nch, g0 = chunk * G;
-    RL_STAMP_AT(100, 100, 0);
-    // registers -> LDS (the rows padded, see sf_pad), then request the next tile
+// a tile's rows and incoming states from the registers they were requested into to LDS
+// (the rows padded, see sf_pad; points past the grid zeroed), then the mixed rows
+// u_f = sum_b A_f[b] x_b: a thread takes points tid and tid + 256, the D values of a
+// point in registers; the weights are broadcast reads of the block in LDS (scalar loads
+// from global memory measured slower: 4.8 against 2.8 us per tile).  A thread touches
+// ITS OWN columns only -- the ones it also assembles y from --, so no barrier is needed
+// between the assembly of one tile, this, and the mixed rows: one at the end.
+template <int D, int XR>
+__device__ __forceinline__ void sf_stage(const double (&xr)[XR], const double (&cr)[4], double* xs,
+                                         double* us, double* cinl, const double* facA, int nfac,
+                                         int ncin, int g0, int m, int tid, int sf_iter) {
+    constexpr int PAD = RL_SF_PAD, NH = RL_SF_NH;
 #pragma unroll
     for (int k = 0; k < XR; ++k)
         if (k / NH < D)
@@ -594,13 +684,8 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < ncin) cinl[tid + 256 * k] = cr[k];
-    sf_lds_barrier();
-    RL_STAMP_AT(101, 100, 0);
-    // mixed rows u_f = sum_b A_f[b] x_b: a thread takes points tid and tid + 256, the D
-    // values of a point in registers; the weights are broadcast reads of the block in LDS
-    // (scalar loads from global memory measured slower: 4.8 against 2.8 us per tile)
+    RL_SF_STAMP(101);
     if (nfac > 0) {
-        const double* gA = facA;
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
             const int pi = sf_pad(tid + 256 * half);
@@ -611,7 +696,7 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
 #pragma unroll
             for (int b = 0; b < 16; ++b) xb[b] = xs[(size_t)(b < D ? b : D - 1) * PAD + pi];
             for (int f = 0; f < nfac; ++f) {
-                const double* ar = gA + f * D;
+                const double* ar = facA + f * D;
                 double u = 0.0;
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
@@ -621,281 +706,118 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
                 us[(size_t)f * PAD + pi] = u;
             }
         }
-        sf_lds_barrier();
     }
-    // the next tile's rows: requested now, they arrive while the matrix cores work
-    if (tile + (int)gridDim.x < ntiles)
-        sf_request<XR>(xr, cr, X, Cin, tile + gridDim.x, nch, nvec, D, m, ncin, tid);
-    RL_STAMP_AT(102, 100, 0);
-    // row slots, one per wave and pass (idle waves repeat a slot and do not store).  The
-    // emulator's cross-lane moves are workgroup barriers, so there the rows of x and the
-    // mixed rows (which run different numbers of them) take separate passes.
-#if defined(RL_EMU)
-    const int xpasses = (D + nwaves - 1) / nwaves, upasses = (nfac + nwaves - 1) / nwaves;
-    const int npasses = xpasses + upasses;
-#else
-    const int npasses = (nslots + nwaves - 1) / nwaves;
-#endif
-    for (int pass = 0; pass < npasses; ++pass) {
-        RL_STAMP_AT(103 + (pass < 6 ? pass : 6), 100, 0);
-#if defined(RL_EMU)
-        const bool xpass = pass < xpasses;
-        const int sraw = xpass ? pass * nwaves + wave : D + (pass - xpasses) * nwaves + wave;
-        const int send = xpass ? D : nslots;
-#else
-        const int sraw = pass * nwaves + wave, send = nslots;
-#endif
-        const int slot = sraw < send ? sraw : send - 1;
-        const bool xrow = slot < D;
-        const int jfix = xrow ? 0 : (int)facJ[xrow ? 0 : slot - D];    // the mixed row's filter
-        double* row = (xrow ? xs + (size_t)slot * PAD : us + (size_t)(slot - D) * PAD);
-        // B fragments of X: point 4 kk + lg of column col (+ 16 per half)
-        double XB[NH][4];
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) XB[h][kk] = row[(16 * h + col) * 17 + 4 * kk + lg];
-        sf_v4d OUT[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h) OUT[h] = sf_v4d{0.0, 0.0, 0.0, 0.0};
-        // filters of the slot, in batches of BF
-        // (NS == 2 and one filter over a multiple of four: batches of four, and the last
-        // filter alone in the PACKED layout below)
-        const int nf_slot = xrow ? NF : 1;
-        const int bf = (NS == 2 && (nf_slot & 3) == 1) ? 4 : BF;
-        for (int j0 = 0; j0 < nf_slot; j0 += bf) {
-            const int nfb = nf_slot - j0 < bf ? nf_slot - j0 : bf;
-            const bool two = nfb > 4 || NS == 3;             // second tile of states in use
-            if (NS == 2 && nfb == 1) {
-                // ---- ONE filter, packed: its four states (F0, F1, H0, H1) sit on the four
-                // lane rows of a single register -- state lg of column col --, so the scan
-                // below moves one value per lane (all 64 lanes busy) instead of pairs on a
-                // quarter of the lanes, and the response is one matrix instruction per half.
-                const int jf = xrow ? j0 : jfix;
-                const int pdir = lg >> 1, pks = lg & 1;
-                sf_v4d SP[NH];
-#pragma unroll
-                for (int h = 0; h < NH; ++h) SP[h] = sf_v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    // A fragment: state id = col (< 4), point k = 4 kk + lg
-                    const int k = 4 * kk + lg, adir = (col >> 1) & 1, aks = col & 1;
-                    const int n = adir == 0 ? 15 - k : k;
-                    double w = bl[jf].pw[n];
-                    if (aks) w *= (double)n;
-                    w = col < 4 ? w : 0.0;
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) sf_mma(w, XB[h][kk], SP[h], scr);
-                }
-                if (j0 == 0) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int k = 4 * kk + lg, dd = col > k ? col - k : k - col;
-                        const double ta = tcomb[slot * 16 + dd];
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) sf_mma(ta, XB[h][kk], OUT[h], scr);
-                    }
-                }
-                const int chan = xrow ? slot * NF + jf : D * NF + (slot - D);
-                const double* p16 = bl[jf].p16;
-                const double c0 = cinl[(chan * 2 + pdir) * NS], c1 = cinl[(chan * 2 + pdir) * NS + 1];
-                const int steps = pdir == 0 ? col : 15 - col;
-                const double rp = p16[steps], np = 16.0 * steps;
-                const double kw = xrow ? kap[jf * D + slot] : 1.0;
-                const int nr = pdir == 0 ? col + 1 : 16 - col;
-                const double wr = kw * (pks == 0 ? bl[jf].tb[nr] : bl[jf].r1[nr]);
-                // scalar first-order scans: the second state rides as  q = F1 -/+ 16 c F0
-                // (F1(c) = Q(c) + 16 c F0(c) causal, H1(c) = Q(c) - 16 c H0(c) anti-causal)
-                double v[NH], x[NH];
-                const double cpre = pks ? (pdir == 0 ? -16.0 * col : 16.0 * col) : 0.0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    v[h] = SP[h][0];
-                    v[h] = fma(cpre, sf_row_partner(v[h], scr), v[h]);
-                }
-#define RL_SF_PSCAN(N_)                                                                      \
-    _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                         \
-        const double up_ = sf_row_shift<N_, true>(v[h], scr);                                \
-        const double dn_ = sf_row_shift<N_, false>(v[h], scr);                               \
-        v[h] = fma(p16[N_], pdir == 0 ? up_ : dn_, v[h]);                                    \
-    }
-                RL_SF_PSCAN(1)
-                RL_SF_PSCAN(2)
-                RL_SF_PSCAN(4)
-                RL_SF_PSCAN(8)
-#undef RL_SF_PSCAN
-                // exclusive values, back to true states: X1 = q +/- 16 (c -/+ 1) X0
-                const double cpost = pks ? (pdir == 0 ? 16.0 * (col - 1) : -16.0 * (col + 1)) : 0.0;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const double up_ = sf_row_shift<1, true>(v[h], scr);
-                    const double dn_ = sf_row_shift<1, false>(v[h], scr);
-                    x[h] = pdir == 0 ? up_ : dn_;
-                    const double edge = pdir == 0 ? (col == 0 ? 0.0 : 1.0) : (col == 15 ? 0.0 : 1.0);
-                    x[h] = fma(cpost * edge, sf_row_partner(x[h], scr), x[h]);
-                }
-                // what enters from outside: the chunk's state (c0, c1), carried `steps` blocks
-                // on -- a lane takes its own component of  rho^n (s0, s1 + n s0)
-                const double cnear = rp * (pks ? fma(np, c0, c1) : c0);
-                if constexpr (NH == 2) {
-                    // near half's total (true state) + the chunk's state 256 points on
-                    double t = pdir == 0 ? sf_row_bcast<true>(v[0], scr) : sf_row_bcast<false>(v[1], scr);
-                    double tp = sf_row_partner(t, scr);
-                    if (pdir == 0 && pks) t = fma(240.0, tp, t);        // (column 15: Q + 16 * 15 F0)
-                    t = fma(p16[16], pks ? fma(256.0, c0, c1) : c0, t);
-                    tp = sf_row_partner(t, scr);
-                    const double cfar = rp * (pks ? fma(np, tp, t) : t);
-                    x[0] += pdir == 0 ? cnear : cfar;
-                    x[1] += pdir == 0 ? cfar : cnear;
-                } else {
-                    x[0] += cnear;
-                }
-                // response: A fragment = point col, state id = lg
-#pragma unroll
-                for (int h = 0; h < NH; ++h) sf_mma(wr, x[h], OUT[h], scr);
-                continue;
-            }
-            // --- S = Wst X.  A fragment: state id = 16 mt + col -> lane row id % 4, register id / 4
-            // (rows of x with all their filters in one batch: the weights do not depend on
-            // the row and were computed once, before the first tile)
-            sf_v4d S[NH][2];
-#pragma unroll
-            for (int h = 0; h < NH; ++h) S[h][0] = S[h][1] = sf_v4d{0.0, 0.0, 0.0, 0.0};
-            double wst[2][4];
-            if (xrow && j0 == 0) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) wst[mt][kk] = wstx[mt][kk];
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        wst[mt][kk] = sf_state_weight<NS>(bl, mt, kk, col, lg, nfb, xrow ? j0 : jfix,
-                                                          xrow);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                if (mt == 1 && !two) break;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) sf_mma(wst[mt][kk], XB[h][kk], S[h][mt], scr);
-                }
-            }
-            if (j0 == 0) {
-                // the block's own points: OUT = Tblk X (independent of the states: the matrix
-                // cores work on it while the scan below runs on the vector pipe)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * kk + lg, dd = col > k ? col - k : k - col;
-                    const double ta = tcomb[slot * 16 + dd];
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) sf_mma(ta, XB[h][kk], OUT[h], scr);
-                }
-            }
-            // --- scan of S over the 32 columns: the state each block STARTS from (register
-            // R = NS (2 fs + dir) + k of a lane).  This lane's filters: fb = lg (+ 4)
-#pragma unroll
-            for (int fs = 0; fs < (NS == 2 ? 2 : 1); ++fs) {
-                if (fs == 1 && !two) break;
-                const int fb = lg + 4 * fs;
-                const bool on = fb < nfb;
-                const int jf = xrow ? j0 + (on ? fb : 0) : jfix;
-                const int chan = xrow ? slot * NF + jf : D * NF + (slot - D);
-                const double* p16 = bl[jf].p16;
-                const int stepsF = col, stepsB = 15 - col;
-                const double r1_ = p16[1], r2_ = p16[2], r4_ = p16[4], r8_ = p16[8], r16_ = p16[16];
-                const double rpF = p16[stepsF], rpB = p16[stepsB];
-#pragma unroll
-                for (int dir = 0; dir < 2; ++dir) {
-                    const int R0 = NS * (2 * fs + dir);
-                    double V[NH][NS], cin[NS];
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        cin[k] = on ? cinl[(chan * 2 + dir) * NS + k] : 0.0;
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) V[h][k] = S[h][(R0 + k) >> 2][(R0 + k) & 3];
-                    }
-                    // (response weights of the group: what a state entering a block contributes at
-                    // point col of it -- n = col + 1 steps on for the causal state, 16 - col for
-                    // the anti-causal one; requested before the scan)
-                    double wr[NS];
-                    {
-                        const int n = dir == 0 ? col + 1 : 16 - col;
-                        const double kw = on ? (xrow ? kap[jf * D + slot] : 1.0) : 0.0;
-                        wr[0] = kw * bl[jf].tb[n];
-                        wr[1] = kw * bl[jf].r1[n];
-                        if constexpr (NS == 3) wr[2] = kw * bl[jf].r2[n];
-                    }
-                    // inclusive scan inside each half (zeros shift in at the row's end)
-#define RL_SF_SCAN_STEP(N_, r_)                                                              \
-    {                                                                                        \
-        double Sv[NH][NS];                                                                   \
-        _Pragma("unroll") for (int h = 0; h < NH; ++h)                                       \
-            _Pragma("unroll") for (int k = 0; k < NS; ++k)                                   \
-                Sv[h][k] = dir == 0 ? sf_row_shift<N_, true>(V[h][k], scr)                   \
-                                    : sf_row_shift<N_, false>(V[h][k], scr);                 \
-        _Pragma("unroll") for (int h = 0; h < NH; ++h)                                       \
-            sf_carry<NS>(V[h], Sv[h], r_, 16.0 * N_);                                        \
-    }
-                    RL_SF_SCAN_STEP(1, r1_)
-                    RL_SF_SCAN_STEP(2, r2_)
-                    RL_SF_SCAN_STEP(4, r4_)
-                    RL_SF_SCAN_STEP(8, r8_)
-#undef RL_SF_SCAN_STEP
-                    // exclusive value; with two halves: the near half's total, carried into the
-                    // far half with the chunk's incoming state 256 points on
-                    double Xh[NH][NS];
-#pragma unroll
-                    for (int k = 0; k < NS; ++k)
-#pragma unroll
-                        for (int h = 0; h < NH; ++h)
-                            Xh[h][k] = dir == 0 ? sf_row_shift<1, true>(V[h][k], scr)
-                                                : sf_row_shift<1, false>(V[h][k], scr);
-                    // (blocks between the half's edge and this one: col / 15 - col)
-                    if constexpr (NH == 2) {
-                        double T[NS];
-#pragma unroll
-                        for (int k = 0; k < NS; ++k)
-                            // causal: total of half 0 (its lane 15); anti-causal: of half 1 (lane 0)
-                            T[k] = dir == 0 ? sf_row_bcast<true>(V[0][k], scr)
-                                            : sf_row_bcast<false>(V[NH - 1][k], scr);
-                        sf_carry<NS>(T, cin, r16_, 256.0);
-                        if (dir == 0) {
-                            sf_carry<NS>(Xh[0], cin, rpF, 16.0 * stepsF);
-                            sf_carry<NS>(Xh[NH - 1], T, rpF, 16.0 * stepsF);
-                        } else {
-                            sf_carry<NS>(Xh[NH - 1], cin, rpB, 16.0 * stepsB);
-                            sf_carry<NS>(Xh[0], T, rpB, 16.0 * stepsB);
-                        }
-                    } else {
-                        if (dir == 0) sf_carry<NS>(Xh[0], cin, rpF, 16.0 * stepsF);
-                        else sf_carry<NS>(Xh[0], cin, rpB, 16.0 * stepsB);
-                    }
-                    // --- OUT += Rsp C for this group's registers R0 .. R0 + NS - 1, at once:
-                    // the matrix cores work on it while the next group's scan runs on the
-                    // vector pipe.  A fragment: point col, state id = 4 R + lg
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) sf_mma(wr[k], Xh[h][k], OUT[h], scr);
-                    }
-                }
-            }
-        }
-        // the slot's result replaces the row: point lg + 4 r of column col
-        if (sraw < send) {
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) row[(16 * h + col) * 17 + lg + 4 * r] = OUT[h][r];
-        }
-    }
-    RL_STAMP_AT(110, 100, 0);
     sf_lds_barrier();
-    RL_STAMP_AT(111, 100, 0);
+    RL_SF_STAMP(102);
+}
+
+template <int NS, int D>        // (D at compile time: the row loops, the 2 D registers that
+                                // hold the next tile's rows and their predicates are static --
+                                // with a runtime D the kernel spilled 128 scalar registers)
+__global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
+k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m, int NF,
+           int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
+    constexpr int G = RL_SF_G, PAD = RL_SF_PAD, NH = RL_SF_NH, XR = NH * D, S = RL_SF_S;
+    RL_SMEM(smem);
+    const int nchan = D * NF + nfac, nblob = sf_blob_doubles(NF, nfac, D);
+    double* xs = reinterpret_cast<double*>(smem);            // [D][PAD]: x, then the rows of y
+    double* us = xs + (size_t)D * PAD;                       // [nfac][PAD]: u_f, then T u_f
+    double* tab = us + (size_t)nfac * PAD;                   // the operator's block (see above)
+    const double* kap = tab;
+    const double* facA = kap + NF * D;
+    const double* facAW = facA + nfac * D;
+    const double* facJ = facAW + nfac * D;
+    const SfBlk* bl = reinterpret_cast<const SfBlk*>(facJ + nfac);
+    double* cinl = tab + nblob;                              // [nchan][2][NS]: the chunk's incoming states
+    double* scr = cinl + (size_t)nchan * 2 * NS;             // emulator only
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int nwaves = nthr >> 6;
+    RL_CENSUS_ENTER(120);
+    // the operator's block -> LDS, once per workgroup
+    for (int e = tid; e < nblob; e += nthr) tab[e] = blob[e];
+    sf_lds_barrier();
+    // A workgroup walks tiles (chunk, vector) tile0, tile0 + gridDim.x, ...  The NEXT
+    // tile's rows and incoming states are requested into registers once the recurrences
+    // over the rows of x are done (these need the registers themselves: requested
+    // earlier, the rows were spilled one by one, every spill waiting for its load);
+    // they arrive during the mixed rows, the assembly and the other resident
+    // workgroup's recurrences.  A request and its use sit in ONE loop iteration.
+    // (256 threads: thread tid holds point tid (and tid + 256) of every row)
+    const int nch = (m + G - 1) / G, ntiles = nch * nvec, ncin = nchan * 2 * NS;
+    int tile = blockIdx.x, sf_iter = -1;
+    if (tile < ntiles) {
+        double xr[XR], cr[4];
+        sf_request<XR>(xr, cr, X, Cin, tile, nch, nvec, D, m, ncin, tid);
+        RL_SF_STAMP(100);
+        sf_stage<D, XR>(xr, cr, xs, us, cinl, facA, nfac, ncin, (tile % nch) * G, m, tid, sf_iter);
+    }
+    while (tile < ntiles) {
+    const int chunk = tile % nch, v = tile / nch, g0 = chunk * G;
+    ++sf_iter;
+    RL_SF_STAMP(99);
+    // (row, segment) tasks, one per lane: the rows of x with all their filters (in batches
+    // of five (NS = 2 only: three states of five filters in both directions do not fit the
+    // registers), two or one), then the mixed rows with their one filter.  A wave without
+    // a live task skips the pass (the emulator's cross-lane moves are workgroup barriers:
+    // there every wave runs every pass).
+    for (int t0 = 0; t0 < D * 16; t0 += nthr) {
+#if !defined(RL_EMU)
+        if (t0 + wave * 64 >= D * 16) break;
+#endif
+        const int t = t0 + tid, araw = t >> 4, s = t & 15;
+#if defined(RL_EMU)
+        const bool live = araw < D;             // (idle lanes walk a clamped row and do not store)
+#else
+        if (araw >= D) continue;                // (whole DPP rows of lanes: the chains stay intact)
+        constexpr bool live = true;
+#endif
+        const int a = live ? araw : D - 1;
+        double* cell = xs + (size_t)a * PAD + s * (S + 1);
+        double xv[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) xv[i] = cell[i];
+        for (int j = 0; j < NF;) {
+            const int b = (NS == 2 && NF - j >= 5) ? 5 : (NF - j >= 2 ? 2 : 1);
+            const double* kw = kap + j * D + a;
+            const double* cin0 = cinl + (size_t)(a * NF + j) * 2 * NS;
+            if (j == 0) {
+                if (NS == 2 && b == 5) sf_task<2, 5, true>(cell, xv, live, s, bl, j, kw, D, cin0, scr);
+                else if (b == 2) sf_task<NS, 2, true>(cell, xv, live, s, bl, j, kw, D, cin0, scr);
+                else sf_task<NS, 1, true>(cell, xv, live, s, bl, j, kw, D, cin0, scr);
+            } else {
+                if (NS == 2 && b == 5) sf_task<2, 5, false>(cell, xv, live, s, bl, j, kw, D, cin0, scr);
+                else if (b == 2) sf_task<NS, 2, false>(cell, xv, live, s, bl, j, kw, D, cin0, scr);
+                else sf_task<NS, 1, false>(cell, xv, live, s, bl, j, kw, D, cin0, scr);
+            }
+            j += b;
+        }
+    }
+    RL_SF_STAMP(103);
+    const int next = tile + (int)gridDim.x;
+    double xr[XR], cr[4];
+    if (next < ntiles) sf_request<XR>(xr, cr, X, Cin, next, nch, nvec, D, m, ncin, tid);
+    // (the waves the rows of x left idle share the mixed rows among them, in rounds;
+    // every wave when none was idle)
+    const int xw = (D * 16 + 63) / 64, uw0 = xw < nwaves ? xw : 0, nuw = nwaves - uw0;
+    for (int t0 = 0; t0 < nfac * 16; t0 += nuw * 64) {
+        const int t = t0 + (wave - uw0) * 64 + lane, fraw = t >> 4, s = t & 15;
+#if defined(RL_EMU)
+        const bool live = wave >= uw0 && fraw < nfac;
+#else
+        if (wave < uw0 || fraw >= nfac) continue;
+        constexpr bool live = true;
+#endif
+        const int f = live ? fraw : 0;
+        double* cell = us + (size_t)f * PAD + s * (S + 1);
+        double xv[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) xv[i] = cell[i];
+        sf_task<NS, 1, true>(cell, xv, live, s, bl, (int)facJ[f], nullptr, 0,
+                             cinl + (size_t)(D * NF + f) * 2 * NS, scr);
+    }
+    RL_SF_STAMP(110);
+    sf_lds_barrier();
+    RL_SF_STAMP(111);
     // y_a = diagonal part + sum_f w_f A_f[a] (T u_f): a thread takes points tid and
     // tid + 256, the D results of a point in registers, all stores of a point issued
     // together
@@ -921,8 +843,12 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
             }
         }
     }
-    RL_STAMP_AT(112, 100, 0);
-    sf_lds_barrier();         // (the next tile overwrites the rows)
+    RL_SF_STAMP(112);
+    tile = next;
+    if (tile < ntiles) {
+        RL_SF_STAMP(100);
+        sf_stage<D, XR>(xr, cr, xs, us, cinl, facA, nfac, ncin, (tile % nch) * G, m, tid, sf_iter);
+    }
     }
     RL_CENSUS_LEAVE(120);
 }

@@ -1543,14 +1543,9 @@ static void sf_device_top(const SfFit& f, SfTop* tp, SfBlk* bk, double* pw) {
     for (int k = 0; k < 3; ++k) tp->c[k] = (double)f.c[k];
     tp->rG = (double)expl(-f.ah * RL_SF_G);
     for (int j = 0; j <= RL_SF_G; ++j) pw[j] = (double)expl(-f.ah * j);
-    for (int n = 0; n <= 16; ++n) {
-        const long double r = expl(-f.ah * n), nn = (long double)n;
-        bk->tb[n] = (double)((f.c[0] + (f.c[1] + f.c[2] * nn) * nn) * r);
-        bk->r1[n] = (double)((f.c[1] + 2.0L * f.c[2] * nn) * r);
-        bk->r2[n] = (double)(f.c[2] * r);
-        bk->pw[n] = (double)r;
-        bk->p16[n] = (double)expl(-f.ah * 16 * n);
-    }
+    bk->rho = tp->rho;
+    for (int k = 0; k < 3; ++k) bk->c[k] = tp->c[k];
+    for (int n = 0; n <= 16; ++n) bk->p32[n] = (double)expl(-f.ah * RL_SF_S * n);
 }
 
 static int sf_nchunks(const rl_gridop* g) { return (g->m + RL_SF_G - 1) / RL_SF_G; }
@@ -1606,18 +1601,16 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
     const int ncd = 2 * (D * sp.NF + sp.nfac);
     RL_LAUNCH((k_sf_scan<NS>), dim3((ncd + 7) / 8, nvec), dim3(256), 256 * NS * sizeof(double),
               st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin);
-    // one wave per row slot at a time; eight waves = two per SIMD, two workgroups per CU at
-    // 128 registers.  (A workgroup of five waves puts two on the first SIMD, and a second
-    // workgroup then finds no room there: measured 2.8 ms per C5 product, one workgroup per CU.)
+    // persistent workgroups of four waves, two per CU (256 registers a lane: a segment's
+    // 32 points and the states of five filters; the tile's LDS allows two at C5), each
+    // walking every (2 x CUs)-th tile.  (A workgroup of five waves puts two on the first
+    // SIMD, and a second workgroup then finds no room there.)
     const int waves = 4;
-    // persistent workgroups, two per CU (what their LDS tiles allow at C5), each walking
-    // every (2 x CUs)-th tile with the next tile's loads in flight
 #if defined(RL_EMU)
     const int ntiles = nch * nvec, resident = 7;            // (so that tests walk several tiles)
 #else
-    // (resident workgroups per CU: what the tile's LDS allows, at most three)
     const size_t tile_lds = sf_apply_lds(D, sp.nfac, sp.NF, 256);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / tile_lds));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / tile_lds));
     const int ntiles = nch * nvec, resident = per_cu * RL_LR_CUS;
 #endif
 #define RL_SF_APPLY(D_)                                                                      \
@@ -1978,14 +1971,6 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
                 for (int e = 0; e < nfb * D; ++e) *o++ = fab[e];
                 for (int e = 0; e < nfb * D; ++e) *o++ = fawb[e];
                 for (int f = 0; f < nfb; ++f) *o++ = (double)fjb[f];
-                for (int a = 0; a < D; ++a)
-                    for (int n = 0; n < 16; ++n) {
-                        long double t = 0.0L;
-                        for (int j = 0; j < NFb; ++j) t += (long double)kapb[(size_t)j * D + a] * bk[j].tb[n];
-                        *o++ = (double)t;
-                    }
-                for (int f = 0; f < nfb; ++f)
-                    for (int n = 0; n < 16; ++n) *o++ = bk[fjb[f]].tb[n];
                 std::memcpy(o, bk, (size_t)NFb * sizeof(SfBlk));
             };
             std::vector<double> blob(sf_blob_doubles(nfilt, nf, D));

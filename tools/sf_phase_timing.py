@@ -22,10 +22,14 @@ buf = (ctypes.c_longlong * 256)()
 lib.rl_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.rl_debug_timing(buf, 256) == 0
 t = np.array(list(buf), dtype=np.float64) / 100.0        # 100 MHz -> microseconds
-names = {100: 'start', 101: 'x tile + tables in LDS', 102: 'mixed rows + block tops done',
-         103: 'pass 0', 104: 'pass 1', 105: 'pass 2', 106: 'pass 3', 107: 'pass 4', 108: 'pass 5',
-         110: 'passes done (thread 0)', 111: 'after barrier', 112: 'stored'}
-for k in sorted(names):
-    if t[k] > 0:
-        print('%8.2f us  %s' % (t[k] - t[100], names[k]))
+names = [(99, 'recurrences start'), (103, 'rows of x done, next tile requested'),
+         (110, 'mixed rows done'), (111, 'after the barrier'), (112, 'y assembled and stored'),
+         (100, 'next tile: staging starts'), (101, 'rows + incoming states in LDS'),
+         (102, 'mixed rows formed, after the barrier')]
+for wave in range(4):
+    base = t[99 + 30 * wave]
+    print('wave %d of workgroup 100, its 21st tile:' % wave)
+    for k, label in names:
+        if t[k + 30 * wave] > 0:
+            print('  %8.2f us  %s' % (t[k + 30 * wave] - base, label))
 print('resident workgroups at most:', int(buf[121]))
