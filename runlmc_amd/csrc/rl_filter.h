@@ -185,6 +185,18 @@ __device__ __forceinline__ int sf_wave_sums(const double (&acc)[NV], double* red
 // the four rows.
 // ---------------------------------------------------------------------------
 // requests RB rows' share of a chunk (lane: points lane + 64 k) from clamped addresses
+// two neighbouring doubles at an 8-byte-aligned address, moved as ONE 16-byte access
+struct __attribute__((packed, aligned(8))) SfPair {
+    double a, b;
+};
+// first point of the pair thread tid requests (clamped into the row: a pair never
+// reaches past it; the staging picks the right half, sf_stage)
+__device__ __forceinline__ int sf_pair_base(int g0, int tid, int m) {
+    const int gi = g0 + 2 * tid;
+    return gi <= m - 2 ? gi : m - 2;            // (the host admits grids of 64 points and more)
+}
+// RB rows' points of a chunk for one wave: lane l takes the pairs 2 l + 128 k, k < NK / 2
+// (one 16-byte load each, clamped into the row like sf_pair_base)
 template <int NK, int RB>
 __device__ __forceinline__ void sf_request_rows(double (&xv)[NK][RB], const double* __restrict__ X,
                                                 int nrows, int m, int r0, int g0, int lane) {
@@ -193,9 +205,10 @@ __device__ __forceinline__ void sf_request_rows(double (&xv)[NK][RB], const doub
         const int row = r0 + r;
         const double* xr = X + (size_t)(row < nrows ? row : nrows - 1) * m;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int gi = g0 + lane + 64 * k;
-            xv[k][r] = xr[gi < m ? gi : m - 1];
+        for (int k = 0; k < NK / 2; ++k) {
+            const SfPair pr = *reinterpret_cast<const SfPair*>(xr + sf_pair_base(g0 + 128 * k, lane, m));
+            xv[2 * k][r] = pr.a;
+            xv[2 * k + 1][r] = pr.b;
         }
     }
 }
@@ -221,9 +234,12 @@ k_sf_carries(const double* __restrict__ X, int nrows, int m, int NF, const doubl
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const double live = (r0 + r < nrows && g0 + lane + 64 * k < m) ? 1.0 : 0.0;
-                xv[k][r] = xn[k][r] * live;
+            for (int k = 0; k < NK / 2; ++k) {
+                // (a pair that would reach past the row was requested one point further left)
+                const int gi = g0 + 2 * lane + 128 * k;
+                const bool rowl = r0 + r < nrows;
+                xv[2 * k][r] = rowl && gi < m ? (gi > m - 2 ? xn[2 * k + 1][r] : xn[2 * k][r]) : 0.0;
+                xv[2 * k + 1][r] = rowl && gi + 1 < m ? xn[2 * k + 1][r] : 0.0;
             }
         if (r0 + 4 * RB < rbase + rows_per_wg)
             sf_request_rows<NK, RB>(xn, X, nrows, m, r0 + 4 * RB, g0, lane);
@@ -234,7 +250,7 @@ k_sf_carries(const double* __restrict__ X, int nrows, int m, int NF, const doubl
             for (int j = 0; j < NV; ++j) acc[j] = 0.0;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
-                const int t = lane + 64 * k;
+                const int t = 2 * lane + (k & 1) + 128 * (k >> 1);      // (the point xv[k] holds)
                 const double tb = (double)t, tf = (double)(G - 1 - t);
                 double wf[NS], wb[NS];
                 wb[0] = p[t];
@@ -306,8 +322,10 @@ __device__ __forceinline__ void sf_chunk_state(const double* __restrict__ E, con
 template <int NS>
 __global__ void __launch_bounds__(256)
 k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams sp,
-          double* __restrict__ Cin) {
+          double* __restrict__ Cin, int* __restrict__ next_tile) {
     RL_SMEM(smem);
+    // (k_sf_apply, launched behind this kernel, deals its tiles through this counter)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *next_tile = 0;
     constexpr int NCD = 8, NSEG = 32;
     double* agg = reinterpret_cast<double*>(smem);       // [NSEG][NCD][NS]
     const int NF = sp.NF, nchan = D * NF + sp.nfac, ncd = 2 * nchan;
@@ -474,27 +492,31 @@ __host__ __device__ inline int sf_blob_doubles(int NF, int nfac, int D) {
 // slots k + 30 wave (tools/sf_phase_timing.py)
 #define RL_SF_STAMP(k) RL_STAMP_IF((k) + 30 * (threadIdx.x >> 6), blockIdx.x == 100 && (threadIdx.x & 63) == 0 && sf_iter == 20)
 
-// requests a tile's D rows (thread tid: point tid + 256 (k % NH) of row k / NH in
-// xr[k], from clamped addresses -- points past the grid are zeroed when the registers
-// go to LDS, not here: a select right behind a load makes the compiler wait for it,
-// measured as twelve serial round trips) and its incoming states into registers
+// requests a tile's D rows -- thread tid: the points 2 tid and 2 tid + 1 of every row, ONE
+// 16-byte load per row (a wave stalls at its 17th vector-memory instruction in flight until
+// the first has returned: with two 8-byte loads per row the request of D = 10 rows took
+// 1.8 us, with half of them 0.4, measured) -- and its incoming states into registers.
+// Loads go to clamped addresses and points past the grid are zeroed when the registers
+// go to LDS, not here: a select right behind a load makes the compiler wait for it.
 template <int XR>
 __device__ __forceinline__ void sf_request(double (&xr)[XR], double (&cr)[4],
                                            const double* __restrict__ X,
                                            const double* __restrict__ Cin, int tile, int nch,
                                            int nvec, int D, int m, int ncin, int tid) {
     const int chunk = tile % nch, v = tile / nch, g0 = chunk * RL_SF_G;
-    const double* xbase = X + (size_t)v * D * m;
+    const double* xbase = X + (size_t)v * D * m + sf_pair_base(g0, tid, m);
 #pragma unroll
-    for (int k = 0; k < XR; ++k) {
-        if (k / RL_SF_NH < D) {
-            const int gi = g0 + tid + 256 * (k % RL_SF_NH);
-            xr[k] = xbase[(size_t)(k / RL_SF_NH) * m + (gi < m ? gi : m - 1)];
+    for (int k = 0; k < XR / 2; ++k) {
+        if (k < D) {
+            const SfPair pr = *reinterpret_cast<const SfPair*>(xbase + (size_t)k * m);
+            xr[2 * k] = pr.a;
+            xr[2 * k + 1] = pr.b;
         }
     }
     const double* src = Cin + ((size_t)chunk * nvec + v) * ncin;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cr[k] = src[tid + 256 * k < ncin ? tid + 256 * k : ncin - 1];
+    for (int k = 0; k < 4; ++k)
+        if (256 * k < ncin) cr[k] = src[tid + 256 * k < ncin ? tid + 256 * k : ncin - 1];
 }
 
 // The unrolled recurrences are long straight-line code; left alone the scheduler moves
@@ -666,7 +688,7 @@ __device__ __forceinline__ void sf_task(double* __restrict__ cell, const double 
 
 // a tile's rows and incoming states from the registers they were requested into to LDS
 // (the rows padded, see sf_pad; points past the grid zeroed), then the mixed rows
-// u_f = sum_b A_f[b] x_b: a thread takes points tid and tid + 256, the D values of a
+// u_f = sum_b A_f[b] x_b: a thread takes its two points (2 tid, 2 tid + 1), the D values of a
 // point in registers; the weights are broadcast reads of the block in LDS (scalar loads
 // from global memory measured slower: 4.8 against 2.8 us per tile).  A thread touches
 // ITS OWN columns only -- the ones it also assembles y from --, so no barrier is needed
@@ -676,11 +698,20 @@ __device__ __forceinline__ void sf_stage(const double (&xr)[XR], const double (&
                                          double* us, double* cinl, const double* facA, int nfac,
                                          int ncin, int g0, int m, int tid, int sf_iter) {
     constexpr int PAD = RL_SF_PAD, NH = RL_SF_NH;
+    static_assert(NH == 2, "a thread owns two neighbouring points of a chunk row");
+    {
+        // (the pair was requested from sf_pair_base: one point further left when the row
+        // ends at the pair's first point)
+        const int gi = g0 + 2 * tid, pi = sf_pad(2 * tid);
+        const bool shifted = gi > m - 2;
 #pragma unroll
-    for (int k = 0; k < XR; ++k)
-        if (k / NH < D)
-            xs[(size_t)(k / NH) * PAD + sf_pad(tid + 256 * (k % NH))] =
-                g0 + tid + 256 * (k % NH) < m ? xr[k] : 0.0;
+        for (int k = 0; k < XR / 2; ++k)
+            if (k < D) {
+                const double p0 = shifted ? xr[2 * k + 1] : xr[2 * k];
+                xs[(size_t)k * PAD + pi] = gi < m ? p0 : 0.0;
+                xs[(size_t)k * PAD + pi + 1] = gi + 1 < m ? xr[2 * k + 1] : 0.0;
+            }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (tid + 256 * k < ncin) cinl[tid + 256 * k] = cr[k];
@@ -688,7 +719,7 @@ __device__ __forceinline__ void sf_stage(const double (&xr)[XR], const double (&
     if (nfac > 0) {
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
-            const int pi = sf_pad(tid + 256 * half);
+            const int pi = sf_pad(2 * tid) + half;
             // (rows beyond D: unconditional reads of a clamped row, zero weight -- a
             // branch around a read makes the compiler wait for every read in turn,
             // measured 5 us per tile)
@@ -716,7 +747,8 @@ template <int NS, int D>        // (D at compile time: the row loops, the 2 D re
                                 // with a runtime D the kernel spilled 128 scalar registers)
 __global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
 k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m, int NF,
-           int nfac, const double* __restrict__ blob, const double* __restrict__ Cin) {
+           int nfac, const double* __restrict__ blob, const double* __restrict__ Cin,
+           int* __restrict__ next_tile) {
     constexpr int G = RL_SF_G, PAD = RL_SF_PAD, NH = RL_SF_NH, XR = NH * D, S = RL_SF_S;
     RL_SMEM(smem);
     const int nchan = D * NF + nfac, nblob = sf_blob_doubles(NF, nfac, D);
@@ -729,28 +761,39 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     const double* facJ = facAW + nfac * D;
     const SfBlk* bl = reinterpret_cast<const SfBlk*>(facJ + nfac);
     double* cinl = tab + nblob;                              // [nchan][2][NS]: the chunk's incoming states
-    double* scr = cinl + (size_t)nchan * 2 * NS;             // emulator only
+    int* nxt = reinterpret_cast<int*>(cinl + (size_t)nchan * 2 * NS);   // [2]: the tiles to come
+    double* scr = cinl + (size_t)nchan * 2 * NS + 1;         // emulator only
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = nthr >> 6;
     RL_CENSUS_ENTER(120);
+#if defined(RL_TIMING) && !defined(RL_EMU)
+    const long long sf_t0 = wall_clock64();
+#endif
     // the operator's block -> LDS, once per workgroup
     for (int e = tid; e < nblob; e += nthr) tab[e] = blob[e];
     sf_lds_barrier();
-    // A workgroup walks tiles (chunk, vector) tile0, tile0 + gridDim.x, ...  The NEXT
-    // tile's rows and incoming states are requested into registers once the recurrences
-    // over the rows of x are done (these need the registers themselves: requested
-    // earlier, the rows were spilled one by one, every spill waiting for its load);
-    // they arrive during the mixed rows, the assembly and the other resident
+    // A workgroup starts with tile blockIdx.x and draws every further tile (chunk, vector)
+    // from a counter: workgroups do not all run at the same speed (two share a CU's
+    // SIMDs; lifetimes of 0.51 .. 1.01 ms were measured at C5 with every workgroup on its
+    // fixed 49 or 50 tiles), and a tile's result does not depend on who computes it.
+    // Thread 0 draws the tile after next while the current one is assembled; the number
+    // crosses to the other threads through LDS and the barrier that ends the staging.
+    // The NEXT tile's rows and incoming states are requested into registers once the
+    // recurrences over the rows of x are done (these need the registers themselves:
+    // requested earlier, the rows were spilled one by one, every spill waiting for its
+    // load); they arrive during the mixed rows, the assembly and the other resident
     // workgroup's recurrences.  A request and its use sit in ONE loop iteration.
-    // (256 threads: thread tid holds point tid (and tid + 256) of every row)
+    // (256 threads: thread tid holds the points 2 tid and 2 tid + 1 of every row)
     const int nch = (m + G - 1) / G, ntiles = nch * nvec, ncin = nchan * 2 * NS;
     int tile = blockIdx.x, sf_iter = -1;
+    if (tid == 0) nxt[0] = (int)gridDim.x + atomicAdd(next_tile, 1);
     if (tile < ntiles) {
         double xr[XR], cr[4];
         sf_request<XR>(xr, cr, X, Cin, tile, nch, nvec, D, m, ncin, tid);
         RL_SF_STAMP(100);
         sf_stage<D, XR>(xr, cr, xs, us, cinl, facA, nfac, ncin, (tile % nch) * G, m, tid, sf_iter);
     }
+    int slot = 0;
     while (tile < ntiles) {
     const int chunk = tile % nch, v = tile / nch, g0 = chunk * G;
     ++sf_iter;
@@ -793,9 +836,10 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
         }
     }
     RL_SF_STAMP(103);
-    const int next = tile + (int)gridDim.x;
+    const int next = nxt[slot];
     double xr[XR], cr[4];
     if (next < ntiles) sf_request<XR>(xr, cr, X, Cin, next, nch, nvec, D, m, ncin, tid);
+    RL_SF_STAMP(104);
     // (the waves the rows of x left idle share the mixed rows among them, in rounds;
     // every wave when none was idle)
     const int xw = (D * 16 + 63) / 64, uw0 = xw < nwaves ? xw : 0, nuw = nwaves - uw0;
@@ -818,32 +862,42 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     RL_SF_STAMP(110);
     sf_lds_barrier();
     RL_SF_STAMP(111);
-    // y_a = diagonal part + sum_f w_f A_f[a] (T u_f): a thread takes points tid and
-    // tid + 256, the D results of a point in registers, all stores of a point issued
-    // together
+    // (drawn now, handed to LDS after the assembly: the round trip hides behind it)
+    slot ^= 1;
+    int drawn = 0;
+    if (tid == 0 && next < ntiles) drawn = (int)gridDim.x + atomicAdd(next_tile, 1);
+    // y_a = diagonal part + sum_f w_f A_f[a] (T u_f): a thread takes its two points, the
+    // D results of each in registers, and stores a row's pair with ONE 16-byte store
     {
         const double* gAW = facAW;
-        double* ybase = Y + (size_t)v * D * m + g0;
+        const int i0 = 2 * tid, pi = sf_pad(i0);
+        double* ybase = Y + (size_t)v * D * m + g0 + i0;
+        double acc[NH][16];
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
-            const int i = tid + 256 * half, pi = sf_pad(i);
-            double acc[16];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) acc[a] = xs[(size_t)(a < D ? a : D - 1) * PAD + pi];
+            for (int a = 0; a < 16; ++a) acc[half][a] = xs[(size_t)(a < D ? a : D - 1) * PAD + pi + half];
             for (int f = 0; f < nfac; ++f) {
                 const double* ar = gAW + f * D;
-                const double uw = us[(size_t)f * PAD + pi];
-#pragma unroll
-                for (int a = 0; a < 16; ++a) acc[a] = fma(ar[a < D ? a : D - 1], uw, acc[a]);
-            }
-            if (g0 + i < m) {
+                const double uw = us[(size_t)f * PAD + pi + half];
 #pragma unroll
                 for (int a = 0; a < 16; ++a)
-                    if (a < D) ybase[(size_t)a * m + i] = acc[a];
+                    acc[half][a] = fma(ar[a < D ? a : D - 1], uw, acc[half][a]);
             }
+        }
+        if (g0 + i0 + 1 < m) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                if (a < D)
+                    *reinterpret_cast<SfPair*>(ybase + (size_t)a * m) = SfPair{acc[0][a], acc[1][a]};
+        } else if (g0 + i0 < m) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a)
+                if (a < D) ybase[(size_t)a * m] = acc[0][a];
         }
     }
     RL_SF_STAMP(112);
+    if (tid == 0) nxt[slot] = drawn;
     tile = next;
     if (tile < ntiles) {
         RL_SF_STAMP(100);
@@ -851,4 +905,14 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     }
     }
     RL_CENSUS_LEAVE(120);
+#if defined(RL_TIMING) && !defined(RL_EMU)
+    if (threadIdx.x == 0) {
+        // a workgroup's life: longest, sum, count, shortest (as 2^40 - duration)
+        const unsigned long long d = (unsigned long long)(wall_clock64() - sf_t0);
+        atomicMax((unsigned long long*)&rl_timing_buf[210], d);
+        atomicAdd((unsigned long long*)&rl_timing_buf[211], d);
+        atomicAdd((unsigned long long*)&rl_timing_buf[212], 1ull);
+        atomicMax((unsigned long long*)&rl_timing_buf[213], (1ull << 40) - d);
+    }
+#endif
 }

@@ -362,6 +362,7 @@ struct rl_gridop {
     double* sf_E = nullptr;     // chunk states [nchunks][rows][NF][2][NS]
     size_t sf_E_cap = 0;
     double* sf_Cin = nullptr;   // incoming states [nchunks][nvec][nchan][2][NS]
+    int* sf_next = nullptr;     // k_sf_apply's tile counter (zeroed by k_sf_scan)
     size_t sf_Cin_cap = 0;
     double* mixtab = nullptr;   // dev [D + nfac][L]: dc rows then gs rows (k_mix_tables)
     size_t mixtab_rows = 0;     // rows allocated
@@ -710,7 +711,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
                     g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_Cc, g->lr_Bc,
                     g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
-                    g->sf_E, g->sf_Cin};
+                    g->sf_E, g->sf_Cin, g->sf_next};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
@@ -1579,7 +1580,7 @@ static int sf_reserve(rl_gridop* g, int nvec, int NF, int nfac, int NS) {
 }
 static size_t sf_apply_lds(int D, int nfac, int NF, int nthr) {
     size_t b = ((size_t)(D + nfac) * RL_SF_PAD + sf_blob_doubles(NF, nfac, D) +
-                (size_t)(D * NF + nfac) * 2 * 3) * sizeof(double);
+                (size_t)(D * NF + nfac) * 2 * 3 + 1) * sizeof(double);
 #if defined(RL_EMU)
     b += (size_t)(nthr / 64) * 128 * sizeof(double);
 #else
@@ -1600,7 +1601,7 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
               sp.pw, rpw, g->sf_E);
     const int ncd = 2 * (D * sp.NF + sp.nfac);
     RL_LAUNCH((k_sf_scan<NS>), dim3((ncd + 7) / 8, nvec), dim3(256), 256 * NS * sizeof(double),
-              st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin);
+              st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin, g->sf_next);
     // persistent workgroups of four waves, two per CU (256 registers a lane: a segment's
     // 32 points and the states of five filters; the tile's LDS allows two at C5), each
     // walking every (2 x CUs)-th tile.  (A workgroup of five waves puts two on the first
@@ -1617,7 +1618,7 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
     case D_:                                                                                    \
         RL_LAUNCH((k_sf_apply<NS, D_>), dim3(std::min(ntiles, resident)), dim3(64 * waves),     \
                   sf_apply_lds(D, sp.nfac, sp.NF, 64 * waves), st, X, Y, nvec, g->m, sp.NF,     \
-                  sp.nfac, blob, (const double*)g->sf_Cin);                                     \
+                  sp.nfac, blob, (const double*)g->sf_Cin, g->sf_next);                         \
         break
     switch (D) {
         RL_SF_APPLY(1); RL_SF_APPLY(2); RL_SF_APPLY(3); RL_SF_APPLY(4);
@@ -1927,6 +1928,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
     if (nfilt) {
         if (!g->sf_tops) {
             RL_HIP(hipMalloc((void**)&g->sf_tops, (size_t)g->max_tops * sizeof(SfTop)));
+            RL_HIP(hipMalloc((void**)&g->sf_next, sizeof(int)));
             RL_HIP(hipMalloc((void**)&g->sf_blob, (size_t)sf_blob_doubles(g->max_tops, g->max_fac, D) * sizeof(double)));
             RL_HIP(hipMalloc((void**)&g->sf_blob_top, (size_t)g->max_tops * sf_blob_doubles(1, 0, D) * sizeof(double)));
             RL_HIP(hipMalloc((void**)&g->sf_pw, (size_t)g->max_tops * (RL_SF_G + 1) * sizeof(double)));

@@ -22,7 +22,7 @@ buf = (ctypes.c_longlong * 256)()
 lib.rl_debug_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.rl_debug_timing(buf, 256) == 0
 t = np.array(list(buf), dtype=np.float64) / 100.0        # 100 MHz -> microseconds
-names = [(99, 'recurrences start'), (103, 'rows of x done, next tile requested'),
+names = [(99, 'recurrences start'), (103, 'rows of x done'), (104, 'next tile requested'),
          (110, 'mixed rows done'), (111, 'after the barrier'), (112, 'y assembled and stored'),
          (100, 'next tile: staging starts'), (101, 'rows + incoming states in LDS'),
          (102, 'mixed rows formed, after the barrier')]
@@ -33,3 +33,6 @@ for wave in range(4):
         if t[k + 30 * wave] > 0:
             print('  %8.2f us  %s' % (t[k + 30 * wave] - base, label))
 print('resident workgroups at most:', int(buf[121]))
+if buf[212]:
+    print('workgroup lifetimes over %d workgroups: shortest %.1f us, mean %.1f us, longest %.1f us'
+          % (buf[212], ((1 << 40) - buf[213]) / 100.0, buf[211] / buf[212] / 100.0, buf[210] / 100.0))
