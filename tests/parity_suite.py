@@ -892,10 +892,12 @@ def check_filter_form():
     try:
         # (20011 points: 40 chunks, so that the chunk scan's segments hold several)
         # (five tops: a batch of four filters and a fifth alone, the layouts of C5's family)
+        # (seven and eleven tops: batches of 5 + 2 and 5 + 5 + 1 filters per row; 13 and 16
+        # outputs: the rows of x fill all four waves, the mixed rows follow on every wave)
         for D, Q, m, k in ((3, 2, 2500, 3), (2, 3, 4101, 2), (5, 2, 700, 2), (2, 2, 20011, 2),
-                           (3, 5, 2200, 2)):
+                           (3, 5, 2200, 2), (13, 7, 1100, 2), (16, 3, 601, 1), (2, 11, 900, 2)):
             x = np.linspace(0, 1, m)
-            gam = np.logspace(0, 1, Q) * (1.0 if m > 1000 else 3.0)
+            gam = np.logspace(0, 1, Q) * (1.0 if m > 1200 else 3.0)
             mat = np.array([_matern32(x, g_) for g_ in gam])
             A = [rng.randn(1 + q % 2, D) for q in range(Q)]
             kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]

@@ -1,5 +1,6 @@
 """One kernel family's grid product in its chosen forms, a few calls (for
-profilers):  python tools/one_family.py c5 matern [batch] [calls]"""
+profilers):  python tools/one_family.py c5 matern [batch] [calls] [fft]
+(fft: the same product on the transform kernels)"""
 import os
 import sys
 import torch
@@ -15,7 +16,7 @@ p = synth.make_problem(D, Q, R, m_data, kern=kern)
 g = GridOp(D, p.m, Q)
 g.set_lmc(synth.tops(p), list(p.coreg_vecs), list(p.coreg_diags))
 print(g.top_forms())
-g.set_form_gate(0)
+g.set_form_gate(1 << 62 if len(sys.argv) > 5 and sys.argv[5] == 'fft' else 0)
 X = torch.randn(batch, D * p.m, dtype=torch.float64, device='cuda')
 Y = torch.empty_like(X)
 for _ in range(calls):

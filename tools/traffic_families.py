@@ -31,7 +31,8 @@ for pdir in sorted(glob.glob(os.path.join(root, 'pass*'))):
             cnt[name][row['Counter_Name']] += 1
 detail, total = {}, 0.0
 for name, c in tot.items():
-    if not name.startswith(('k_lr_project', 'k_lr_mix', 'k_lr_expand', 'k_sf_')):
+    if not name.startswith(('k2_', 'k3_', 'k1_') if family == 'fft' else
+                           ('k_lr_project', 'k_lr_mix', 'k_lr_expand', 'k_sf_')):
         continue
     # the product's launches only: the set-time verification also launches k_lr_* kernels
     # (a few dozen rows each) -- per-launch averages over ALL launches would be diluted,
@@ -47,7 +48,8 @@ try:
     table = json.load(open(out_path))
 except (OSError, ValueError):
     table = {}
-key = '%s:%d:%s' % (config, batch, 'poly' if family == 'rbf' else family)
+key = ('%s:%d' % (config, batch) if family == 'fft' else
+       '%s:%d:%s' % (config, batch, 'poly' if family == 'rbf' else family))
 table[key] = {'bytes_per_step': total / calls, 'source': label, 'kernels': detail}
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(table, open(out_path, 'w'), indent=1, sort_keys=True)
