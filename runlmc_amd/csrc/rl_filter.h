@@ -117,25 +117,42 @@ __device__ __forceinline__ void sf_carry(double (&V)[NS], const double (&S)[NS],
 }
 
 // ---------------------------------------------------------------------------
-// sums of NV values per lane over the 64 lanes of a wave.  Afterwards the lanes
-// with (lane & 7) == 0 hold NV / 8 of the sums each, out[k] = sum number j0 + k.
-// GPU: halving butterfly (at distance 32 a lane keeps one half of its values and
-// receives that half from its partner, at 16 a quarter, at 8 an eighth; the last
-// NV / 8 go through plain exchanges) -- NV / 2 + NV / 4 + NV / 8 + 3 NV / 8
-// cross-lane moves instead of 6 NV.  Emulator (no cross-lane operations): LDS.
+// sums of NV values per lane over the 64 lanes of a wave.  Afterwards the EVEN lanes
+// of the first lane row (lane < 16) hold NV / 8 of the sums each, out[k] = sum number
+// j0 + k (the return value is j0; sf_wave_sums_writer says whether a lane holds any).
+// GPU: halving butterfly INSIDE the 16-lane rows with DPP moves -- at distance 8
+// (row_ror:8) a lane keeps one half of its values and receives that half from its
+// partner, at 4 (row_half_mirror: lane l <-> 7 - l, which also differ in bit 2) a
+// quarter, at 2 (quad_perm) an eighth; the last NV / 8 values go through plain
+// exchanges at distance 1 (DPP) and across the four lane rows (two shuffles).
+// (Measured at C5 Matern, k_sf_carries per product: every level a shuffle through the
+// LDS crossbar, starting at distance 32, 0.29 ms; this 0.26 ms; the NV x 64 values
+// through the wave's own LDS and added there by 64 lanes, 0.27 ms.  The kernel runs at
+// the fp64 vector rate: 164 multiply-adds and 126 reduction instructions per filter and
+// block of four rows.)  Emulator: LDS.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ bool sf_wave_sums_writer(int lane) { return lane < 16 && (lane & 1) == 0; }
+#if !defined(RL_EMU)
+template <int CTRL>
+__device__ __forceinline__ double sf_dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+#endif
 template <int NV>
 __device__ __forceinline__ int sf_wave_sums(const double (&acc)[NV], double* red, double (&out)[NV / 8]) {
     constexpr int A = NV / 2, B = NV / 4, C = NV / 8;
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
-    const int j0 = (h5 ? A : 0) + (h4 ? B : 0) + (h3 ? C : 0);
+    const bool h3 = (lane & 8) != 0, h2 = (lane & 4) != 0, h1 = (lane & 2) != 0;
+    const int j0 = (h3 ? A : 0) + (h2 ? B : 0) + (h1 ? C : 0);
 #if defined(RL_EMU)
     const int wave = tid >> 6;
     for (int j = 0; j < NV; ++j) {
         red[tid] = acc[j];
         __syncthreads();
-        if ((lane & 7) == 0 && j >= j0 && j < j0 + C) {
+        if (sf_wave_sums_writer(lane) && j >= j0 && j < j0 + C) {
             double s = 0.0;
             for (int l = 0; l < 64; ++l) s += red[wave * 64 + l];
             out[j - j0] = s;
@@ -147,24 +164,24 @@ __device__ __forceinline__ int sf_wave_sums(const double (&acc)[NV], double* red
     double a[A], b[B], c[C];
 #pragma unroll
     for (int k = 0; k < A; ++k) {
-        const double mine = h5 ? acc[A + k] : acc[k], send = h5 ? acc[k] : acc[A + k];
-        a[k] = mine + __shfl_xor(send, 32, 64);
+        const double mine = h3 ? acc[A + k] : acc[k], send = h3 ? acc[k] : acc[A + k];
+        a[k] = mine + sf_dpp_move<0x128>(send);                 // row_ror:8 = lane ^ 8
     }
 #pragma unroll
     for (int k = 0; k < B; ++k) {
-        const double mine = h4 ? a[B + k] : a[k], send = h4 ? a[k] : a[B + k];
-        b[k] = mine + __shfl_xor(send, 16, 64);
+        const double mine = h2 ? a[B + k] : a[k], send = h2 ? a[k] : a[B + k];
+        b[k] = mine + sf_dpp_move<0x141>(send);                 // row_half_mirror: l <-> 7 - l
     }
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-        const double mine = h3 ? b[C + k] : b[k], send = h3 ? b[k] : b[C + k];
-        c[k] = mine + __shfl_xor(send, 8, 64);
+        const double mine = h1 ? b[C + k] : b[k], send = h1 ? b[k] : b[C + k];
+        c[k] = mine + sf_dpp_move<0x4E>(send);                  // quad_perm [2, 3, 0, 1] = lane ^ 2
     }
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-        c[k] += __shfl_xor(c[k], 4, 64);
-        c[k] += __shfl_xor(c[k], 2, 64);
-        c[k] += __shfl_xor(c[k], 1, 64);
+        c[k] += sf_dpp_move<0xB1>(c[k]);                        // quad_perm [1, 0, 3, 2] = lane ^ 1
+        c[k] += __shfl_xor(c[k], 16, 64);
+        c[k] += __shfl_xor(c[k], 32, 64);
         out[k] = c[k];
     }
 #endif
@@ -272,7 +289,7 @@ k_sf_carries(const double* __restrict__ X, int nrows, int m, int NF, const doubl
             }
             double out[NV / 8];
             const int j0 = sf_wave_sums<NV>(acc, red, out);
-            if ((lane & 7) == 0) {
+            if (sf_wave_sums_writer(lane)) {
 #pragma unroll
                 for (int k = 0; k < NV / 8; ++k) {
                     const int j = j0 + k, r = j / (2 * NS), rest = j - r * 2 * NS;
