@@ -611,7 +611,9 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
             np.random.seed(4321)
             # the config's N probes in total, dealt round-robin to the ranks
             # (strong scaling of one optimiser step)
-            probes = np.random.randint(0, 2, (n_probes, pe.n)) * 2 - 1
+            # (drawn as the reference draws them -- int64 -- and kept as one byte per entry:
+            # drawing and narrowing are data preparation, outside the timed step)
+            probes = (np.random.randint(0, 2, (n_probes, pe.n)) * 2 - 1).astype(np.int8)
             group = None
             if args.force_dist or world > 1:
                 import torch.distributed as tdist

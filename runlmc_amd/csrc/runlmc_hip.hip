@@ -3270,12 +3270,15 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             RL_HIP(e);
             RL_HIP(hipGraphInstantiate(&guard.exec, guard.graph, nullptr, nullptr, 0));
         }
-        // Polynomial rounds cost next to nothing for frozen systems (P and B return
-        // at once, there is no operator kernel), so the host does not wait for the
-        // count of a replay before it launches the next one: the count of replay j
-        // is read while replay j + 1 runs (one replay of no-ops at the end of a
-        // solve against a host round trip per replay).
-        const bool lagged = guard.exec != nullptr && mb.poly_part != nullptr;
+        // The host does not wait for the count of a replay before it launches the next
+        // one: the count of replay j is read while replay j + 1 runs.  Submitting a
+        // replay (per2 rounds of five to seven kernels) takes the host 1.5-2 ms, during
+        // which the GPU sat idle when every replay ended in a synchronisation (C5, 129
+        // systems: 3.82 ms per round against the kernels' 3.6); the price is one replay
+        // of rounds for systems that have all stopped at the end of a solve -- P and B
+        // return at once for them, the operator's kernels run (14 ms at C5) -- or next
+        // to nothing in the polynomial rounds, which have no operator kernel.
+        const bool lagged = guard.exec != nullptr;
         if (lagged && !s->pin_count) {
             RL_HIP(hipHostMalloc((void**)&s->pin_count, 2 * sizeof(int), hipHostMallocDefault));
             for (hipEvent_t& e : s->count_ev)
