@@ -380,3 +380,115 @@ __device__ __forceinline__ void lr_row_accumulate(double acc[RL_LR_RS],
         acc[j] = fma(y, t, acc[j]);
     }
 }
+
+// ---------------------------------------------------------------------------
+// k_spmv_w_poly<VB, XPT, R>: Y = W (Phi Zhat) (+ diag (.) X2) -- the interpolation
+// product of k_spmv_w_staged (rl_kernels.h) with the polynomial form's EXPANSION
+// inside it: the contiguous grid range of a workgroup's RL_THREADS data rows is not
+// read from a grid vector but evaluated from the mixed coefficients,
+//     g[v][c] = sum_j q_j(n) Zhat[v D + d][j],   c = d m + n,
+// once per group of VB vectors into the same LDS tile the rows then gather from.  A
+// thread keeps the R basis values of its XPT points in registers for all the groups
+// it walks (recurrence once per workgroup); the coefficients of a group -- VB vectors
+// x the at most two outputs a range of <= 4 RL_THREADS < m points meets -- are staged
+// in LDS and read as broadcasts.  R multiply-adds per (grid point, vector) on the
+// vector pipe (0.11 ms of instructions per C5 round at full lanes) against the write
+// of the grid vector by k_lr_expand and its read by k_spmv_w_staged (0.4 ms).
+// (The standalone expansion sums even and odd degrees apart, for a point and its
+// mirror at once; here a point's R terms are summed in order: the two agree to
+// roundoff, not bit for bit.)
+//   grid (ceil(nrows / RL_THREADS), ceil(ceil(nvec / VB) / vgroups))
+//   LDS: VB xcap doubles (grid values) + VB 2 R (coefficients)
+// ---------------------------------------------------------------------------
+template <int VB, int XPT, int R>
+__global__ void __launch_bounds__(RL_THREADS)
+k_spmv_w_poly(const int* __restrict__ base, const double* __restrict__ w4, int nrows, int ncols,
+              int nvec, const double* __restrict__ Zhat, const double* __restrict__ beta, int D,
+              int m, double* __restrict__ Y, const double* __restrict__ diag,
+              const double* __restrict__ X2, int xcap, int vgroups) {
+    RL_SMEM(smem);
+    double* xs = reinterpret_cast<double*>(smem);          // [VB][xcap]
+    double* zs = xs + (size_t)VB * xcap;                   // [VB][2][R]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int bx = lin / gridDim.y, by = lin - bx * gridDim.y;
+    const int r0 = bx * nthr;
+    const int rl = (r0 + nthr < nrows ? r0 + nthr : nrows) - 1;
+    const int groups = (nvec + VB - 1) / VB;
+    const int g0 = by * vgroups;
+    const int ng = groups - g0 < vgroups ? groups - g0 : vgroups;
+    const int c0 = base[r0], c1 = base[rl] + 4;
+    const int len = c1 - c0;
+    const int row = r0 + tid;
+    const int rowc = row <= rl ? row : rl;
+    const int b = base[rowc];
+    double w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = w4[(size_t)4 * rowc + e];
+    const double dg = diag != nullptr ? diag[rowc] : 0.0;
+    // the basis at this thread's points of the range (points past the grid -- a base
+    // column near the end of the last output plus its four entries -- meet zero weights)
+    const int d0 = c0 / m;
+    double p[XPT][R];
+    int dsel[XPT];
+#pragma unroll
+    for (int u = 0; u < XPT; ++u) {
+        int c = c0 + tid + u * nthr;
+        c = c < ncols ? c : ncols - 1;
+        const int d = c / m, n = c - d * m;
+        dsel[u] = d - d0 < 1 ? 0 : 1;
+        const double s = lr_point(n, m);
+        double qm = 0.0, q = 1.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            p[u][j] = q;
+            const double qn = fma(s, q, -beta[j] * qm);
+            qm = q;
+            q = qn;
+        }
+    }
+    const double* xrow = xs + (b - c0);
+    for (int grp = 0; grp < ng; ++grp) {
+        const int v0 = (g0 + grp) * VB;
+        for (int e = tid; e < VB * 2 * R; e += nthr) {
+            const int j = e / (2 * R), rem = e - j * 2 * R, dd = rem / R, k = rem - dd * R;
+            const int v = v0 + j < nvec ? v0 + j : nvec - 1;
+            const int dc = d0 + dd < D ? d0 + dd : D - 1;
+            zs[e] = Zhat[((size_t)v * D + dc) * R + k];
+        }
+        double x2[VB];
+#pragma unroll
+        for (int j = 0; j < VB; ++j)
+            x2[j] = diag != nullptr ? X2[(size_t)(v0 + j < nvec ? v0 + j : nvec - 1) * nrows + rowc] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int i = tid + u * nthr;
+            if (i < len) {
+#pragma unroll
+                for (int j = 0; j < VB; ++j) {
+                    const double* z = zs + (j * 2 + dsel[u]) * R;
+                    double ev = 0.0, od = 0.0;
+#pragma unroll
+                    for (int k = 0; k + 1 < R; k += 2) {
+                        ev = fma(z[k], p[u][k], ev);
+                        od = fma(z[k + 1], p[u][k + 1], od);
+                    }
+                    xs[(size_t)j * xcap + i] = ev + od;
+                }
+            }
+        }
+        __syncthreads();
+        if (row <= rl) {
+#pragma unroll
+            for (int j = 0; j < VB; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fma(w[e], xrow[(size_t)j * xcap + e], acc);
+                if (diag != nullptr) acc = fma(dg, x2[j], acc);
+                if (v0 + j < nvec) Y[(size_t)(v0 + j) * nrows + row] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -96,6 +96,7 @@ struct RlKnobs {
     long long lr_min = -1;       // RUNLMC_LR_MIN: batch gate of the structured forms
     bool staged_wt = false;      // RUNLMC_STAGED_WT: LDS-staged SpMVs whatever the size
     bool no_staged_wt = false;   // RUNLMC_NO_STAGED_WT
+    bool no_w_poly = false;      // RUNLMC_NO_W_POLY: the W product reads the expanded grid vector
     bool no_sort = false;        // RUNLMC_NO_SORT: caller's data order inside the SKI handle
     long long ws_cache_mb = -1;  // RUNLMC_WS_CACHE_MB
     int solver_maxblk = 0;       // RUNLMC_SOLVER_MAXBLK
@@ -124,6 +125,7 @@ static RlKnobs read_knobs() {
     k.lr_min = num("RUNLMC_LR_MIN", -1);
     k.staged_wt = flag("RUNLMC_STAGED_WT");
     k.no_staged_wt = flag("RUNLMC_NO_STAGED_WT");
+    k.no_w_poly = flag("RUNLMC_NO_W_POLY");
     k.no_sort = flag("RUNLMC_NO_SORT");
     k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
     k.solver_maxblk = (int)num("RUNLMC_SOLVER_MAXBLK", 0);
@@ -311,6 +313,8 @@ struct rl_gridop {
     // polynomial-subspace form for smooth kernels (rl_lowrank.h)
     bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
     bool lr_ok = false;         // verified against the FFT path for the current parameters
+    bool defer_expand = false;  // ski_mvm_int: leave the expansion to the W kernel (k_spmv_w_poly) ...
+    bool expand_deferred = false;   // ... done: lr_zhat holds the mixed coefficients of the batch
     int lr_rejects = 0;         // consecutive parameter sets with a top the verification rejected
     int lr_skip = 0;            // parameter updates the verification still sits out (back-off:
                                 // 0, 1, 3 ... 31 updates after 1, 2, 3 ... rejections in a row)
@@ -1384,6 +1388,12 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
               (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
               (const double*)g->lr_nu, g->lr_zhat);
+    // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
+    // the evaluation costs what the two vector passes it saves do)
+    if (g->defer_expand && !accumulate && R <= 32) {
+        g->expand_deferred = true;
+        return;
+    }
     // rows per expansion workgroup: the basis values of a slot are generated once
     // per workgroup (48 instructions against 14 per row and slot).  16 rows when
     // that makes at least two resident rounds of workgroups (measured at C5, 1290
@@ -2090,7 +2100,14 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
     // (nothing may be allocated or copied inside a capture: a pending verification
     // waits for the next product outside one; the solver runs it before it captures)
     const bool capturing = big && stream_capturing(stream);
-    if (big && g->lr_dirty && !capturing) RL_TRY(lr_ensure(g));
+    if (big && g->lr_dirty && !capturing) {
+        // (the verification runs whole products of its own: never with a deferred expansion)
+        const bool defer = g->defer_expand;
+        g->defer_expand = false;
+        const int rc = lr_ensure(g);
+        g->defer_expand = defer;
+        if (rc != RL_OK) return rc;
+    }
     if (big && !g->lr_dirty) {
         // a batch large enough to fill the chip with projection / filter workgroups:
         // each top row in the form it was found in at set time (forms_setup)
@@ -2724,15 +2741,66 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
+// can the W product of a batch take the grid values from the polynomial form's mixed
+// coefficients (k_spmv_w_poly)?  Staged W on a 1-D grid the polynomial form is eligible
+// for; whether the operator IS in that form at rank 24 or 32 the grid handle decides when
+// the product runs (its verification may still be pending here): lr_launch
+static bool ski_w_poly_ok(const rl_ski* s, int nvec) {
+    constexpr int VB = 8;
+    const rl_gridop* g = s->g;
+    const size_t lds = ((size_t)VB * s->w_xmax + (size_t)VB * 2 * RL_LR_RMAX) * sizeof(double);
+    return s->W4_base != nullptr && s->w_xmax > 0 && s->w_xmax <= 2 * RL_THREADS &&
+           lds <= 64 * 1024 && ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) &&
+           !s->kn.no_staged_wt &&
+           (g->lr_try || g->lr_ok) && g->m >= 4 * RL_THREADS && s->ngrid == g->D * g->m &&
+           !s->kn.no_w_poly;
+}
+static int ski_w_poly(rl_ski* s, double* Yp, int nvec, const double* diag, const double* X2p,
+                      hipStream_t st) {
+    constexpr int VB = 8;
+    rl_gridop* g = s->g;
+    const int R = g->lr_r;
+    const size_t lds = ((size_t)VB * s->w_xmax + (size_t)VB * 2 * R) * sizeof(double);
+    trace_once("W product: k_spmv_w_poly (grid values from the mixed coefficients)");
+    const unsigned gx = (s->n + RL_THREADS - 1) / RL_THREADS;
+    const int vg = staged_vgroups();
+    const dim3 grid(gx, ((nvec + VB - 1) / VB + vg - 1) / vg);
+#define RL_W_POLY(XPT, R_)                                                                      \
+    RL_LAUNCH((k_spmv_w_poly<VB, XPT, R_>), grid, dim3(RL_THREADS), lds, st,                    \
+              (const int*)s->W4_base, (const double*)s->W4_w, s->n, s->ngrid, nvec,             \
+              (const double*)g->lr_zhat, (const double*)g->lr_beta, g->D, g->m, Yp, diag, X2p,  \
+              s->w_xmax, vg)
+    if (R == 24) {
+        if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 24);
+        else RL_W_POLY(2, 24);
+    } else {
+        if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 32);
+        else RL_W_POLY(2, 32);
+    }
+#undef RL_W_POLY
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
 // Yp = K~ Xp, both in internal row order (what the solver iterates on)
 // (noise = false: Yp = W K_UU W^T Xp only -- the caller adds eps (.) Xp itself)
 static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st,
                        int* bump = nullptr, bool noise = true) {
     RL_TRY(ski_reserve(s, nvec));
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
-    RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st));
-    RL_TRY(ski_w_int(s, s->G2, Yp, nvec, s->has_noise && noise ? s->noise_diag : nullptr, Xp,
-                     st));
+    const double* diag = s->has_noise && noise ? s->noise_diag : nullptr;
+    // a polynomial-form operator hands its mixed coefficients to the W kernel instead of
+    // writing the grid vector (the grid handle says whether it took that path)
+    s->g->expand_deferred = false;
+    s->g->defer_expand = ski_w_poly_ok(s, nvec);
+    const int rc = rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st);
+    s->g->defer_expand = false;
+    if (rc != RL_OK) return rc;
+    if (s->g->expand_deferred) {
+        s->g->expand_deferred = false;
+        RL_TRY(ski_w_poly(s, Yp, nvec, diag, Xp, st));
+    } else {
+        RL_TRY(ski_w_int(s, s->G2, Yp, nvec, diag, Xp, st));
+    }
     for (const SkiTerm& t : s->extra) {       // Yp += W_t K_t W_t^T Xp
         launch_spmv(t.WT_indptr, t.WT_indices, t.WT_data, t.ngrid, s->n, nvec, Xp, s->G1,
                     nullptr, nullptr, st);

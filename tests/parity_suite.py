@@ -1404,3 +1404,52 @@ def check_staged_wt_product():
         os.environ.pop('RUNLMC_STAGED_WT', None)
         if saved is not None:
             os.environ['RUNLMC_STAGED_WT'] = saved
+
+
+def check_w_poly_product():
+    """The interpolation product that takes its grid values from the polynomial form's
+    mixed coefficients (k_spmv_w_poly: the expansion inside the W kernel, no grid vector
+    written or read), forced on a small system: against the same operator with the
+    expansion kernel and the staged W product (RUNLMC_NO_W_POLY: agreement to roundoff,
+    a different summation order), against the transform kernels, through a solve; ragged
+    outputs, so that workgroup ranges straddle two outputs, and a batch that is no
+    multiple of the vector block."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch
+    rng = np.random.RandomState(23)
+    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_W_POLY')
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    try:
+        os.environ['RUNLMC_STAGED_WT'] = '1'
+        for D, Q, m_data, k in ((3, 2, 2600, 37), (2, 3, 5000, 9)):
+            p = synth.make_problem(D, Q, 1, m_data, eps=1.0)
+            fk = synth.functional_kernel(p)
+            ad = (0,)
+            V = rng.randn(k, p.n)
+
+            def run(no_fuse, gate):
+                os.environ.pop('RUNLMC_NO_W_POLY', None)
+                if no_fuse:
+                    os.environ['RUNLMC_NO_W_POLY'] = '1'
+                K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+                op = K.device_operator()
+                op.grid.set_form_gate(gate)
+                Y = op.matmat_host(V)
+                X = solve_batch(op, torch.from_numpy(V[:3]).to(op.device), tol=1e-6,
+                                maxiter=30)[0].cpu().numpy()
+                forms = op.grid.top_forms()
+                return Y, X, forms
+            Yf, Xf, forms = run(False, 0)
+            assert forms[0] == [1] * Q and forms[1], forms       # (the polynomial form)
+            Yu, Xu, _ = run(True, 0)
+            Yt, Xt, _ = run(True, 1 << 62)                        # transform kernels
+            scale = np.abs(Yu).max()
+            assert np.abs(Yf - Yu).max() <= 1e-13 * scale, np.abs(Yf - Yu).max() / scale
+            assert not np.array_equal(Yf, Yu)        # (another summation order: the fused kernel ran)
+            assert np.abs(Yf - Yt).max() <= 1e-11 * scale
+            assert np.abs(Xf - Xu).max() <= 1e-9 * np.abs(Xu).max()
+    finally:
+        for k_, v in saved.items():
+            os.environ.pop(k_, None)
+            if v is not None:
+                os.environ[k_] = v

@@ -137,6 +137,10 @@ def test_staged_wt_product():
     ps.check_staged_wt_product()
 
 
+def test_w_poly_product():
+    ps.check_w_poly_product()
+
+
 def test_chunked_product():
     ps.check_chunked_product()
 
