@@ -1389,7 +1389,8 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
               (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
               (const double*)g->lr_nu, g->lr_zhat);
     // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
-    // the evaluation costs what the two vector passes it saves do)
+    // the evaluation costs more than the two vector passes it saves -- measured, C5
+    // periodic: 5.03 against 4.17 ms per solver round)
     if (g->defer_expand && !accumulate && R <= 32) {
         g->expand_deferred = true;
         return;

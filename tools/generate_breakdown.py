@@ -1,5 +1,5 @@
 """Where StochasticDerivService.generate spends a C5 step outside the solver's rounds
-(GPU box):  python tools/generate_breakdown.py"""
+(GPU box):  python tools/generate_breakdown.py [rbf|periodic|matern|mix]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +8,7 @@ from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
 from runlmc_amd.approx.iterative import Iterative
 
 D, Q, R, m, npr = synth.CONFIGS['c5']
-p = synth.make_problem(D, Q, R, m)
+p = synth.make_problem(D, Q, R, m, kern=sys.argv[1] if len(sys.argv) > 1 else 'rbf')
 fk = synth.functional_kernel(p)
 ad = (0,)
 K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
