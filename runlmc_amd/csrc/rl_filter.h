@@ -855,6 +855,10 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
     RL_SF_STAMP(103);
     const int next = nxt[slot];
     double xr[XR], cr[4];
+#if defined(RL_EMU)
+    for (int k = 0; k < XR; ++k) xr[k] = 0.0;      // (g++ cannot see that a request always precedes a use)
+    for (int k = 0; k < 4; ++k) cr[k] = 0.0;
+#endif
     if (next < ntiles) sf_request<XR>(xr, cr, X, Cin, next, nch, nvec, D, m, ncin, tid);
     RL_SF_STAMP(104);
     // (the waves the rows of x left idle share the mixed rows among them, in rounds;
