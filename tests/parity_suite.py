@@ -1453,3 +1453,36 @@ def check_w_poly_product():
             os.environ.pop(k_, None)
             if v is not None:
                 os.environ[k_] = v
+
+
+def check_generate_probe_dtypes():
+    """StochasticDerivService.generate puts the right-hand sides together on the device;
+    +-1 probes cross as one byte per entry whatever integer width they come in.  The
+    same solves, bit for bit, from int64 probes (what the reference draws), int8, a
+    strided view, float64 +-1 (the plain path), for an even and an odd probe count (y
+    alone in the last pair / next to a zero row); probes that are not +-1 take the
+    plain path too."""
+    from runlmc_amd.util import synth
+    p = synth.make_problem(3, 2, 1, 300, eps=1.0)
+    p.noise = p.noise + 0.5
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    rng = np.random.RandomState(3)
+    for n_it in (4, 3):
+        rs = rng.randint(0, 2, (n_it, p.n)) * 2 - 1
+        svc = StochasticDerivService(None, None, n_it, 1e-6)
+        ref = svc.generate(K, p.y, rs)
+        wide = np.zeros((2 * n_it, p.n), dtype=np.int64)
+        wide[::2] = rs
+        for alt in (rs.astype(np.int8), rs.astype(np.float64), rs.astype(np.int32), wide[::2]):
+            d = svc.generate(K, p.y, alt)
+            assert np.array_equal(d.alpha, ref.alpha)
+            assert np.array_equal(d._inv_rs, ref._inv_rs) and np.array_equal(d._rs, rs)
+            assert list(d.iterations) == list(ref.iterations)
+        # (entries other than +-1: nothing is narrowed)
+        odd = rs.copy()
+        odd[0, 0] = 3
+        d = svc.generate(K, p.y, odd)
+        assert d._rs[0, 0] == 3.0 and np.array_equal(d._rs[1:], rs[1:])
+        assert np.array_equal(d.alpha, ref.alpha)

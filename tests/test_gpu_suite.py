@@ -112,6 +112,10 @@ def test_w_poly_product():
     ps.check_w_poly_product()
 
 
+def test_generate_probe_dtypes():
+    ps.check_generate_probe_dtypes()
+
+
 def test_chunked_product():
     ps.check_chunked_product()
 
