@@ -494,6 +494,11 @@ k_spmv_wide(const int* __restrict__ indptr, const int* __restrict__ indices,
 // vector, xcap <= XPT * RL_THREADS) while the current group is summed out of
 // LDS and stored -- loads, sums and stores of a workgroup overlap instead of
 // taking turns (measured at C5, 129 vectors: DESIGN.md).
+// (Measured and dropped, round 3: the pieces of a group as one flat list of 16-byte
+// pairs, two groups ahead in flight -- fewer, wider loads, none of them past the piece.
+// 536 against 467 us per C5 product with pairs at the piece's own parity, 745 with pairs
+// aligned to 16 bytes and nine slots a thread: the kernel's registers went from ~100 to
+// 165 and its occupancy with them.)
 //   grid (ceil(nrows / RL_THREADS), ceil(ceil(nvec / VB) / vgroups))
 //   LDS: VB * xcap doubles (vector pieces) + ecap doubles (weights); the host
 //   guarantees every workgroup's range <= xcap and entries <= ecap
