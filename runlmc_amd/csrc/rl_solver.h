@@ -645,6 +645,12 @@ k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ p
     }
 }
 
+// (Measured and dropped, round 3: the plain large-system round compiled apart from the
+// variants with the W product / the polynomial form inside -- 128 instead of 209 registers
+// for P, 54 instead of 176 for B, four and eight waves per SIMD instead of two: P 1.65
+// against 1.56-1.63 ms, B 0.53 against 0.52-0.59 at C5.  Nine and three vector streams at
+// 5.6 TB/s: the kernels are at the rate HBM gives mixed reads and writes, not short of
+// loads in flight.)
 __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_p(Minres2Bufs mb, int n, int par) {
     RL_STAMP(0);
