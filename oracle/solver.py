@@ -10,7 +10,8 @@ here:
   (Paige & Saunders 1975 MINRES with the stopping tests of SciPy's
   ``_isolve/minres.py``; Hestenes-Stiefel CG with SciPy's ``rtol*||b||``
   test).  These are what the HIP batched solver is compared with iterate by
-  iterate.  tests/test_oracle_solver.py checks them against SciPy itself.
+  iterate.  tests/test_oracle_golden.py checks them against SciPy itself and against
+  the reference's stored iterates.
 * ``iterative_solve``: the reference wrapper's stopping rule on top
   (reference runlmc/approx/iterative.py:23-62): inner tolerance
   min(1e-10, tol), maxiter n, and every 100th iteration an explicit residual
@@ -21,12 +22,20 @@ import numpy as np
 _EPS = np.finfo(np.float64).eps
 
 
-def minres_ps(matvec, b, rtol=1e-10, maxiter=None, callback=None):
+def minres_ps(matvec, b, rtol=1e-10, maxiter=None, callback=None, own_exits=True):
     """MINRES for symmetric A, x0 = 0, no preconditioner, no shift.
 
     Returns (x, info, itn, istop).  Follows SciPy 1.15.3
     scipy/sparse/linalg/_isolve/minres.py statement by statement (same
-    operation order, so iterates agree with SciPy's to roundoff)."""
+    operation order, so iterates agree with SciPy's to roundoff).
+
+    own_exits=False switches SciPy's own stopping tests off (istop 1-4: test1 /
+    test2 against rtol and against 1, Acond, epsx) so that only the caller's
+    callback or maxiter ends the iteration -- the mode in which the reference's
+    rule (iterative.py:36-42: explicit residual < tol every 100th iteration) is
+    the one that stops a solve, as in its published logs
+    (benchmarks/representation-cmp/out/inv-run-1.txt: counts are multiples of
+    100, residuals < 1e-4)."""
     b = np.asarray(b, dtype=np.float64)
     n = b.shape[0]
     if maxiter is None:
@@ -99,7 +108,10 @@ def minres_ps(matvec, b, rtol=1e-10, maxiter=None, callback=None):
         test2 = np.inf if Anorm == 0 else root / Anorm
         Acond = gmax / gmin
 
-        if istop == 0:
+        if istop == 0 and not own_exits:
+            if itn >= maxiter:
+                istop = 6
+        elif istop == 0:
             if 1 + test2 <= 1:
                 istop = 2
             if 1 + test1 <= 1:

@@ -16,9 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = [os.path.join(CSRC, 'runlmc_hip.hip')]
-HEADERS = [os.path.join(CSRC, f) for f in
-           ('rl_device.h', 'rl_fft.h', 'rl_kernels.h', 'rl_kernels2.h', 'rl_kernels3.h', 'rl_lowrank.h',
-            'rl_solver.h')] + [
+import glob
+HEADERS = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [
     os.path.join(ROOT, 'include', 'runlmc_hip.h')]
 HIP_LIB = os.path.join(CSRC, 'librunlmc_hip.so')
 EMU_DIR = os.path.join(ROOT, 'tests', 'emu')

@@ -895,7 +895,10 @@ def check_filter_form():
         # (seven and eleven tops: batches of 5 + 2 and 5 + 5 + 1 filters per row; 13 and 16
         # outputs: the rows of x fill all four waves, the mixed rows follow on every wave)
         for D, Q, m, k in ((3, 2, 2500, 3), (2, 3, 4101, 2), (5, 2, 700, 2), (2, 2, 20011, 2),
-                           (3, 5, 2200, 2), (13, 7, 1100, 2), (16, 3, 601, 1), (2, 11, 900, 2)):
+                           (3, 5, 2200, 2), (13, 7, 1100, 2), (16, 3, 601, 1), (2, 11, 900, 2),
+                           # (eight outputs: a rank-48 polynomial part ACCUMULATES onto the filter
+                           # part -- the layout of the benchmark's 'mix' family at C5)
+                           (8, 3, 2100, 2)):
             x = np.linspace(0, 1, m)
             gam = np.logspace(0, 1, Q) * (1.0 if m > 1200 else 3.0)
             mat = np.array([_matern32(x, g_) for g_ in gam])
@@ -975,7 +978,18 @@ def check_filter_form():
             forms, structured = gm.top_forms()
             assert forms == [1, 1, 2, 1][:Qm] and gm.lib is not None
             assert structured or D < 8, (forms, structured)      # (rank 48 at D < 8: transforms)
-            _close(_poly_product(gm, X), oracle(p1, Bs_=Bm))
+            if D >= 8:
+                # a short RBF length scale (rank 48 on every grid this size) next to the
+                # filter top: projection / expansion at rank 48, accumulating expansion
+                p1[0] = np.exp(-0.5 * 60.0 * x ** 2)
+                gm.set_lmc(p1, Am, km)
+                assert gm.top_forms() == ([1, 1, 2, 1][:Qm], True)
+                g48 = GridOp(D, m, 1)             # (that top alone: rank 48 it is)
+                g48.set_lmc(p1[:1], Am[:1], km[:1])
+                assert g48.form()[0] == 48
+            got = _poly_product(gm, X)
+            _close(got, oracle(p1, Bs_=Bm))
+            _close(got, gm.matmat_host(X), 1e-12)
         os.environ['RUNLMC_NO_FILTER'] = '1'
         g1 = GridOp(2, 2500, 1)
         g1.set_lmc(_matern32(np.linspace(0, 1, 2500), 2.0)[None], [rng.randn(1, 2)], [np.ones(2)])

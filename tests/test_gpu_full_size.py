@@ -294,6 +294,196 @@ def test_c5_gradient_at_fixed_iterations_both_forms(native, c5):
     assert _rel(alphas['poly'], xo) < 1e-8
 
 
+# ---------------------------------------------------------------------------
+# The reference benchmark's other kernel families (benchmarks/benchlib/bench.py:94,
+# 284-297; kern/std_periodic.py:44-67, kern/matern32.py:40-55) at the shapes
+# bench.py times them at: the instantiations and multi-tile paths only these
+# sizes reach (k_sf_apply<NS, 10> / <NS, 4>, persistent workgroups that draw
+# many tiles each, rank-48 projection / expansion on 1290 rows, a rank-48
+# polynomial part accumulating onto a filter part at D >= 8).
+
+FAMILY_FORMS = {'periodic': ['polynomial'] * 5, 'matern': ['filter'] * 5,
+                'mix': ['polynomial', 'polynomial', 'filter', 'polynomial', 'polynomial']}
+FORM_NAMES = {0: 'transform', 1: 'polynomial', 2: 'filter'}
+
+
+def _family_gridop(D, Q, m_data, kern):
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import GridOp
+    p = synth.make_problem(D, Q, 1, m_data, kern=kern)
+    g = GridOp(D, p.m, Q)
+    g.set_lmc(synth.tops(p), list(p.coreg_vecs), list(p.coreg_diags))
+    return p, g
+
+
+def _oracle_rows(p, X, rows):
+    from runlmc_amd.util import synth
+    Bs = ops.coreg_mats(list(p.coreg_vecs), list(p.coreg_diags))
+    toeps = [ops.BTTBOracle(t) for t in synth.tops(p)]
+    return {v: ops.grid_sum_matvec(Bs, toeps, X[v].numpy()) for v in rows}
+
+
+@pytest.mark.parametrize('kern', ['periodic', 'matern', 'mix'])
+def test_c5_family_product_vs_oracle(native, kern):
+    """C5 (D=10, Q=5, grid 100 004), 129 vectors, the forms bench.py reports for
+    the family: five of the outputs against the oracle's 'sum' representation at
+    1e-11, ALL 129 against the transform kernels of the same handle at 1e-12.
+    1290 rows: 196 chunks x 129 vectors = 25 284 tiles for k_sf_apply's 512
+    persistent workgroups (about 49 tiles each)."""
+    p, g = _family_gridop(10, 5, 100000, kern)
+    forms, structured = g.top_forms()
+    assert [FORM_NAMES[f] for f in forms] == FAMILY_FORMS[kern] and structured
+    rank, gate = g.form()
+    # (rl_gridop_form reports a rank only when EVERY top is in the polynomial form)
+    assert rank == (48 if kern == 'periodic' else 0) and 129 * p.D * p.m >= gate
+    gen = torch.Generator().manual_seed(23)
+    X = torch.randn(129, p.D * p.m, dtype=torch.float64, generator=gen)
+    X[128] = torch.cos(7 * torch.linspace(0, 1, p.D * p.m, dtype=torch.float64)) + 0.5   # coherent
+    Xd = X.to(g.device)
+    got = g.mvm(Xd).cpu().numpy()
+    for v, ref in _oracle_rows(p, X, (0, 1, 64, 127, 128)).items():
+        assert _rel(got[v], ref) < REL, (kern, v)
+    g.set_form_gate(1 << 62)
+    try:
+        fft = g.mvm(Xd).cpu().numpy()
+    finally:
+        g.set_form_gate(-1)
+    assert not np.array_equal(got, fft)
+    scale = np.abs(fft).max(axis=1, keepdims=True)
+    assert (np.abs(got - fft) / scale).max() < 1e-12
+    # the product does not depend on who draws which tile: a second run gives the same bits
+    assert np.array_equal(got, g.mvm(Xd).cpu().numpy())
+
+
+def test_c5_single_top_products_matern_and_derivative(native):
+    """The gradient's dK products at C5 size: a Matern-3/2 row (two states per
+    direction) and its d/d gamma row (-3 gamma r^2 exp(-sqrt(3) gamma r), three
+    states; reference kern/matern32.py:50-55) as single-top products over 17
+    and 129 vectors, against the oracle's Toeplitz product and the transform
+    kernels."""
+    from runlmc_amd._native import GridOp
+    from runlmc_amd.util import synth
+    D = 10
+    p = synth.make_problem(D, 5, 1, 100000, kern='matern')
+    kobj = synth.kernel_objects(p.kern_desc)[2]
+    tops = np.array([kobj.from_dist(p.grid_dists), kobj.kernel_gradient(p.grid_dists)[0]])
+    g = GridOp(D, p.m, 2)
+    g.set_lmc(tops, [None, None], [np.zeros(D)] * 2)
+    assert g.top_forms()[0] == [2, 2]
+    gen = torch.Generator().manual_seed(29)
+    X = torch.randn(129, D * p.m, dtype=torch.float64, generator=gen)
+    Xd = X.to(g.device)
+    for t in range(2):
+        toep = ops.BTTBOracle(tops[t])
+        for nvec in (17, 129):
+            got = g.mvm(Xd[:nvec], top=t).cpu().numpy()
+            for v in (0, nvec - 1):
+                ref = np.concatenate([toep.matvec(r) for r in X[v].numpy().reshape(D, p.m)])
+                assert _rel(got[v], ref) < REL, (t, nvec, v)
+        g.set_form_gate(1 << 62)
+        try:
+            fft = g.mvm(Xd, top=t).cpu().numpy()
+        finally:
+            g.set_form_gate(-1)
+        got = g.mvm(Xd, top=t).cpu().numpy()
+        assert (np.abs(got - fft) / np.abs(fft).max(axis=1, keepdims=True)).max() < 1e-12
+
+
+@pytest.mark.parametrize('kern', ['periodic', 'matern', 'mix'])
+@pytest.mark.parametrize('nvec', [17, 1024])
+def test_c2_family_product_vs_oracle(native, kern, nvec):
+    """The C2 shape (D=4, Q=3, grid 5004) with the batch gate lifted -- the D = 4
+    instantiations -- at the solver's 17 vectors and at 1024 vectors (10 chunks x
+    1024 = 10 240 tiles): oracle on four vectors at 1e-11, the transform kernels on
+    all of them at 1e-12.  ('mix' at D < 8 with a rank-48 top is handed to the
+    transform kernels by forms_setup; the single-top products keep their forms.)"""
+    p, g = _family_gridop(4, 3, 5000, kern)
+    forms, structured = g.top_forms()
+    want = {'periodic': [1, 1, 1], 'matern': [2, 2, 2], 'mix': [1, 1, 2]}[kern]
+    assert forms == want, forms
+    gen = torch.Generator().manual_seed(31 + nvec)
+    X = torch.randn(nvec, p.D * p.m, dtype=torch.float64, generator=gen)
+    Xd = X.to(g.device)
+    g.set_form_gate(0)
+    try:
+        got = g.mvm(Xd).cpu().numpy()
+        tops_got = [g.mvm(Xd, top=q).cpu().numpy() for q in range(p.Q)]
+    finally:
+        g.set_form_gate(-1)
+    for v, ref in _oracle_rows(p, X, (0, 1, nvec // 2, nvec - 1)).items():
+        assert _rel(got[v], ref) < REL, (kern, v)
+    g.set_form_gate(1 << 62)
+    try:
+        fft = g.mvm(Xd).cpu().numpy()
+        tops_fft = [g.mvm(Xd, top=q).cpu().numpy() for q in range(p.Q)]
+    finally:
+        g.set_form_gate(-1)
+    assert (np.abs(got - fft) / np.abs(fft).max(axis=1, keepdims=True)).max() < 1e-12
+    for a, b in zip(tops_got, tops_fft):
+        assert (np.abs(a - b) / np.abs(b).max(axis=1, keepdims=True)).max() < 1e-12
+    if structured:
+        assert not np.array_equal(got, fft)
+
+
+@pytest.mark.parametrize('kern', ['matern', 'mix'])
+def test_c5_family_gradient_at_fixed_iterations(native, kern):
+    """As test_c5_gradient_at_fixed_iterations_both_forms for the Matern and mix
+    families: after CAP MINRES iterations the complete gradient (all four
+    families of partial derivatives, kernel_gradients through the filter form's
+    three-state derivative rows) from the structured forms and from the transform
+    kernels of the same handle agree to 1e-7 of its norm, alpha to 1e-8 and with
+    the oracle's MINRES."""
+    from runlmc_amd.util import synth
+    from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
+    from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+    from runlmc_amd.lmc.stochastic_deriv import StochasticDeriv
+    from runlmc_amd._native import solve_batch
+    from oracle.kernels import Matern32Spec, StdPeriodicSpec
+    p = synth.make_problem(10, 5, 1, 100000, kern=kern)
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    rng = np.random.RandomState(4321)
+    nprobe = 16
+    rs = rng.randint(0, 2, (nprobe, p.n)) * 2.0 - 1
+    B = np.vstack([p.y, rs])
+
+    class Fixed:
+        def __init__(self, X, dev):
+            self.X, self.dev = X, dev
+
+        def generate(self, K, y, rs=None):
+            t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
+            return StochasticDeriv(self.X[0], t(B[1:]), self.X[1:], nprobe)
+
+    grads, alphas = {}, {}
+    for form in ('structured', 'fft'):
+        K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+        op = K.device_operator()
+        assert op.grid.top_forms()[1]
+        op.grid.set_form_gate(0 if form == 'structured' else 1 << 62)
+        X, it = solve_batch(op, torch.from_numpy(B).to(op.device), tol=1e-4, maxiter=CAP)[:2]
+        assert np.all(np.array(it) == CAP)
+        lik = ApproxLMCLikelihood(fk, K, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.Ys,
+                                  Fixed(X, op.device))
+        g = (lik.coreg_vec_gradients(), lik.coreg_diags_gradients(), lik.kernel_gradients(),
+             lik.noise_gradient())
+        grads[form] = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.hstack(g[2])] + [g[3]]])
+        alphas[form] = X[0].cpu().numpy()
+    gn = np.linalg.norm(grads['fft'])
+    diff = np.linalg.norm(grads['structured'] - grads['fft']) / gn
+    print('C5 %s, %d iterations: gradient norm %.4g, forms differ by %.3g of it; alpha by %.3g'
+          % (kern, CAP, gn, diff, _rel(alphas['structured'], alphas['fft'])))
+    assert diff < 1e-7
+    assert _rel(alphas['structured'], alphas['fft']) < 1e-8
+    make = {'rbf': RBFSpec, 'periodic': StdPeriodicSpec, 'matern': Matern32Spec}
+    spec = KernelSpec(p.D, [make[d[0]](*d[1:]) for d in p.kern_desc], list(p.coreg_vecs),
+                      list(p.coreg_diags), p.noise)
+    spec.set_input_dim(1)
+    oop = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    xo = minres_ps(oop.matvec, B[0], rtol=1e-10, maxiter=CAP)[0]
+    assert _rel(alphas['structured'], xo) < 1e-8
+
+
 def test_polynomial_gate_boundary_full_size():
     """The acceptance gate at its boundary on the C5 grid (100 004 points): see
     parity_suite.check_polynomial_gate_boundary."""
