@@ -353,7 +353,7 @@ def time_steps(fn, steps, warmup, world, dev):
 
 def measured_traffic(config, batch, form='fft'):
     """HBM-side bytes per step of the grid product from this round's PMC
-    passes (tools/pmc.sh -> profiles/r02/traffic.json), or (None, None).
+    passes (tools/traffic_families.py -> TRAFFIC_FILE), or (None, None).
     Entries are keyed config:batch for the transform kernels and
     config:batch:poly for the polynomial form."""
     try:
@@ -469,8 +469,9 @@ def product_form(g, batch, D, m):
                                'kernels), D=%d' % (rank_poly, D))
     if all(f == 2 for f in forms):
         return 'filter', names, ('grid MVM, recursive-filter form of exponential-polynomial top '
-                                 'rows (k_sf_carries -> k_sf_scan -> k_sf_apply: block maps on the '
-                                 'fp64 matrix cores, states chained by DPP), D=%d' % D)
+                                 'rows (k_sf_carries -> k_sf_scan -> k_sf_apply: one lane per (row, '
+                                 '32-point segment) runs the recurrences, segments chained over DPP '
+                                 'rows, persistent workgroups), D=%d' % D)
     return 'filter+poly', names, ('grid MVM, filter part (k_sf_*) + polynomial part (k_lr_*, '
                                   'accumulating), D=%d' % D)
 
@@ -611,9 +612,10 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
             np.random.seed(4321)
             # the config's N probes in total, dealt round-robin to the ranks
             # (strong scaling of one optimiser step)
-            # (drawn as the reference draws them -- int64 -- and kept as one byte per entry:
-            # drawing and narrowing are data preparation, outside the timed step)
-            probes = (np.random.randint(0, 2, (n_probes, pe.n)) * 2 - 1).astype(np.int8)
+            # (drawn as the reference draws them and as StochasticDerivService.draw_probes
+            # hands them to generate(): int64.  Checking and narrowing them to one byte per
+            # entry is INSIDE the timed step, as it is for a caller of the model)
+            probes = np.random.randint(0, 2, (n_probes, pe.n)) * 2 - 1
             group = None
             if args.force_dist or world > 1:
                 import torch.distributed as tdist

@@ -149,7 +149,15 @@ int rl_ski_apply_w_term(rl_ski* s, int term, const double* G, double* Y, int nve
  * together, each with its own recurrence scalars and stopping state.
  *   B, X      dev [nrhs][n]   (X is written; initial guess is 0 as in the
  *                              reference)
- *   method    RL_MINRES (reference default, stochastic_deriv.py:37) or RL_CG
+ *   method    RL_MINRES (reference default, stochastic_deriv.py:37), RL_CG, or
+ *             RL_MINRES_RULE: MINRES with SciPy's own stopping tests (istop 1-4:
+ *             test1 / test2 / Acond / epsx) switched off, so that a system ends
+ *             only on the reference's explicit residual rule below or at
+ *             maxiter -- how the reference's PUBLISHED runs ended (iteration
+ *             counts are multiples of 100 and residuals < 1e-4 in
+ *             benchmarks/representation-cmp/out/inv-run-1.txt:3-20; SciPy
+ *             1.15's test1 <= rtol exit fires long before on the same systems,
+ *             DESIGN.md section 5).  Needs check_every > 0.
  *   tol       absolute residual target of the reference's rule; the inner
  *             method runs with rtol = min(1e-10, tol) (iterative.py:50-51)
  *   check_every  explicit-residual check period (reference: 100,
@@ -167,6 +175,7 @@ int rl_ski_apply_w_term(rl_ski* s, int term, const double* G, double* Y, int nve
  * RUNLMC_WS_CACHE_MB bounds what is kept).                                     */
 #define RL_MINRES 0
 #define RL_CG 1
+#define RL_MINRES_RULE 2
 int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method, double tol,
                    int check_every, int maxiter, int* iters_out, double* resid_out,
                    int* istop_out, void* stream);
@@ -178,10 +187,12 @@ int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method, 
  * estimate of log det K~ at no extra operator products -- the matrix-free
  * log-determinant the reference lists as future work (README.md:88-89; its
  * own log_det_K is a dense Cholesky, models/interpolated_llgp.py:262-276).
- * RL_MINRES only; lanczos_out may be NULL (then identical to rl_solve_batch). */
-int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, double tol,
-                           int check_every, int maxiter, int* iters_out, double* resid_out,
-                           int* istop_out, double* lanczos_out, int lanczos_cap, void* stream);
+ * method: RL_MINRES or RL_MINRES_RULE; lanczos_out may be NULL (then identical to
+ * rl_solve_batch). */
+int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, int method,
+                           double tol, int check_every, int maxiter, int* iters_out,
+                           double* resid_out, int* istop_out, double* lanczos_out,
+                           int lanczos_cap, void* stream);
 
 /* ---- partial sums of the Hutchinson gradient --------------------------------
  * Replace the P*(N+1) operator products of StochasticDeriv.d_normal_quadratic

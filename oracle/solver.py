@@ -175,8 +175,10 @@ class _EarlyExit(Exception):
 
 
 def iterative_solve(matvec, y, tol=1e-4, minres=True, check_every=100,
-                    use_scipy=False):
+                    use_scipy=False, own_exits=True):
     """The reference's Iterative.solve (approx/iterative.py:23-62).
+    own_exits=False: MINRES's own stopping tests off (see minres_ps), so the
+    reference's residual rule or n iterations end the solve.
 
     Returns (x, iterations, final_residual_norm, converged_flag)."""
     y = np.asarray(y, dtype=np.float64)
@@ -199,7 +201,7 @@ def iterative_solve(matvec, y, tol=1e-4, minres=True, check_every=100,
             x, info = fn(op, y, rtol=inner_tol, maxiter=n, callback=cb)
         elif minres:
             x, info, _, _ = minres_ps(matvec, y, rtol=inner_tol, maxiter=n,
-                                      callback=cb)
+                                      callback=cb, own_exits=own_exits)
         else:
             x, info, _ = cg_hs(matvec, y, rtol=inner_tol, maxiter=n,
                                callback=cb)

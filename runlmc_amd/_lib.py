@@ -50,7 +50,7 @@ _SIGNATURES = {
     'rl_ski_apply_wt': [_vp, _vp, _vp, _i, _vp],
     'rl_ski_apply_w': [_vp, _vp, _vp, _i, _vp],
     'rl_solve_batch': [_vp, _vp, _vp, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp],
-    'rl_solve_batch_lanczos': [_vp, _vp, _vp, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    'rl_solve_batch_lanczos': [_vp, _vp, _vp, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 }

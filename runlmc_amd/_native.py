@@ -262,6 +262,7 @@ class SkiOp:
 
 
 MINRES, CG = 0, 1
+MINRES_RULE = 2     # MINRES with SciPy's own stopping tests off (include/runlmc_hip.h)
 
 
 def solve_batch(ski, B, method=MINRES, tol=1e-4, check_every=100, maxiter=0,
@@ -276,11 +277,11 @@ def solve_batch(ski, B, method=MINRES, tol=1e-4, check_every=100, maxiter=0,
     istop = np.zeros(k, dtype=np.int32)
     resid = np.zeros(k, dtype=np.float64)
     if lanczos_cap > 0:
-        if method != MINRES:
+        if method not in (MINRES, MINRES_RULE):
             raise ValueError('Lanczos coefficients come from MINRES only')
         lz = np.zeros((k, int(lanczos_cap), 2), dtype=np.float64)
         ski.lib.call('rl_solve_batch_lanczos', ski.handle, dev_ptr(B), dev_ptr(X),
-                     k, float(tol), int(check_every), int(maxiter),
+                     k, int(method), float(tol), int(check_every), int(maxiter),
                      host_ptr(iters), host_ptr(resid), host_ptr(istop),
                      host_ptr(lz), int(lanczos_cap), ski.lib.stream_ptr(ski.device))
         return X, iters, resid, istop, lz

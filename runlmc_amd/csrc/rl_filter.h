@@ -56,6 +56,7 @@
 #define RL_SF_S 32                         // points per segment: one lane's share of a row
 #define RL_SF_LPR (RL_SF_G / RL_SF_S)      // segments per row of a chunk (= a DPP row of lanes)
 #define RL_SF_PAD (RL_SF_G + RL_SF_LPR)    // doubles per LDS row: one pad per segment
+#define RL_SF_NSEG 32                      // segments of the chunk chain in k_sf_scan
 #define RL_SF_MAXTOPS 16                   // filter tops per operator at most
 #define RL_SF_TOL 2e-14                    // accepted sum|t - model| / sum|t|
 
@@ -69,6 +70,7 @@ struct SfTop {
     double rho;       // decay per grid step
     double c[3];      // t_i = (c0 + c1 i + c2 i^2) rho^i
     double rG;        // rho^G: from chunk to chunk
+    double rL;        // rho^(G * seglen): from segment to segment of k_sf_scan's chunk chain
 };
 
 // one operator's filter part (device pointers; NF tops, nfac rank-one factors)
@@ -343,7 +345,7 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
     RL_SMEM(smem);
     // (k_sf_apply, launched behind this kernel, deals its tiles through this counter)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *next_tile = 0;
-    constexpr int NCD = 8, NSEG = 32;
+    constexpr int NCD = 8, NSEG = RL_SF_NSEG;
     double* agg = reinterpret_cast<double*>(smem);       // [NSEG][NCD][NS]
     const int NF = sp.NF, nchan = D * NF + sp.nfac, ncd = 2 * nchan;
     const int tid = threadIdx.x, cdl = tid & (NCD - 1), seg = tid / NCD, v = blockIdx.y;
@@ -378,8 +380,9 @@ k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams s
     for (int k = 0; k < NS; ++k) agg[(seg * NCD + cdl) * NS + k] = st[k];
     __syncthreads();
     // the segments before this one (all of them full: seglen chunks each)
-    double rL = 1.0;
-    for (int i = 0; i < seglen; ++i) rL *= rG;
+    // (a power the host computed in long double and rounded once, like every factor a
+    // state is carried by across chunks: seglen grows with the grid)
+    const double rL = sp.tops[j].rL;
     const double nL = n * seglen;
 #pragma unroll
     for (int k = 0; k < NS; ++k) st[k] = 0.0;

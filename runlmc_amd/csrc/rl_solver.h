@@ -430,7 +430,10 @@ k_minres_test(MinresBufs mb, const double* __restrict__ partialC, int nblk, int 
         const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? inf : rnorm / (Anorm * ynorm);
         const double test2 = Anorm == 0.0 ? inf : st[S_ROOT] / Anorm;
         const double Acond = st[S_GMAX] / st[S_GMIN];
-        if (istop == 0) {
+        if (istop == 0 && rtol < 0.0) {
+            // RL_MINRES_RULE: SciPy's own tests off, the caller's residual rule decides
+            if (itn >= maxiter) istop = 6;
+        } else if (istop == 0) {
             const double t1 = 1.0 + test1, t2 = 1.0 + test2;
             if (t2 <= 1.0) istop = 2;
             if (t1 <= 1.0) istop = 1;
@@ -1085,7 +1088,10 @@ __device__ __forceinline__ int minres_stop_test(const double* st, double ynorm, 
     const double test1 = (ynorm == 0.0 || Anorm == 0.0) ? inf : rnorm / (Anorm * ynorm);
     const double test2 = Anorm == 0.0 ? inf : st[S_ROOT] / Anorm;
     const double Acond = st[S_GMAX] / st[S_GMIN];
-    if (istop == 0) {
+    if (istop == 0 && rtol < 0.0) {
+        // RL_MINRES_RULE: SciPy's own tests off, the caller's residual rule decides
+        if (itn >= maxiter) istop = 6;
+    } else if (istop == 0) {
         const double t1 = 1.0 + test1, t2 = 1.0 + test2;
         if (t2 <= 1.0) istop = 2;
         if (t1 <= 1.0) istop = 1;

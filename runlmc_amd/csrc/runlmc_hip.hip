@@ -313,6 +313,7 @@ struct rl_gridop {
     // polynomial-subspace form for smooth kernels (rl_lowrank.h)
     bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
     bool lr_ok = false;         // verified against the FFT path for the current parameters
+    bool lr_round_try = false;  // the solver's polynomial rounds may use this grid
     bool defer_expand = false;  // ski_mvm_int: leave the expansion to the W kernel (k_spmv_w_poly) ...
     bool expand_deferred = false;   // ... done: lr_zhat holds the mixed coefficients of the batch
     int lr_rejects = 0;         // consecutive parameter sets with a top the verification rejected
@@ -647,10 +648,15 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
         rows_ok = true;
     }
     g->v2 = g->code1 != 0 && rows_ok;
-    // polynomial-subspace form (rl_lowrank.h): 1-D grids long enough for the
-    // three-kernel FFT path, decided per parameter set by verification
-    // (short grids only matter to the solver's opt-in polynomial rounds)
-    g->lr_try = m1 == 0 && m >= (g->kn.poly_round ? 2 * RL_LR_RMAX : 2048) && !g->kn.no_lowrank;
+    // polynomial-subspace form (rl_lowrank.h): any 1-D grid of at least twice the largest
+    // rank, decided per parameter set by verification -- and only when a batch above the
+    // gate (2^20 elements) asks for it, so handles that see small batches only (the
+    // real-data fits) never pay the verification.  (Until round 4 grids under 2048 points
+    // were excluded: RBF at m = 1000 then saturated at 6-11 % on the single-tile kernel.)
+    g->lr_try = m1 == 0 && m >= 2 * RL_LR_RMAX && !g->kn.no_lowrank;
+    // the solver's two-kernel polynomial rounds: grids of >= 2048 points by default,
+    // shorter ones on request (RUNLMC_POLY_ROUND=1)
+    g->lr_round_try = g->lr_try && (m >= 2048 || g->kn.poly_round);
     // recursive-filter form (rl_filter.h): any 1-D grid; decided per top row from the row
     g->sf_try = m1 == 0 && m >= 64 && !g->kn.no_filter;
     g->lr_min = lr_min_elements(g);
@@ -1317,6 +1323,10 @@ static int lr_make_basis(rl_gridop* g) {
 // longest chunk (the 64-lane reduction at its end costs about 8 lane-steps) that
 // still leaves whole rounds of resident workgroups (2 per CU) well filled.
 static int lr_steps(const rl_gridop* g, int nrows, int R) {
+    // (a short grid is ONE chunk of as few lane-steps as hold its slots; a multiple of the
+    // request ring's length)
+    const int slots = (g->m + 1) / 2;
+    if (slots <= 64 * RL_LR_T) return std::max(4, ((slots + 63) / 64 + 3) / 4 * 4);
     const int rowblocks = (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R);
     const double resident = 2.0 * RL_LR_CUS;
     int best = RL_LR_T;
@@ -1550,10 +1560,13 @@ static bool sf_detect(const double* t, int m, SfFit* fit) {
     return false;
 }
 
-static void sf_device_top(const SfFit& f, SfTop* tp, SfBlk* bk, double* pw) {
+static void sf_device_top(const SfFit& f, int m, SfTop* tp, SfBlk* bk, double* pw) {
     tp->rho = (double)expl(-f.ah);
     for (int k = 0; k < 3; ++k) tp->c[k] = (double)f.c[k];
     tp->rG = (double)expl(-f.ah * RL_SF_G);
+    // k_sf_scan chains the chunks in 32 segments of seglen chunks each
+    const int nchunks = (m + RL_SF_G - 1) / RL_SF_G, seglen = (nchunks + RL_SF_NSEG - 1) / RL_SF_NSEG;
+    tp->rL = (double)expl(-f.ah * RL_SF_G * (long double)seglen);
     for (int j = 0; j <= RL_SF_G; ++j) pw[j] = (double)expl(-f.ah * j);
     bk->rho = tp->rho;
     for (int k = 0; k < 3; ++k) bk->c[k] = tp->c[k];
@@ -1602,9 +1615,10 @@ static size_t sf_apply_lds(int D, int nfac, int NF, int nthr) {
 
 // Y = [filter part] X: carries -> scan -> apply
 template <int NS>
-static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const double* X,
-                      double* Y, int nvec, hipStream_t st) {
+static int sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const double* X,
+                     double* Y, int nvec, hipStream_t st) {
     const int D = g->D, nrows = nvec * D, nch = sf_nchunks(g);
+    if (D < 1 || D > 16) return fail(RL_ELIMIT, "filter form: D outside 1..16");
     // rows per carries workgroup: the filter powers are staged once per workgroup
     const int rpw = nrows >= 16 * 64 ? 64 : 16;
     RL_LAUNCH((k_sf_carries<NS>), dim3(nch, (nrows + rpw - 1) / rpw), dim3(256),
@@ -1636,19 +1650,19 @@ static void sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, cons
         RL_SF_APPLY(5); RL_SF_APPLY(6); RL_SF_APPLY(7); RL_SF_APPLY(8);
         RL_SF_APPLY(9); RL_SF_APPLY(10); RL_SF_APPLY(11); RL_SF_APPLY(12);
         RL_SF_APPLY(13); RL_SF_APPLY(14); RL_SF_APPLY(15); RL_SF_APPLY(16);
-        default: break;
+        default: return fail(RL_ELIMIT, "filter form: no k_sf_apply for this D");
     }
 #undef RL_SF_APPLY
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
 // the operator's filter part (every filter top with its couplings)
 static int sf_apply_all(rl_gridop* g, const double* X, double* Y, int nvec, hipStream_t st) {
     SfParams sp{g->sf_n, g->sf_nfac, g->sf_tops, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW,
                 g->sf_facJ};
-    if (g->sf_ns == 3) sf_launch<3>(g, sp, g->sf_blob, X, Y, nvec, st);
-    else sf_launch<2>(g, sp, g->sf_blob, X, Y, nvec, st);
-    RL_HIP(hipGetLastError());
-    return RL_OK;
+    return g->sf_ns == 3 ? sf_launch<3>(g, sp, g->sf_blob, X, Y, nvec, st)
+                         : sf_launch<2>(g, sp, g->sf_blob, X, Y, nvec, st);
 }
 // (I_D (x) T_q) X for one filter top
 static int sf_apply_top(rl_gridop* g, int q, const double* X, double* Y, int nvec, hipStream_t st) {
@@ -1656,10 +1670,8 @@ static int sf_apply_top(rl_gridop* g, int q, const double* X, double* Y, int nve
     SfParams sp{1, 0, g->sf_tops + j, g->sf_pw + (size_t)j * (RL_SF_G + 1), g->ones, nullptr,
                 nullptr, nullptr};
     const double* blob = g->sf_blob_top + (size_t)j * sf_blob_doubles(1, 0, g->D);
-    if (g->sf_top_ns[q] == 3) sf_launch<3>(g, sp, blob, X, Y, nvec, st);
-    else sf_launch<2>(g, sp, blob, X, Y, nvec, st);
-    RL_HIP(hipGetLastError());
-    return RL_OK;
+    return g->sf_top_ns[q] == 3 ? sf_launch<3>(g, sp, blob, X, Y, nvec, st)
+                                : sf_launch<2>(g, sp, blob, X, Y, nvec, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -1798,7 +1810,6 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
     std::vector<double> back;
     std::vector<char> best;
     for (int r : {24, 32, 48}) {
-        if (r > 24 && m < 2048) break;      // (short grids: only the solver's rank-24 rounds use the form)
         g->lr_r = r;
         const int nvr = (r + RL_LR_EXTRA + D - 1) / D, nrows = nvr * D;
         RL_TRY(lr_reserve(g, std::max(nvr, 1)));
@@ -1937,17 +1948,22 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
     // 3. tables.  Filter tops: parameters + powers (single-top products need them
     //    whatever the operator as a whole does)
     if (nfilt) {
-        if (!g->sf_tops) {
-            RL_HIP(hipMalloc((void**)&g->sf_tops, (size_t)g->max_tops * sizeof(SfTop)));
-            RL_HIP(hipMalloc((void**)&g->sf_next, sizeof(int)));
-            RL_HIP(hipMalloc((void**)&g->sf_blob, (size_t)sf_blob_doubles(g->max_tops, g->max_fac, D) * sizeof(double)));
-            RL_HIP(hipMalloc((void**)&g->sf_blob_top, (size_t)g->max_tops * sf_blob_doubles(1, 0, D) * sizeof(double)));
-            RL_HIP(hipMalloc((void**)&g->sf_pw, (size_t)g->max_tops * (RL_SF_G + 1) * sizeof(double)));
-            RL_HIP(hipMalloc((void**)&g->sf_kappa, (size_t)g->max_tops * D * sizeof(double)));
-            RL_HIP(hipMalloc((void**)&g->sf_facA, (size_t)g->max_fac * D * sizeof(double)));
-            RL_HIP(hipMalloc((void**)&g->sf_facAW, (size_t)g->max_fac * D * sizeof(double)));
-            RL_HIP(hipMalloc((void**)&g->sf_facJ, (size_t)g->max_fac * sizeof(int)));
-        }
+        // (each buffer under its own guard: an allocation that fails part-way is retried
+        // at the next parameter update instead of leaving later pointers null)
+        auto need = [](void** p, size_t bytes) -> int {
+            if (*p) return RL_OK;
+            RL_HIP(hipMalloc(p, bytes));
+            return RL_OK;
+        };
+        RL_TRY(need((void**)&g->sf_tops, (size_t)g->max_tops * sizeof(SfTop)));
+        RL_TRY(need((void**)&g->sf_next, sizeof(int)));
+        RL_TRY(need((void**)&g->sf_blob, (size_t)sf_blob_doubles(g->max_tops, g->max_fac, D) * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_blob_top, (size_t)g->max_tops * sf_blob_doubles(1, 0, D) * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_pw, (size_t)g->max_tops * (RL_SF_G + 1) * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_kappa, (size_t)g->max_tops * D * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_facA, (size_t)std::max(g->max_fac, 1) * D * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_facAW, (size_t)std::max(g->max_fac, 1) * D * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_facJ, (size_t)std::max(g->max_fac, 1) * sizeof(int)));
         std::vector<SfTop> tops(nfilt);
         std::vector<SfBlk> blks(nfilt);
         std::vector<double> pw((size_t)nfilt * (RL_SF_G + 1)), kp((size_t)nfilt * D), fa, faw;
@@ -1956,7 +1972,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         for (int q = 0; q < Q; ++q) {
             const int j = g->sf_slot[q];
             if (j < 0) continue;
-            sf_device_top(fits[q], &tops[j], &blks[j], pw.data() + (size_t)j * (RL_SF_G + 1));
+            sf_device_top(fits[q], m, &tops[j], &blks[j], pw.data() + (size_t)j * (RL_SF_G + 1));
             for (int a = 0; a < D; ++a) kp[(size_t)j * D + a] = kap[(size_t)q * D + a];
             ns = std::max(ns, g->sf_top_ns[q]);
         }
@@ -3020,7 +3036,7 @@ static int poly_round_prepare(rl_ski* s, int nrhs, int max_blk, bool* ok) {
     *ok = false;
     rl_gridop* g = s->g;
     if (!s->extra.empty() || s->W4_base == nullptr || s->h_base.empty() ||
-        !g->lr_try || s->poly_nblk < 0 || s->kn.no_poly_round || g->kn.no_poly_round)
+        !g->lr_round_try || s->poly_nblk < 0 || s->kn.no_poly_round || g->kn.no_poly_round)
         return RL_OK;
     if (s->poly_nblk == 0) {
         const int D = g->D, m = g->m, n = s->n;
@@ -3153,12 +3169,14 @@ extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, i
 }
 
 extern "C" int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs,
-                                      double tol, int check_every, int maxiter, int* iters_out,
-                                      double* resid_out, int* istop_out, double* lanczos_out,
-                                      int lanczos_cap, void* stream) {
+                                      int method, double tol, int check_every, int maxiter,
+                                      int* iters_out, double* resid_out, int* istop_out,
+                                      double* lanczos_out, int lanczos_cap, void* stream) {
     if (lanczos_out != nullptr && lanczos_cap < 1)
         return fail(RL_EINVAL, "rl_solve_batch_lanczos: lanczos_cap < 1");
-    return solve_batch_impl(s, B, X, nrhs, RL_MINRES, tol, check_every, maxiter, iters_out,
+    if (method != RL_MINRES && method != RL_MINRES_RULE)
+        return fail(RL_EINVAL, "rl_solve_batch_lanczos: RL_MINRES or RL_MINRES_RULE only");
+    return solve_batch_impl(s, B, X, nrhs, method, tol, check_every, maxiter, iters_out,
                             resid_out, istop_out, lanczos_out, lanczos_cap, stream);
 }
 
@@ -3168,8 +3186,16 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
                             int lanczos_cap, void* stream) {
     if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_batch: NULL argument");
     if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_batch: nrhs < 0");
-    if (method != RL_MINRES && method != RL_CG)
+    if (method != RL_MINRES && method != RL_CG && method != RL_MINRES_RULE)
         return fail(RL_EINVAL, "rl_solve_batch: unknown method");
+    // RL_MINRES_RULE: MINRES whose own stopping tests are off -- a system ends on the
+    // reference's explicit residual rule or at maxiter (the kernels read rtol < 0)
+    const bool rule_only = method == RL_MINRES_RULE;
+    if (rule_only) {
+        if (check_every <= 0)
+            return fail(RL_EINVAL, "rl_solve_batch: RL_MINRES_RULE needs check_every > 0");
+        method = RL_MINRES;
+    }
     if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_batch: tol must be > 0");
     if (check_every < 0) return fail(RL_EINVAL, "rl_solve_batch: check_every < 0");
     if (nrhs == 0) return RL_OK;
@@ -3182,7 +3208,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     hipStream_t st = s->solver_stream;
     const int n = s->n;
     if (maxiter <= 0) maxiter = n;
-    const double rtol = tol < 1e-10 ? tol : 1e-10;
+    const double rtol = rule_only ? -1.0 : (tol < 1e-10 ? tol : 1e-10);
     const int rows_per_blk = 1024;       // (512 / 320 / 256 measured slower at C2)
     int nblk = (n + rows_per_blk - 1) / rows_per_blk;
     int max_blk = 64;       // <= RL_SOLVER_THREADS: the partial sums are read one per thread

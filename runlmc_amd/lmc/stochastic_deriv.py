@@ -70,11 +70,16 @@ class StochasticDerivService:
         Bfull = torch.zeros((nrow, n), dtype=torch.float64, device=dev)
         Bfull[yat] = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(dev)
         if nm:
-            small = mine_rows.dtype.kind in 'iu'
+            # (signed integer kinds only: the values are checked BEFORE they are narrowed --
+            # 255 or 257 would wrap to -1 / +1 in one byte and pass a check made afterwards)
+            small = mine_rows.dtype.kind == 'i'
             if small:
-                # (torch narrows on all host cores; NumPy's astype on one)
-                narrow = torch.from_numpy(mine_rows).to(torch.int8).to(dev)
-                small = bool((narrow.abs() == 1).all())           # (+-1 by contract; anything else:
+                wide = torch.from_numpy(mine_rows)
+                lo, hi = torch.aminmax(wide)                      # (torch: all host cores)
+                small = int(lo) >= -1 and int(hi) <= 1
+            if small:
+                narrow = wide.to(torch.int8).to(dev)
+                small = bool((narrow != 0).all())                 # (+-1 by contract; anything else:
             if small:                                             # the plain way)
                 Bfull[first:first + nm] = narrow
             else:

@@ -56,6 +56,10 @@ def test_solver_cg():
     ps.check_solver('lmc_small', minres=False)
 
 
+def test_solver_reference_rule():
+    print(ps.check_solver_reference_rule())
+
+
 def test_solver_edge_cases():
     ps.check_solver_edge_cases()
 

@@ -1,5 +1,6 @@
 """Where one NLL+gradient step spends its time (GPU box): operator update,
-probe solves, gradient partial sums.   python tools/nll_breakdown.py [c2|c5]"""
+probe solves, gradient partial sums.   python tools/nll_breakdown.py [c2|c5] [probes] [kern]
+(probes: e.g. 16 = one rank's share of an 8-way split of C5's 128)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,7 +11,9 @@ from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'c2'
 D, Q, R, m, npr = synth.CONFIGS[cfg]
-p = synth.make_problem(D, Q, R, m)
+if len(sys.argv) > 2:
+    npr = int(sys.argv[2])
+p = synth.make_problem(D, Q, R, m, kern=sys.argv[3] if len(sys.argv) > 3 else 'rbf')
 fk = synth.functional_kernel(p)
 ad = (0,)
 K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
@@ -35,7 +38,7 @@ for rep in range(3):
     g = (lik.coreg_vec_gradients(), lik.coreg_diags_gradients(), lik.kernel_gradients(),
          lik.noise_gradient())
     t4 = sync()
-    print('%s rep %d: update %.2f ms | solves (%d rounds) %.2f ms | partial sums %.2f ms | '
+    print('%s (%d probes) rep %d: update %.2f ms | solves (%d rounds) %.2f ms | partial sums %.2f ms | '
           'assembly %.2f ms | total %.2f ms' % (
-              cfg, rep, (t1 - t0) * 1e3, int(np.max(lik.deriv.iterations)), (t2 - t1) * 1e3,
+              cfg, npr, rep, (t1 - t0) * 1e3, int(np.max(lik.deriv.iterations)), (t2 - t1) * 1e3,
               (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3))
