@@ -24,7 +24,26 @@ struct Tile2 {
     int R;              // rows per k2_rows_mix workgroup (power of two)
     unsigned colsMagic; // fast_div magic of R * D
     int thrC, thrR;     // workgroup sizes of the column / row kernels
+    int aff;            // > 0: pair-affine order over this many pairs (affine_tile below)
 };
+
+// Pair-affine order (round 4).  The three kernels of a product hand a pair's
+// intermediates T[pair] from one to the next through memory; each XCD has its own
+// 4 MB L2, and workgroups go to the XCDs round robin by linear block id.  With the
+// orders above, the tiles that write T[pair] in one kernel and those that read it in the
+// next sit on different XCDs, so every read of T comes from HBM / Infinity Cache.  In
+// this order XCD k owns the pairs k, k + 8, ... in ALL three kernels (a 1-D launch of
+// 8 * ceil(pairs / 8) * tiles workgroups; those of a pair past the end return at
+// once), and the host keeps a chunk's intermediates per XCD inside its L2: a kernel's
+// reads of T are then served by the L2 the previous kernel wrote through.  (Placement
+// is the dispatcher's observed behaviour: only speed depends on it.)
+__device__ __forceinline__ bool affine_tile(const Tile2& tp, int tiles, int* tile, int* pair) {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int pl = slot / tiles;
+    *tile = slot - pl * tiles;
+    *pair = pl * 8 + xcd;
+    return *pair < tp.aff;
+}
 
 // Column-tile index of this workgroup.  Workgroups go to the eight XCDs round
 // robin by linear block id, so with the plain order the column tiles that share
@@ -75,7 +94,15 @@ k2_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode,
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
-    const int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
+    int ct, b, pair;
+    if (tp.aff > 0) {
+        int t;
+        if (!affine_tile(tp, (N2 / C) * D, &t, &pair)) return;
+        ct = t % (N2 / C);
+        b = t / (N2 / C);
+    } else {
+        ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
+    }
     const int c0 = ct * C;
     const int L = N1 * N2;
     const int m = geo.m;
@@ -258,7 +285,17 @@ k2_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D,
     cplx* tile = reinterpret_cast<cplx*>(smem);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int N1 = tp.N1, N2 = tp.N2, C = tp.C;
-    const int ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
+    int ct, b, pair;
+    if (tp.aff > 0) {
+        const int need = geo.m1 ? geo.m2 : (geo.m < N2 ? geo.m : N2);
+        const int nct = (need + C - 1) / C;
+        int t;
+        if (!affine_tile(tp, nct * D, &t, &pair)) return;
+        ct = t % nct;
+        b = t / nct;
+    } else {
+        ct = xcd_column_tile(), b = blockIdx.y, pair = blockIdx.z;
+    }
     const int c0 = ct * C;
     const size_t L = (size_t)N1 * N2;
     const cplx* in = T + ((size_t)pair * D + b) * L;

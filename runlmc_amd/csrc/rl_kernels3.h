@@ -233,7 +233,9 @@ k3_rows_mix(cplx* __restrict__ T, Tile2 tp, const cplx* __restrict__ tw2,
     // the dispatcher's observed placement) takes the row tiles k, k + 8, ... and
     // runs the pairs of each one after another.  Otherwise: plain 2-D order.
     int rt = blockIdx.x, pair = blockIdx.y;
-    if ((gridDim.x & 7) == 0 && gridDim.y > 1) {
+    if (tp.aff > 0) {
+        if (!affine_tile(tp, N1 / R, &rt, &pair)) return;       // (pair-affine order, rl_kernels2.h)
+    } else if ((gridDim.x & 7) == 0 && gridDim.y > 1) {
         const int b = blockIdx.x + gridDim.x * blockIdx.y;
         const int xcd = b & 7, slot = b >> 3;
         rt = (slot / (int)gridDim.y) * 8 + xcd;

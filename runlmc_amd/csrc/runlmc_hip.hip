@@ -87,6 +87,9 @@ struct RlKnobs {
     bool pow2_only = false;      // RUNLMC_POW2_ONLY: the reference's embedding length
     int chunk_mb = 0;            // RUNLMC_CHUNK_MB: intermediates per chunk of a batched product
     int two_streams = -1;        // RUNLMC_TWO_STREAMS=0/1 (default: by size)
+    int affine = -1;             // RUNLMC_AFFINE=0/1: pair-affine order of the transform kernels
+    int affine_kb = 0;           // RUNLMC_AFFINE_KB: L2-sized chunks of that many KB per XCD (experiment)
+    int affine_max_kb = 2048;    // RUNLMC_AFFINE_MAX_KB: largest pair (KB of intermediates) that takes the order
     bool no_v1p = false;         // RUNLMC_NO_V1P: never the single-tile product
     int v1p_min = 0;             // RUNLMC_V1P_MIN
     bool no_lowrank = false;     // RUNLMC_NO_LOWRANK: no polynomial-subspace form
@@ -116,6 +119,9 @@ static RlKnobs read_knobs() {
     k.pow2_only = flag("RUNLMC_POW2_ONLY");
     k.chunk_mb = (int)num("RUNLMC_CHUNK_MB", 0);
     k.two_streams = (int)num("RUNLMC_TWO_STREAMS", -1);
+    k.affine = (int)num("RUNLMC_AFFINE", -1);
+    k.affine_kb = (int)num("RUNLMC_AFFINE_KB", 0);
+    k.affine_max_kb = (int)num("RUNLMC_AFFINE_MAX_KB", 2048);
     k.no_v1p = flag("RUNLMC_NO_V1P");
     k.v1p_min = (int)num("RUNLMC_V1P_MIN", 0);
     k.no_lowrank = flag("RUNLMC_NO_LOWRANK");
@@ -401,6 +407,7 @@ struct rl_gridop {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     size_t chunk_pairs = 1;
+    bool affine = false;        // pair-affine order of the three transform kernels (rl_kernels2.h)
     // single-tile product (k1_product): grids short enough that all D transforms
     // of a pair fit one LDS tile
     bool v1p = false;
@@ -696,6 +703,23 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     size_t chunk_mb = (size_t)D * L * sizeof(cplx) >= ((size_t)8 << 20) ? 64 : 192;
     if (g->kn.chunk_mb > 0) chunk_mb = (size_t)g->kn.chunk_mb;
     g->chunk_pairs = std::max<size_t>(1, (chunk_mb << 20) / ((size_t)D * L * sizeof(cplx)));
+    // Pair-affine order (rl_kernels2.h: affine_tile): every pair on ONE XCD through all
+    // three kernels.  Measured (tools/affine_ab.py, profiles/r04/affine_*.txt): the order
+    // itself pays -- C2: 19.6 -> 17.9 us at 17 vectors, 347 -> 320 us at 1024 --; chunks
+    // small enough that a chunk's intermediates would stay in the XCDs' L2s (RUNLMC_AFFINE_KB)
+    // do NOT: the fabric-side reads of T are the same with and without them (PMC: T is not
+    // found in L2 by the next kernel) and the many small launches cost 25 %.
+    {
+        const size_t pairT = (size_t)D * L * sizeof(cplx);
+        const bool can = g->v2 && g->rows3 && m1 == 0;
+        // (pairs of 0.5 ... 2 MB gain 2-16 %; smaller ones are level, a 6.4 MB pair loses
+        // 3-50 %, C5's 32 MB pair a factor of two: profiles/r04/affine_ab_shapes.txt)
+        g->affine = can && (g->kn.affine >= 0 ? g->kn.affine != 0
+                                              : (pairT >= ((size_t)512 << 10) &&
+                                                 pairT <= ((size_t)g->kn.affine_max_kb << 10)));
+        if (g->affine && g->kn.affine_kb > 0 && g->kn.chunk_mb <= 0)
+            g->chunk_pairs = 8 * std::max<size_t>(1, ((size_t)g->kn.affine_kb << 10) / pairT);
+    }
     // single-tile product for short grids
     if (m1 == 0 && L <= 2048 && !g->kn.no_v1p) {
         const size_t lds = ((size_t)L * (D | 1) + L) * sizeof(cplx);
@@ -1106,6 +1130,7 @@ template <int RA, int RB>
 static void launch2_cols_fwd(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                              const double* X, int nv, int D, int mode, const Gather& gs) {
     dim3 grid(g->N2 / tp.C, D, (unsigned)pairs);
+    if (tp.aff > 0) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * (g->N2 / tp.C) * D));
     if (gs.indptr != nullptr)
         RL_LAUNCH((k2_cols_fwd<RA, RB, true>), grid, dim3(tp.thrC),
                   (size_t)g->N1 * tp.C * sizeof(cplx), st, X, nv, D, g->geo, mode, g->Tcur, tp,
@@ -1120,6 +1145,8 @@ static void launch2_cols_inv(rl_gridop* g, const Tile2& tp, size_t pairs, hipStr
                              double* Y, int nv) {
     const int colsNeeded = g->geo.m1 ? g->geo.m2 : std::min(g->m, g->N2);
     dim3 grid((colsNeeded + tp.C - 1) / tp.C, g->D, (unsigned)pairs);
+    if (tp.aff > 0)
+        grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * ((colsNeeded + tp.C - 1) / tp.C) * g->D));
     RL_LAUNCH((k2_cols_inv<RA, RB>), grid, dim3(tp.thrC), (size_t)g->N1 * tp.C * sizeof(cplx),
               st, g->Tcur, Y, nv, g->D, g->geo, tp, g->plan1, g->tw1);
 }
@@ -1136,6 +1163,7 @@ template <int D, int RA, int RB>
 static void launch3_rows(rl_gridop* g, const Tile2& tp, size_t pairs, hipStream_t st,
                          const MixParams& mp, int* bump) {
     dim3 grid(g->N1 / tp.R, (unsigned)pairs);
+    if (tp.aff > 0) grid = dim3((unsigned)(8 * ((pairs + 7) / 8) * (g->N1 / tp.R)));
     const size_t lds = (size_t)g->N2 * tp.R * D * sizeof(cplx);
 #if !defined(RL_EMU)
     {
@@ -1179,6 +1207,8 @@ static int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, dou
     g->Tcur = Tbuf ? Tbuf : g->T;      // the launches below read it
     Tile2 tp;
     choose_tiles(g, pairs, &tp);
+    tp.aff = g->affine ? (int)pairs : 0;
+    if (tp.aff > 0) trace_once("transform kernels: pair-affine order (one XCD per pair)");
     Gather gs;
     if (gather != nullptr) gs = *gather; else gs.indptr = nullptr;
     switch (g->code1) {
@@ -1266,7 +1296,8 @@ static int prepare_two_streams(rl_gridop* g, size_t chunk) {
 }
 static bool wants_two_streams(const rl_gridop* g) {
     return g->kn.two_streams >= 0 ? g->kn.two_streams != 0
-                                  : (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20);
+                                  : ((g->affine && g->kn.affine_kb > 0) ||
+                                     (size_t)g->D * g->L * sizeof(cplx) >= ((size_t)8 << 20));
 }
 
 

@@ -1256,9 +1256,10 @@ def check_chunked_product():
     Bs = ops.coreg_mats(A, kap)
     toeps = [ops.BTTBOracle(t) for t in tops]
     ref = np.array([ops.grid_sum_matvec(Bs, toeps, x) for x in X[:4]])
-    knobs = ('RUNLMC_CHUNK_MB', 'RUNLMC_TWO_STREAMS')
+    knobs = ('RUNLMC_CHUNK_MB', 'RUNLMC_TWO_STREAMS', 'RUNLMC_AFFINE', 'RUNLMC_AFFINE_KB')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     try:
+        os.environ['RUNLMC_AFFINE'] = '0'
         g = GridOp(D, m, Q)
         g.set_lmc(tops, A, kap)
         whole = g.matmat_host(X)
@@ -1271,6 +1272,24 @@ def check_chunked_product():
             for _ in range(2):                       # second call reuses both workspaces
                 got = g2.matmat_host(X)
                 assert np.array_equal(got, whole), two
+        # the pair-affine order of the three kernels (rl_kernels2.h: affine_tile): the
+        # same tiles in another launch order -- the same bits -- for 12 pairs in one
+        # launch (8 + 4: the second round of XCD slots is half empty), in chunks of 8
+        # pairs on two streams (the default when a pair's intermediates fit an L2) and
+        # with a chunk that is no multiple of 8
+        for kb, mb in (('16384', None), ('64', None), ('64', '1')):
+            os.environ.pop('RUNLMC_CHUNK_MB', None)
+            os.environ.pop('RUNLMC_TWO_STREAMS', None)
+            os.environ['RUNLMC_AFFINE'] = '1'
+            os.environ['RUNLMC_AFFINE_KB'] = kb
+            if mb:
+                os.environ['RUNLMC_CHUNK_MB'] = mb
+            g3 = GridOp(D, m, Q)
+            g3.set_lmc(tops, A, kap)
+            for _ in range(2):
+                assert np.array_equal(g3.matmat_host(X), whole), (kb, mb)
+            assert np.array_equal(g3.matmat_host(X[:1]), g.matmat_host(X[:1]))
+            assert np.array_equal(g3.matmat_host(X[:5], top=1), g.matmat_host(X[:5], top=1))
     finally:
         for k in knobs:
             os.environ.pop(k, None)
