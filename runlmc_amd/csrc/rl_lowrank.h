@@ -400,6 +400,13 @@ __device__ __forceinline__ void lr_row_accumulate(double acc[RL_LR_RS],
 // (The standalone expansion sums even and odd degrees apart, for a point and its
 // mirror at once; here a point's R terms are summed in order: the two agree to
 // roundoff, not bit for bit.)
+// (Round 4, measured and dropped -- the counters put the LDS pipe at 0.32 of this kernel's
+// 0.48 ms per C5 round, SQ_LDS_IDX_ACTIVE, one 8-byte broadcast read per multiply-add:
+// (a) the coefficients through SCALAR loads instead -- a wave's 64 points lie in one output
+// except at an output border, three s_load_dwordx16 per (point slot, vector): 554 us against
+// 517 on the same box; (b) one coefficient read serving both of a thread's points: 198
+// registers, two waves per SIMD instead of three, 558 us; held to 168 registers it spills,
+// 639 us.  What overlaps the LDS cycles today is worth more than removing half of them.)
 //   grid (ceil(nrows / RL_THREADS), ceil(ceil(nvec / VB) / vgroups))
 //   LDS: VB xcap doubles (grid values) + VB 2 R (coefficients)
 // ---------------------------------------------------------------------------

@@ -12,7 +12,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else 'c5'
 nrhs = int(sys.argv[2]) if len(sys.argv) > 2 else 43
 maxiter = int(sys.argv[3]) if len(sys.argv) > 3 else 41
 D, Q, R, m, npr = synth.CONFIGS[cfg]
-p = synth.make_problem(D, Q, R, m)
+p = synth.make_problem(D, Q, R, m, kern=sys.argv[4] if len(sys.argv) > 4 else "rbf")
 fk = synth.functional_kernel(p)
 ad = (0,)
 K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
