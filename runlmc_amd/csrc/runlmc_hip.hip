@@ -1461,6 +1461,8 @@ static int lr_apply(rl_gridop* g, const double* X, double* Y, int nvec, int q0, 
     switch (g->lr_r) {
         case 24: lr_launch<24>(g, X, Y, nvec, Q, Cq, Bq, st); break;
         case 32: lr_launch<32>(g, X, Y, nvec, Q, Cq, Bq, st); break;
+        case 36: lr_launch<36>(g, X, Y, nvec, Q, Cq, Bq, st); break;
+        case 40: lr_launch<40>(g, X, Y, nvec, Q, Cq, Bq, st); break;
         case 48: lr_launch<48>(g, X, Y, nvec, Q, Cq, Bq, st); break;
         default: return fail(RL_EINVAL, "low-rank path: bad basis size");
     }
@@ -1475,6 +1477,8 @@ static int lr_apply_compact(rl_gridop* g, const double* X, double* Y, int nvec, 
     switch (g->lr_r) {
         case 24: lr_launch<24>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
         case 32: lr_launch<32>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
+        case 36: lr_launch<36>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
+        case 40: lr_launch<40>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
         case 48: lr_launch<48>(g, X, Y, nvec, g->lr_np, g->lr_Cc, g->lr_Bc, st, 1); break;
         default: return fail(RL_EINVAL, "low-rank path: bad basis size");
     }
@@ -1840,7 +1844,7 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
     hipStream_t st = nullptr;
     std::vector<double> back;
     std::vector<char> best;
-    for (int r : {24, 32, 48}) {
+    for (int r : {24, 32, 36, 40, 48}) {
         g->lr_r = r;
         const int nvr = (r + RL_LR_EXTRA + D - 1) / D, nrows = nvr * D;
         RL_TRY(lr_reserve(g, std::max(nvr, 1)));
@@ -1861,6 +1865,8 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
             switch (r) {
                 case 24: nparts = lr_project<24>(g, tphi, nrows, st); break;
                 case 32: nparts = lr_project<32>(g, tphi, nrows, st); break;
+                case 36: nparts = lr_project<36>(g, tphi, nrows, st); break;
+                case 40: nparts = lr_project<40>(g, tphi, nrows, st); break;
                 default: nparts = lr_project<48>(g, tphi, nrows, st); break;
             }
             RL_LAUNCH(k_lr_finish_C, dim3(r), dim3(256), 512 * sizeof(double), st,
@@ -2106,7 +2112,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
     // (few outputs, a rank-48 polynomial part AND a filter part: the transform kernels are
     // level or ahead -- measured at D = 4, Q = 3, m = 5000, 1024 vectors: 0.36 against 0.33 ms;
     // at D = 10 the two parts together take 1.65 against 2.7 ms)
-    if (g->st_ok && npoly > 0 && g->lr_r >= 48 && D < 8) g->st_ok = false;
+    if (g->st_ok && npoly > 0 && g->lr_r >= 40 && D < 8) g->st_ok = false;
     return RL_OK;
 }
 

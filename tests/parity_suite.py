@@ -820,7 +820,7 @@ def check_polynomial_form():
             g = GridOp(D, m, Q)
             g.set_lmc(smooth, A, kap)
             rank, gate = g.form()
-            assert rank in (24, 32, 48), rank
+            assert rank in (24, 32, 36, 40, 48), rank
             assert gate > k * D * m          # default gate: these batches stay on the FFT path
             fft = g.matmat_host(X)
             g0 = g
@@ -851,7 +851,7 @@ def check_polynomial_form():
         # short grids (round 4: eligible from 2 x 48 points on; ONE projection chunk of as
         # few lane-steps as hold the grid): even / odd lengths around the chunking borders
         # -- 128 slots = 2 lane-steps rounded up to the ring's 4, 500 and 1000 points (the
-        # sweep's m = 10^3), 2047 --, ranks 24 and 48, against the oracle and the
+        # sweep's m = 10^3), 2047 --, ranks 24 and 40, against the oracle and the
         # transform kernels (here the single-tile kernel)
         for D, m, gam in ((2, 500, 2.0), (3, 255, 1.0), (2, 1004, 60.0), (1, 2047, 8.0), (5, 97, 1.0)):
             x = np.linspace(0, 1, m)
@@ -862,7 +862,7 @@ def check_polynomial_form():
             gs = GridOp(D, m, 2)
             gs.set_lmc(tops, A, kap)
             rank = gs.form()[0]
-            assert rank == (48 if gam == 60.0 else 24), (m, rank)
+            assert (rank in (36, 40) if gam == 60.0 else rank == 24), (m, rank)
             X = rng.randn(3, D * m)
             toeps = [ops.BTTBOracle(t) for t in tops]
             ref = np.array([ops.grid_sum_matvec(Bs, toeps, r) for r in X])
@@ -1040,9 +1040,9 @@ def check_filter_form():
                 p1[0] = np.exp(-0.5 * 60.0 * x ** 2)
                 gm.set_lmc(p1, Am, km)
                 assert gm.top_forms() == ([1, 1, 2, 1][:Qm], True)
-                g48 = GridOp(D, m, 1)             # (that top alone: rank 48 it is)
+                g48 = GridOp(D, m, 1)             # (that top alone: one of the two large ranks)
                 g48.set_lmc(p1[:1], Am[:1], km[:1])
-                assert g48.form()[0] == 48
+                assert g48.form()[0] in (36, 40, 48)
             got = _poly_product(gm, X)
             _close(got, oracle(p1, Bs_=Bm))
             _close(got, gm.matmat_host(X), 1e-12)
@@ -1114,7 +1114,7 @@ def check_polynomial_gate_boundary(m=5004, factor=1.3):
                 seen_reject += 1        # (one back-off step may follow a rejection)
             t *= factor
         assert last, 'no parameter of the %s family was accepted' % name
-        assert set(last) <= {24, 32, 48}, last
+        assert set(last) <= {24, 32, 36, 40, 48}, last
         report[name] = dict(last)
         for r, tb in sorted(last.items()):
             top = top_of(tb)
