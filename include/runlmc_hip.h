@@ -49,7 +49,11 @@ int rl_device_count(int* count);
  *   D outputs, m grid points (1-D grid), embedding length L = the smallest
  *   odd * 2^k >= 2m with odd in {1, 3, 5, 9, 15, 25} (any length >= 2m - 1
  *   embeds the Toeplitz matrix exactly; the reference takes the next power
- *   of two, bttb.py:16-19).  max_tops bounds Q in later rl_gridop_set_* calls. */
+ *   of two, bttb.py:16-19).  max_tops bounds Q in later rl_gridop_set_* calls.
+ *   D is not limited (the reference's Kronecker has no limit, kronecker.py:39-46):
+ *   up to 16 outputs the D x D mix runs inside the product's kernels; above, the
+ *   handle applies T_q to the nvec * D rows through a one-output handle of its own
+ *   and mixes the outputs in a pass of its own (Q products + Q mix passes).      */
 int rl_gridop_create(int device, int D, int m, int max_tops, rl_gridop** out);
 /* Same for a two-dimensional m1 x m2 grid: T_q is then a block-Toeplitz matrix
  * of Toeplitz blocks, BTTB(top, (m1, m2)) (bttb.py:91-148 with two sizes; grid

@@ -509,7 +509,7 @@ __host__ __device__ inline int sf_blob_doubles(int NF, int nfac, int D) {
 #endif
 
 // phase stamps (timing builds): thread 0 of each wave of workgroup 100 at its 21st tile,
-// slots k + 30 wave (tools/sf_phase_timing.py)
+// slots k + 30 wave (round-3 timing build; the tool is in the history of tools/)
 #define RL_SF_STAMP(k) RL_STAMP_IF((k) + 30 * (threadIdx.x >> 6), blockIdx.x == 100 && (threadIdx.x & 63) == 0 && sf_iter == 20)
 
 // requests a tile's D rows -- thread tid: the points 2 tid and 2 tid + 1 of every row, ONE

@@ -471,33 +471,37 @@ k_spmv_w_poly(const int* __restrict__ base, const double* __restrict__ w4, int n
         for (int j = 0; j < VB; ++j)
             x2[j] = diag != nullptr ? X2[(size_t)(v0 + j < nvec ? v0 + j : nvec - 1) * nrows + rowc] : 0.0;
         __syncthreads();
+        // (a ragged last group skips the evaluation of its empty slots: uniform branch)
+        const int nvg = nvec - v0 < VB ? nvec - v0 : VB;
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int i = tid + u * nthr;
             if (i < len) {
 #pragma unroll
-                for (int j = 0; j < VB; ++j) {
-                    const double* z = zs + (j * 2 + dsel[u]) * R;
-                    double ev = 0.0, od = 0.0;
+                for (int j = 0; j < VB; ++j)
+                    if (j < nvg) {
+                        const double* z = zs + (j * 2 + dsel[u]) * R;
+                        double ev = 0.0, od = 0.0;
 #pragma unroll
-                    for (int k = 0; k + 1 < R; k += 2) {
-                        ev = fma(z[k], p[u][k], ev);
-                        od = fma(z[k + 1], p[u][k + 1], od);
+                        for (int k = 0; k + 1 < R; k += 2) {
+                            ev = fma(z[k], p[u][k], ev);
+                            od = fma(z[k + 1], p[u][k + 1], od);
+                        }
+                        xs[(size_t)j * xcap + i] = ev + od;
                     }
-                    xs[(size_t)j * xcap + i] = ev + od;
-                }
             }
         }
         __syncthreads();
         if (row <= rl) {
 #pragma unroll
-            for (int j = 0; j < VB; ++j) {
-                double acc = 0.0;
+            for (int j = 0; j < VB; ++j)
+                if (j < nvg) {
+                    double acc = 0.0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = fma(w[e], xrow[(size_t)j * xcap + e], acc);
-                if (diag != nullptr) acc = fma(dg, x2[j], acc);
-                if (v0 + j < nvec) Y[(size_t)(v0 + j) * nrows + row] = acc;
-            }
+                    for (int e = 0; e < 4; ++e) acc = fma(w[e], xrow[(size_t)j * xcap + e], acc);
+                    if (diag != nullptr) acc = fma(dg, x2[j], acc);
+                    Y[(size_t)(v0 + j) * nrows + row] = acc;
+                }
         }
         __syncthreads();
     }

@@ -320,6 +320,17 @@ struct rl_gridop {
     bool lr_try = false;        // eligible: 1-D grid, long enough, not switched off
     bool lr_ok = false;         // verified against the FFT path for the current parameters
     bool lr_round_try = false;  // the solver's polynomial rounds may use this grid
+    // D > RL_MAX_D outputs ("wide" operator, round 4): the D x D mix does not fit the row
+    // kernels' registers, so the Toeplitz blocks run through a child handle with ONE output
+    // on nvec * D rows (T_q applied to every row: rl_gridop_mvm_top of the child, in
+    // whatever form that top takes) and k_wide_mix applies the dense couplings,
+    //   Y[v][a] (+)= sum_b B_q[a][b] (T_q X)[v][b].
+    // (reference kronecker.py:39-46 has no limit on D; Q products + Q mix passes)
+    bool wide = false;
+    rl_gridop* child = nullptr;
+    double* wide_B = nullptr;   // [max_tops][D][D]
+    double* wide_Z = nullptr;   // T_q X of one top: nvec * D * m
+    size_t wide_Z_cap = 0;
     bool defer_expand = false;  // ski_mvm_int: leave the expansion to the W kernel (k_spmv_w_poly) ...
     bool expand_deferred = false;   // ... done: lr_zhat holds the mixed coefficients of the batch
     int lr_rejects = 0;         // consecutive parameter sets with a top the verification rejected
@@ -579,11 +590,33 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     *out = nullptr;
     if (D < 1 || m < 1 || max_tops < 1)
         return fail(RL_EINVAL, "rl_gridop_create: D, m, max_tops must be >= 1");
-    if (D > RL_MAX_D)
-        return fail(RL_ELIMIT, "rl_gridop_create: D > 16 outputs not supported");
     if ((long)m > (1L << 27)) return fail(RL_ELIMIT, "rl_gridop_create: m too large");
     RL_HIP(hipSetDevice(device));
     set_lds_attrs();
+    if (D > RL_MAX_D) {
+        // wide operator: see rl_gridop::wide
+        if (D > 4096) return fail(RL_ELIMIT, "rl_gridop_create: D > 4096 outputs not supported");
+        rl_gridop* w = new rl_gridop;
+        HandleGuard<rl_gridop, rl_gridop_destroy> wguard(w);
+        w->kn = read_knobs();
+        w->device = device;
+        w->D = D;
+        w->m = m;
+        w->max_tops = max_tops;
+        w->geo = Geom{m, m1, m2};
+        w->wide = true;
+        RL_TRY(gridop_create_impl(device, 1, m, m1, m2, max_tops, &w->child));
+        w->L = w->child->L;
+        w->N1 = w->child->N1;
+        w->N2 = w->child->N2;
+        w->colsA = w->child->colsA;
+        w->rowsB = w->child->rowsB;
+        w->chunk_pairs = w->child->chunk_pairs;
+        w->max_fac = max_tops * D;
+        RL_HIP(hipMalloc((void**)&w->wide_B, (size_t)max_tops * D * D * sizeof(double)));
+        *out = wguard.release();
+        return RL_OK;
+    }
 
     rl_gridop* g = new rl_gridop;
     HandleGuard<rl_gridop, rl_gridop_destroy> guard(g);
@@ -740,6 +773,9 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
 extern "C" int rl_gridop_destroy(rl_gridop* g) {
     if (!g) return RL_OK;
     (void)hipSetDevice(g->device);
+    if (g->child) (void)rl_gridop_destroy(g->child);
+    if (g->wide_B) (void)hipFree(g->wide_B);
+    if (g->wide_Z) (void)hipFree(g->wide_Z);
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
@@ -771,6 +807,10 @@ extern "C" int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int*
 static int lr_ensure(rl_gridop* g);
 extern "C" int rl_gridop_form(const rl_gridop* gc, int* rank, long long* min_elements) {
     if (!gc) return fail(RL_EINVAL, "gridop is NULL");
+    if (gc->wide) {
+        // (the child's gate counts ITS elements, nvec * D rows of m points: the same number)
+        return rl_gridop_form(gc->child, rank, min_elements);
+    }
     rl_gridop* g = const_cast<rl_gridop*>(gc);      // (runs the pending verification)
     if (g->Q >= 1) RL_TRY(lr_ensure(g));
     if (rank) *rank = g->lr_ok ? g->lr_r : 0;
@@ -780,6 +820,16 @@ extern "C" int rl_gridop_form(const rl_gridop* gc, int* rank, long long* min_ele
 
 extern "C" int rl_gridop_top_forms(const rl_gridop* gc, int* forms, int* structured) {
     if (!gc) return fail(RL_EINVAL, "gridop is NULL");
+    if (gc->wide) {
+        // every top runs alone (single-top products of the child): each in its own form
+        RL_TRY(rl_gridop_top_forms(gc->child, forms, nullptr));
+        if (structured) {
+            *structured = 1;
+            for (int q = 0; q < gc->child->Q; ++q)
+                if (gc->child->top_form[q] == 0) *structured = 0;
+        }
+        return RL_OK;
+    }
     rl_gridop* g = const_cast<rl_gridop*>(gc);      // (runs the pending verification)
     if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
     RL_TRY(lr_ensure(g));
@@ -792,6 +842,7 @@ extern "C" int rl_gridop_top_forms(const rl_gridop* gc, int* forms, int* structu
 
 extern "C" int rl_gridop_set_form_gate(rl_gridop* g, long long min_elements) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (g->wide) return rl_gridop_set_form_gate(g->child, min_elements);
     g->lr_min = min_elements < 0 ? lr_min_elements(g) : (size_t)min_elements;
     return RL_OK;
 }
@@ -904,11 +955,41 @@ static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector
     return rc;
 }
 
+// wide operator (D > RL_MAX_D): the child takes the top rows alone, the parent keeps the
+// dense couplings B_q.  A failure leaves the handle without parameters.
+static int wide_set(rl_gridop* g, int Q, const double* tops, const std::vector<double>& B) {
+    RL_HIP(hipSetDevice(g->device));
+    g->Q = 0;
+    std::vector<int> zero(Q, 0);
+    std::vector<double> ones(Q, 1.0);
+    RL_TRY(rl_gridop_set_lmc(g->child, Q, tops, zero.data(), nullptr, ones.data()));
+    RL_HIP(hipMemcpy(g->wide_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
+    g->Q = Q;
+    return RL_OK;
+}
+
 extern "C" int rl_gridop_set_lmc(rl_gridop* g, int Q, const double* tops, const int* ranks,
                                  const double* coreg_vecs, const double* coreg_diags) {
     RL_TRY(set_check(g, Q, tops));
     if (!ranks || !coreg_diags) return fail(RL_EINVAL, "rl_gridop_set_lmc: NULL argument");
     const int D = g->D;
+    if (g->wide) {
+        std::vector<double> B((size_t)Q * D * D, 0.0);
+        size_t wrow = 0;
+        for (int q = 0; q < Q; ++q) {
+            if (ranks[q] < 0) return fail(RL_EINVAL, "rl_gridop_set_lmc: negative rank");
+            if (ranks[q] > 0 && !coreg_vecs)
+                return fail(RL_EINVAL, "rl_gridop_set_lmc: coreg_vecs is NULL");
+            for (int r = 0; r < ranks[q]; ++r, ++wrow)
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j)
+                        B[((size_t)q * D + i) * D + j] +=
+                            coreg_vecs[wrow * D + i] * coreg_vecs[wrow * D + j];
+            for (int i = 0; i < D; ++i)
+                B[((size_t)q * D + i) * D + i] += coreg_diags[(size_t)q * D + i];
+        }
+        return wide_set(g, Q, tops, B);
+    }
     std::vector<double> A, W, kap(coreg_diags, coreg_diags + (size_t)Q * D);
     std::vector<int> Qi;
     size_t row = 0;
@@ -991,6 +1072,17 @@ extern "C" int rl_gridop_set_dense(rl_gridop* g, int Q, const double* tops, cons
     RL_TRY(set_check(g, Q, tops));
     if (!B) return fail(RL_EINVAL, "rl_gridop_set_dense: B is NULL");
     const int D = g->D;
+    if (g->wide) {
+        for (int q = 0; q < Q; ++q)
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < i; ++j) {
+                    const double bij = B[((size_t)q * D + i) * D + j];
+                    const double bji = B[((size_t)q * D + j) * D + i];
+                    if (std::fabs(bij - bji) > 1e-12 * std::max(std::fabs(bij), std::fabs(bji)))
+                        return fail(RL_EINVAL, "rl_gridop_set_dense: B_q is not symmetric");
+                }
+        return wide_set(g, Q, tops, std::vector<double>(B, B + (size_t)Q * D * D));
+    }
     std::vector<double> A, W, kap((size_t)Q * D, 0.0);
     std::vector<int> Qi;
     for (int q = 0; q < Q; ++q) {
@@ -2134,6 +2226,74 @@ static int lr_ensure(rl_gridop* g) {
     return forms_setup(g, g->lr_A, g->lr_W, g->lr_Qi, g->lr_kap);
 }
 
+// ---------------------------------------------------------------------------
+// wide operator (D > RL_MAX_D outputs): Y[v][a][i] (+)= sum_b B[a][b] Z[v][b][i]
+//   grid (ceil(m / 256), ceil(D / 8), nvec)   block 256
+// A thread owns a grid point and 8 outputs a; the D values Z[v][.][i] stream through
+// once per block of 8 outputs (B rows are scalar loads).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_wide_mix(const double* __restrict__ Z, const double* __restrict__ B, int D, int m,
+           double* __restrict__ Y, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int a0 = blockIdx.y * 8, v = blockIdx.z;
+    if (i >= m) return;
+    const double* z = Z + (size_t)v * D * m + i;
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    for (int b = 0; b < D; ++b) {
+        const double zb = z[(size_t)b * m];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int a = a0 + k < D ? a0 + k : D - 1;
+            acc[k] = fma(B[(size_t)a * D + b], zb, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (a0 + k < D) {
+            double* y = Y + ((size_t)v * D + a0 + k) * m + i;
+            *y = accumulate ? *y + acc[k] : acc[k];
+        }
+}
+
+static int wide_reserve(rl_gridop* g, int nvec) {
+    const size_t need = (size_t)nvec * g->D * g->m;
+    if (g->wide_Z_cap >= need) return RL_OK;
+    if (g->wide_Z) RL_HIP(hipFree(g->wide_Z));
+    g->wide_Z = nullptr;
+    g->wide_Z_cap = 0;
+    RL_HIP(hipMalloc((void**)&g->wide_Z, need * sizeof(double)));
+    g->wide_Z_cap = need;
+    return RL_OK;
+}
+
+static bool stream_capturing(hipStream_t stream);
+// the operator: one single-top product of the child per top row, one mix pass each
+static int wide_mvm(rl_gridop* g, const double* X, double* Y, int nvec, hipStream_t stream) {
+    if (nvec < 0) return fail(RL_EINVAL, "nvec < 0");
+    if (nvec == 0) return RL_OK;
+    if (!X || !Y) return fail(RL_EINVAL, "X or Y is NULL");
+    if (X == Y) return fail(RL_EINVAL, "X and Y may not alias");
+    if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
+    RL_HIP(hipSetDevice(g->device));
+    if (g->wide_Z_cap < (size_t)nvec * g->D * g->m) {
+        if (stream_capturing(stream))
+            return fail(RL_EINVAL, "wide operator: workspace not reserved before a capture");
+        RL_TRY(wide_reserve(g, nvec));
+    }
+    const int D = g->D, m = g->m;
+    for (int q = 0; q < g->Q; ++q) {
+        RL_TRY(rl_gridop_mvm_top(g->child, q, X, g->wide_Z, nvec * D, stream));
+        RL_LAUNCH(k_wide_mix, dim3((m + 255) / 256, (D + 7) / 8, nvec), dim3(256), 0, stream,
+                  (const double*)g->wide_Z, (const double*)(g->wide_B + (size_t)q * D * D), D, m, Y,
+                  q > 0 ? 1 : 0);
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 static bool stream_capturing(hipStream_t stream) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     return stream != nullptr && hipStreamIsCapturing(stream, &cs) == hipSuccess &&
@@ -2268,6 +2428,7 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
 
 extern "C" int rl_gridop_mvm(rl_gridop* g, const double* X, double* Y, int nvec, void* stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
+    if (g->wide) return wide_mvm(g, X, Y, nvec, (hipStream_t)stream);
     MixParams mp{g->Q, g->nfac, g->spec, g->facA, g->facW, g->facQ, g->kappa,
                  g->mixtab_ok ? g->mixtab : nullptr,
                  g->mixtab_ok ? g->mixtab + (size_t)g->D * g->L : nullptr};
@@ -2278,6 +2439,10 @@ extern "C" int rl_gridop_mvm_top(rl_gridop* g, int q, const double* X, double* Y
                                  void* stream) {
     if (!g) return fail(RL_EINVAL, "gridop is NULL");
     if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_mvm_top: q out of range");
+    if (g->wide) {
+        if (nvec < 0) return fail(RL_EINVAL, "nvec < 0");
+        return rl_gridop_mvm_top(g->child, q, X, Y, nvec * g->D, stream);
+    }
     MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones, nullptr,
                  nullptr};
     return mvm_with_mix(g, mp, X, Y, nvec, (hipStream_t)stream);
@@ -2285,6 +2450,7 @@ extern "C" int rl_gridop_mvm_top(rl_gridop* g, int q, const double* X, double* Y
 
 extern "C" int rl_gridop_spectrum_host(rl_gridop* g, int q, double* out) {
     if (!g || !out) return fail(RL_EINVAL, "NULL argument");
+    if (g->wide) return rl_gridop_spectrum_host(g->child, q, out);
     if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_spectrum_host: q out of range");
     RL_HIP(hipSetDevice(g->device));
     std::vector<double> scr(g->L);
@@ -3198,6 +3364,22 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
                             double* resid_out, int* istop_out, double* lanczos_out,
                             int lanczos_cap, void* stream);
 
+// everything a product of nvec vectors allocates lazily, before a graph capture: pending
+// verification and buffers of the structured forms, intermediates of the transform kernels
+// (second set for the two-stream chunks); a wide operator: its row buffer and its child
+static int gridop_prepare(rl_gridop* g, int nvec) {
+    if (g->wide) {
+        RL_TRY(wide_reserve(g, nvec));
+        return gridop_prepare(g->child, nvec * g->D);
+    }
+    RL_TRY(lr_prepare(g, nvec));
+    const size_t pairs = ((size_t)nvec + 1) / 2;
+    RL_TRY(ensure_workspace(g, std::min(pairs, g->chunk_pairs)));
+    if (g->v2 && pairs > g->chunk_pairs && wants_two_streams(g))
+        RL_TRY(prepare_two_streams(g, g->chunk_pairs));
+    return RL_OK;
+}
+
 extern "C" int rl_solve_batch(rl_ski* s, const double* B, double* X, int nrhs, int method,
                               double tol, int check_every, int maxiter, int* iters_out,
                               double* resid_out, int* istop_out, void* stream) {
@@ -3281,13 +3463,8 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     RL_TRY(solver_alloc(s, w, need, nrhs, n, nblk, st));
     // everything the operator product allocates lazily must exist before capture
     RL_TRY(ski_reserve(s, nrhs));
-    RL_TRY(lr_prepare(s->g, nrhs));
-    for (const SkiTerm& t : s->extra) RL_TRY(lr_prepare(t.g, nrhs));
-    RL_TRY(ensure_workspace(s->g, std::min(((size_t)nrhs + 1) / 2, s->g->chunk_pairs)));
-    if (s->g->v2 && ((size_t)nrhs + 1) / 2 > s->g->chunk_pairs && wants_two_streams(s->g))
-        RL_TRY(prepare_two_streams(s->g, s->g->chunk_pairs));
-    for (const SkiTerm& t : s->extra)
-        RL_TRY(ensure_workspace(t.g, std::min(((size_t)nrhs + 1) / 2, t.g->chunk_pairs)));
+    RL_TRY(gridop_prepare(s->g, nrhs));
+    for (const SkiTerm& t : s->extra) RL_TRY(gridop_prepare(t.g, nrhs));
     int active = nrhs;
     int done = 0;          // iterations issued so far
 
@@ -3327,7 +3504,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         // points: a row of 30 entries, as on the weather workload, is a serial chain
         // of gathers inside the transform kernel: 1.45 vs 1.23 s per fit)
         const bool short_rows = (size_t)s->nnzWT <= (size_t)8 * s->ngrid;
-        const bool fuse_wt = fuse_w && short_rows && s->g->Q >= 1 &&
+        const bool fuse_wt = fuse_w && short_rows && s->g->Q >= 1 && !s->g->wide &&
                              ((size_t)nrhs + 1) / 2 <= s->g->chunk_pairs &&
                              !s->kn.no_fuse_wt;
         mb.fuse_wt = fuse_wt ? 1 : 0;

@@ -21,12 +21,13 @@ def _is_lmc_term(K):
 
 def fuse_kronecker_sum(terms):
     """One GridOp for sum_q B_q (x) T_q, or None if `terms` is not of that
-    form (symmetric dense B_q of one size, 1-D BTTB of one size, D <= 16)."""
+    form (symmetric dense B_q of one size, 1-D BTTB of one size; any D -- above 16
+    outputs the handle is the 'wide' operator of csrc/runlmc_hip.hip)."""
     if not all(_is_lmc_term(K) for K in terms):
         return None
     D = terms[0].A.shape[0]
     m = terms[0].B.shape[0]
-    if D > 16 or any(K.A.shape[0] != D or K.B.shape[0] != m for K in terms):
+    if any(K.A.shape[0] != D or K.B.shape[0] != m for K in terms):
         return None
     op = GridOp(D, m, len(terms))
     op.set_dense(np.stack([K.B.top for K in terms]),

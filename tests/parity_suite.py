@@ -1364,6 +1364,94 @@ def check_single_tile_product():
             os.environ['RUNLMC_V1P_MIN'] = old
 
 
+def check_many_outputs():
+    """D > 16 outputs (the reference's Kronecker / LMC operators have no limit on D,
+    kronecker.py:39-46): the device handle is the 'wide' operator -- the Toeplitz blocks
+    through a one-output child handle on nvec * D rows, the dense couplings by k_wide_mix.
+    D = 24 (three blocks of eight outputs) and D = 19 (a ragged last block): grid operator
+    and single tops against the oracle at 1e-11 (transform kernels and, with the gate
+    lifted, the structured forms of the child), set_dense, the Kronecker mirror class,
+    the full SKI operator, a MINRES solve against the oracle's and the gradient against
+    the reference's loops on the oracle's solves."""
+    from runlmc_amd._native import GridOp, SkiOp, solve_batch
+    rng = np.random.RandomState(5)
+    for D, m, Q in ((24, 700, 2), (19, 2300, 3)):
+        x = np.linspace(0, 1, m)
+        tops = np.array([np.exp(-0.5 * (1 + 3 * q) * x ** 2) if q != 1 else _matern32(x, 2.0)
+                         for q in range(Q)])
+        A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+        kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+        Bs = ops.coreg_mats(A, kap)
+        toeps = [ops.BTTBOracle(t) for t in tops]
+        X = rng.randn(3, D * m)
+        ref = np.array([ops.grid_sum_matvec(Bs, toeps, v) for v in X])
+        g = GridOp(D, m, Q)
+        g.set_lmc(tops, A, kap)
+        _close(g.matmat_host(X), ref, 1e-11)
+        _close(_poly_product(g, X), ref, 1e-11)            # (the child's structured forms)
+        forms, structured = g.top_forms()
+        assert forms == [1, 2, 1][:Q], forms
+        one = g.matmat_host(X[:2], top=Q - 1)
+        want = np.array([np.concatenate([toeps[Q - 1].matvec(r) for r in v.reshape(D, m)])
+                         for v in X[:2]])
+        _close(one, want, 1e-11)
+        g.set_dense(tops, np.array(Bs))
+        _close(g.matmat_host(X), ref, 1e-11)
+        # the mirror classes: a sum of Kronecker(NumpyMatrix(B_q), BTTB(k_q)) is one handle
+        K = SumMatrix([Kronecker(NumpyMatrix(B), BTTB(t, (m,))) for B, t in zip(Bs, tops)])
+        _close(K.matvec(X[0]), ref[0], 1e-11)
+        bad = np.array(Bs)
+        bad[0][0, 1] += 1.0
+        try:
+            g.set_dense(tops, bad)
+            raise AssertionError('asymmetric B accepted')
+        except ValueError:
+            pass
+    # the whole path on a small model with D = 18 outputs
+    D, Q, n_o = 18, 2, 40
+    Xs = [np.sort(rng.rand(n_o)).reshape(-1, 1) for _ in range(D)]
+    Ys = [np.sin(3 * xx[:, 0]) + 0.1 * rng.randn(n_o) for xx in Xs]
+    fk = FunctionalKernel(D=D, lmc_kernels=[RBF(2.0), Matern32(1.5)], lmc_ranks=[1, 2])
+    fk.coreg_vecs = [rng.randn(1, D), rng.randn(2, D)]
+    fk.coreg_diags = [np.abs(rng.randn(D)) + 0.2 for _ in range(Q)]
+    fk.noise = np.abs(rng.randn(D)) * 0.1 + 0.5
+    fk.set_input_dim(1)
+    from runlmc_amd.approx.interpolation import autogrid, multi_interpolant
+    grid = autogrid(Xs, lo=None, hi=None, m=None)[0]
+    dists = grid - grid[0]
+    W = multi_interpolant(Xs, grid)
+    WT = W.transpose().tocsr()
+    lens = [n_o] * D
+    ad = (0,)
+    K, gks = gen_grid_kernel(fk, {ad: dists}, {ad: (W, WT)}, lens)
+    from oracle.kernels import KernelSpec, RBFSpec, Matern32Spec
+    spec = KernelSpec(D, [RBFSpec(2.0), Matern32Spec(1.5)], fk.coreg_vecs, fk.coreg_diags, fk.noise)
+    spec.set_input_dim(1)
+    oop = olik.LMCOperatorOracle(spec, dists, W, WT, lens)
+    y = np.hstack(Ys)
+    v = rng.randn(len(y))
+    _close(K.matvec(v), oop.matvec(v), 1e-11)
+    xd, itd, errd = Iterative.solve(K, y, verbose=True, tol=1e-6)
+    xo, ito, erro, _ = iterative_solve(oop.matvec, y, tol=1e-6)
+    assert abs(itd - ito) <= max(3, ito // 10) and errd <= max(1e-6, 1.5 * erro)
+    _close(xd, xo, rel=1e-6)
+    nprobe = 6
+    rs = rng.randint(0, 2, (nprobe, len(y))) * 2 - 1
+    svc = StochasticDerivService(None, None, nprobe, 1e-8)
+    lik = ApproxLMCLikelihood(fk, K, {ad: dists}, {ad: (W, WT)}, Ys, svc, probes=rs)
+    inv = np.array([iterative_solve(oop.matvec, r.astype(float), tol=1e-8)[0] for r in rs])
+    alpha = iterative_solve(oop.matvec, y, tol=1e-8)[0]
+    want = olik.stochastic_gradients(spec, dists, W, WT, lens, alpha, rs, inv)
+    got = (lik.coreg_vec_gradients(), lik.coreg_diags_gradients(), lik.kernel_gradients(),
+           lik.noise_gradient())
+    flat = lambda g_: np.concatenate([np.ravel(x_) for x_ in list(g_[0]) + list(g_[1]) +
+                                      [np.hstack([np.ravel(k_) for k_ in g_[2]])] + [g_[3]]])
+    gw = flat((want['coreg_vec'], want['coreg_diag'], want['kernel'], want['noise']))
+    gg = flat(got)
+    assert np.linalg.norm(gw - gg) <= 1e-5 * np.linalg.norm(gw), \
+        np.linalg.norm(gw - gg) / np.linalg.norm(gw)
+
+
 def check_rank_above_outputs():
     """Coregionalisation ranks above D (redundant, legal in the reference:
     functional_kernel.py:113-133 draws any R_q x D block): more factors than the

@@ -157,6 +157,10 @@ def test_single_tile_product():
     ps.check_single_tile_product()
 
 
+def test_many_outputs():
+    ps.check_many_outputs()
+
+
 def test_rank_above_outputs():
     ps.check_rank_above_outputs()
 

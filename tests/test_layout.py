@@ -104,8 +104,9 @@ def test_argument_errors_map_to_valueerror():
     try:
         with pytest.raises(ValueError):
             GridOp(0, 5, 1)
+        assert GridOp(17, 5, 1).D == 17   # (no limit on D since round 4: the wide operator)
         with pytest.raises(NotImplementedError):
-            GridOp(17, 5, 1)           # documented limit: D <= 16
+            GridOp(5000, 5, 1)         # documented limit: D <= 4096
         g = GridOp(2, 5, 1)
         import numpy as np
         with pytest.raises(ValueError):
