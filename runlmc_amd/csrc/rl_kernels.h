@@ -552,39 +552,28 @@ k_spmv_wt_staged(const int* __restrict__ indptr, const int* __restrict__ lo,
     const double* a = vs + (kb - k0);
     const double* xrow = xs + (l - c0);
     for (int grp = 0; grp < ng; ++grp) {
-        // (a ragged last group -- the N + 1 vectors of a probe batch are 8 k + 1 -- skips
-        // the LDS traffic and the sums of its empty slots: a third of this kernel's work at
-        // 17 vectors, round 4.  The branch is uniform; loads stay unconditional)
-        const int v0 = (g0 + grp) * VB;
-        const int nvg = nvec - v0 < VB ? nvec - v0 : VB;
+        // (round 4, measured and dropped: skipping the LDS traffic and sums of a ragged last
+        // group's empty slots -- 17 = 2 x 8 + 1 vectors -- behind a uniform branch: 96 vs 88 us
+        // at 17 vectors, 519 vs 485 at 129; the same guard pays in k_spmv_w_poly, whose slots
+        // cost 24 multiply-adds each: 78 vs 96 us at 17 vectors)
 #pragma unroll
         for (int j = 0; j < VB; ++j)
-            if (j < nvg) {
 #pragma unroll
-                for (int u = 0; u < XPT; ++u) {
-                    const int i = tid + u * nthr;
-                    if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
-                }
+            for (int u = 0; u < XPT; ++u) {
+                const int i = tid + u * nthr;
+                if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
             }
         __syncthreads();
         if (grp + 1 < ng) request(grp + 1);
         double acc[VB];
 #pragma unroll
         for (int j = 0; j < VB; ++j) acc[j] = 0.0;
-        if (nvg == VB) {
-            for (int e = 0; e < cnt; ++e) {
-                const double w = a[e];
+        for (int e = 0; e < cnt; ++e) {
+            const double w = a[e];
 #pragma unroll
-                for (int j = 0; j < VB; ++j) acc[j] = fma(w, xrow[(size_t)j * xcap + e], acc[j]);
-            }
-        } else {
-            for (int e = 0; e < cnt; ++e) {
-                const double w = a[e];
-#pragma unroll
-                for (int j = 0; j < VB; ++j)
-                    if (j < nvg) acc[j] = fma(w, xrow[(size_t)j * xcap + e], acc[j]);
-            }
+            for (int j = 0; j < VB; ++j) acc[j] = fma(w, xrow[(size_t)j * xcap + e], acc[j]);
         }
+        const int v0 = (g0 + grp) * VB;
         if (row <= rl) {
 #pragma unroll
             for (int j = 0; j < VB; ++j)
@@ -656,32 +645,28 @@ k_spmv_w_staged(const int* __restrict__ base, const double* __restrict__ w4, int
     request(0);
     const double* xrow = xs + (b - c0);
     for (int grp = 0; grp < ng; ++grp) {
-        const int v0 = (g0 + grp) * VB;
-        const int nvg = nvec - v0 < VB ? nvec - v0 : VB;      // (ragged last group: see k_spmv_wt_staged)
         double d2[VB];
 #pragma unroll
         for (int j = 0; j < VB; ++j) {
             d2[j] = x2[j];
-            if (j < nvg) {
 #pragma unroll
-                for (int u = 0; u < XPT; ++u) {
-                    const int i = tid + u * nthr;
-                    if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
-                }
+            for (int u = 0; u < XPT; ++u) {
+                const int i = tid + u * nthr;
+                if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
             }
         }
         __syncthreads();
         if (grp + 1 < ng) request(grp + 1);
+        const int v0 = (g0 + grp) * VB;
         if (row <= rl) {
 #pragma unroll
-            for (int j = 0; j < VB; ++j)
-                if (j < nvg) {
-                    double acc = 0.0;
+            for (int j = 0; j < VB; ++j) {
+                double acc = 0.0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = fma(w[e], xrow[(size_t)j * xcap + e], acc);
-                    if (diag != nullptr) acc = fma(dg, d2[j], acc);
-                    Y[(size_t)(v0 + j) * nrows + row] = acc;
-                }
+                for (int e = 0; e < 4; ++e) acc = fma(w[e], xrow[(size_t)j * xcap + e], acc);
+                if (diag != nullptr) acc = fma(dg, d2[j], acc);
+                if (v0 + j < nvec) Y[(size_t)(v0 + j) * nrows + row] = acc;
+            }
         }
         __syncthreads();
     }
