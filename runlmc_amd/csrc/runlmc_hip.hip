@@ -100,6 +100,8 @@ struct RlKnobs {
     bool staged_wt = false;      // RUNLMC_STAGED_WT: LDS-staged SpMVs whatever the size
     bool no_staged_wt = false;   // RUNLMC_NO_STAGED_WT
     bool no_w_poly = false;      // RUNLMC_NO_W_POLY: the W product reads the expanded grid vector
+    int w_poly_rmax = 32;        // RUNLMC_W_POLY_RMAX: largest rank whose expansion the W kernel takes over
+                                 // (36 measured: 791 us against 186 + 473 for expansion + staged W per C5 round)
     bool no_sort = false;        // RUNLMC_NO_SORT: caller's data order inside the SKI handle
     long long ws_cache_mb = -1;  // RUNLMC_WS_CACHE_MB
     int solver_maxblk = 0;       // RUNLMC_SOLVER_MAXBLK
@@ -132,6 +134,7 @@ static RlKnobs read_knobs() {
     k.staged_wt = flag("RUNLMC_STAGED_WT");
     k.no_staged_wt = flag("RUNLMC_NO_STAGED_WT");
     k.no_w_poly = flag("RUNLMC_NO_W_POLY");
+    k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
     k.no_sort = flag("RUNLMC_NO_SORT");
     k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
     k.solver_maxblk = (int)num("RUNLMC_SOLVER_MAXBLK", 0);
@@ -1524,7 +1527,7 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
     // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
     // the evaluation costs more than the two vector passes it saves -- measured, C5
     // periodic: 5.03 against 4.17 ms per solver round)
-    if (g->defer_expand && !accumulate && R <= 32) {
+    if (g->defer_expand && !accumulate && R <= g->kn.w_poly_rmax) {
         g->expand_deferred = true;
         return;
     }
@@ -2993,9 +2996,12 @@ static int ski_w_poly(rl_ski* s, double* Yp, int nvec, const double* diag, const
     if (R == 24) {
         if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 24);
         else RL_W_POLY(2, 24);
-    } else {
+    } else if (R == 32) {
         if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 32);
         else RL_W_POLY(2, 32);
+    } else {
+        if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 36);
+        else RL_W_POLY(2, 36);
     }
 #undef RL_W_POLY
     RL_HIP(hipGetLastError());

@@ -1594,12 +1594,16 @@ def check_w_poly_product():
     from runlmc_amd.util import synth
     from runlmc_amd._native import solve_batch
     rng = np.random.RandomState(23)
-    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_W_POLY')
+    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_W_POLY', 'RUNLMC_W_POLY_RMAX')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     try:
         os.environ['RUNLMC_STAGED_WT'] = '1'
-        for D, Q, m_data, k in ((3, 2, 2600, 37), (2, 3, 5000, 9)):
-            p = synth.make_problem(D, Q, 1, m_data, eps=1.0)
+        os.environ['RUNLMC_W_POLY_RMAX'] = '36'      # (default 32: rank 36 measured slower fused)
+        # (rbf: rank 24; the periodic family's period-1 kernel: one of the larger ranks the W
+        # kernel takes, 32 or 36)
+        for D, Q, m_data, k, kern in ((3, 2, 2600, 37, 'rbf'), (2, 3, 5000, 9, 'rbf'),
+                                      (2, 2, 2600, 11, 'periodic')):
+            p = synth.make_problem(D, Q, 1, m_data, eps=1.0, kern=kern)
             fk = synth.functional_kernel(p)
             ad = (0,)
             V = rng.randn(k, p.n)
@@ -1615,6 +1619,7 @@ def check_w_poly_product():
                 X = solve_batch(op, torch.from_numpy(V[:3]).to(op.device), tol=1e-6,
                                 maxiter=30)[0].cpu().numpy()
                 forms = op.grid.top_forms()
+                assert op.grid.form()[0] == 24 if kern == 'rbf' else op.grid.form()[0] in (32, 36)
                 return Y, X, forms
             Yf, Xf, forms = run(False, 0)
             assert forms[0] == [1] * Q and forms[1], forms       # (the polynomial form)
