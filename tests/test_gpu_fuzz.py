@@ -53,6 +53,76 @@ def test_random_shapes_vs_oracle():
     print('fuzz: %d shapes, worst relative error %.2e' % (n_draws, worst))
 
 
+def test_random_structured_forms_vs_oracle():
+    """Randomised kernels through the per-top FORMS of the product with the batch gate
+    lifted: RBF / periodic rows (polynomial form at whatever rank the verification
+    accepts: 24 ... 48, short grids from 96 points on), Matern-3/2 / its derivative /
+    exponential rows (recursive filter), a kinked row now and then (transform kernels for
+    the operator), 1 ... 28 outputs (above 16: the wide operator).  Every product against
+    the oracle at 1e-11 and against the transform kernels of the same handle at 1e-12."""
+    from runlmc_amd._native import GridOp
+    n_draws = int(os.environ.get('RUNLMC_FUZZ_N', '40'))
+    rng = np.random.RandomState(20261003)
+    worst, seen = 0.0, {}
+    for draw in range(n_draws):
+        D = int(rng.choice([1, 2, 3, 4, 7, 8, 10, 13, 16, 17, 19, 28]))
+        Q = int(rng.randint(1, 5))
+        m = int(np.exp(rng.uniform(np.log(96), np.log(9000))))
+        nvec = int(rng.choice([1, 2, 3, 9, 17, 40]))
+        if D * m * nvec > 2e6:
+            nvec = max(1, int(2e6 // (D * m)))
+        x = np.linspace(0, 1 + 2 * rng.rand(), m)
+        tops = []
+        for q in range(Q):
+            kind = rng.choice(['rbf', 'rbf', 'periodic', 'matern', 'dmatern', 'exp', 'kink'],
+                              p=[0.25, 0.15, 0.15, 0.2, 0.1, 0.1, 0.05])
+            gam = float(np.exp(rng.uniform(np.log(0.5), np.log(60.0))))
+            if kind == 'rbf':
+                tops.append(np.exp(-0.5 * gam * x ** 2))
+            elif kind == 'periodic':
+                tops.append(np.exp(-0.5 * np.sin(np.pi * x / (0.8 + 4 * rng.rand())) ** 2))
+            elif kind == 'matern':
+                tops.append((1 + np.sqrt(3) * gam * x) * np.exp(-np.sqrt(3) * gam * x))
+            elif kind == 'dmatern':
+                tops.append(-3.0 * gam * x * x * np.exp(-np.sqrt(3) * gam * x))
+            elif kind == 'exp':
+                tops.append(np.exp(-gam * x))
+            else:
+                tops.append(1.0 / (1.0 + gam * x))
+        tops = np.array(tops)
+        A = [rng.randn(int(rng.randint(0, 3)), D) for _ in range(Q)]
+        A = [a if len(a) else None for a in A]
+        kap = [np.abs(rng.randn(D)) + 0.05 for _ in range(Q)]
+        g = GridOp(D, m, Q)
+        g.set_lmc(tops, A, kap)
+        forms, structured = g.top_forms()
+        X = rng.randn(nvec, D * m)
+        g.set_form_gate(0)
+        Y = g.matmat_host(X)
+        Yt = [g.matmat_host(X[:1], top=q)[0] for q in range(Q)]
+        g.set_form_gate(1 << 62)
+        F = g.matmat_host(X)
+        g.set_form_gate(-1)
+        Bs = ops.coreg_mats([a if a is not None else np.zeros((0, D)) for a in A], kap)
+        toeps = [ops.BTTBOracle(t) for t in tops]
+        key = (tuple(forms), bool(structured), D > 16)
+        seen[key] = seen.get(key, 0) + 1
+        for v in sorted(set([0, nvec - 1])):
+            ref = ops.grid_sum_matvec(Bs, toeps, X[v])
+            err = np.abs(Y[v] - ref).max() / max(np.abs(ref).max(), 1e-300)
+            worst = max(worst, err)
+            assert err < 1e-11, (draw, D, Q, m, nvec, forms, structured, err)
+        scale = np.maximum(np.abs(F).max(axis=1, keepdims=True), 1e-300)
+        assert (np.abs(Y - F) / scale).max() < 1e-12, (draw, D, Q, m, forms)
+        for q in range(Q):
+            ref = np.concatenate([toeps[q].matvec(r) for r in X[0].reshape(D, m)])
+            err = np.abs(Yt[q] - ref).max() / max(np.abs(ref).max(), 1e-300)
+            assert err < 1e-11, (draw, 'top', q, D, m, forms, err)
+    print('structured-form fuzz: %d shapes, worst relative error %.2e, %d distinct '
+          '(forms, structured, wide) combinations' % (n_draws, worst, len(seen)))
+    assert len(seen) >= 6
+
+
 @pytest.mark.parametrize('staged', [False, True])
 def test_random_ski_operators_and_solves(staged, monkeypatch):
     """Random ragged multi-output problems through the package API: the SKI
