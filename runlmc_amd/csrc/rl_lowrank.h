@@ -198,12 +198,31 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
 __global__ void __launch_bounds__(256)
 k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, int Q,
          const double* __restrict__ Cq, const double* __restrict__ Bq,
-         const double* __restrict__ nu, double* __restrict__ Zhat) {
+         const double* __restrict__ nu, double* __restrict__ Zhat,
+         const int* __restrict__ run_ptr) {
     RL_SMEM(smem);
     double* Z = reinterpret_cast<double*>(smem);          // [D][r]
     double* W = Z + D * r;                                 // [Q][D][r]
     const int v = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int nrows = nvec * D;
+    if (run_ptr != nullptr) {
+        // partial sums of k_rp_project (rl_rowpoly.h): part[run][v][j], the runs of output b
+        // are run_ptr[b] .. run_ptr[b + 1]; summed in a fixed order, eight loads in flight
+        for (int e = tid; e < D * r; e += nthr) {
+            const int b = e / r, j = e - b * r;
+            const int c0 = run_ptr[b], c1 = run_ptr[b + 1];
+            const size_t stride = (size_t)nvec * r;
+            const double* src = part + (size_t)v * r + j;
+            double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(c + u) * stride];
+            }
+            for (; c < c1; ++c) s8[0] += src[(size_t)c * stride];
+            Z[e] = nu[j] * (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
+        }
+    } else
     for (int e = tid; e < D * r; e += nthr) {
         // chunks summed in a fixed order (eight interleaved running sums, so that
         // eight loads are in flight; the same order on every run and every rank)

@@ -1,0 +1,318 @@
+// Row-polynomial form of a polynomial-form SKI operator (round 4): LARGE solver rounds.
+//
+// When every top row of the grid operator is in the polynomial-subspace form
+// (rl_lowrank.h: K_UU = Phi M Phi^T on the grid's orthonormal polynomials), the SKI
+// operator of reference approx/ski.py:13-16
+//
+//     K~ x = W K_UU W^T x + eps (.) x = F M F^T x + eps (.) x,      F = W Phi  (n x r per output)
+//
+// needs neither the interpolation products nor a grid vector: F[i][j] = sum_e w_i[e] q_j(n_i + e)
+// -- the r polynomials interpolated at data row i -- depends on the inputs and the grid only, is
+// built ONCE per (SKI handle, rank) and kept (8 r n bytes: 192 MB at C5, rank 24), and a
+// solver round's operator is
+//     k_rp_project   part = F^T Y   (a tall-skinny product: fp64 matrix cores, operands
+//                                    staged through LDS)
+//     k_lr_mix       Zhat = nu (.) sum_q B_q C_q (nu (.) Z)          (rl_lowrank.h)
+//     k_rp_expand    Q = F Zhat (+ eps (.) Y)                         (scalar-loaded coefficients)
+// i.e. one read of Y, one write of Q and two reads of F, against W^T (read Y, write g),
+// projection (read g), mix, W with expansion (write Q) before: 1.16 -> see DESIGN.md section 6.
+// Same operator, another summation order (roundoff-level agreement, as k_spmv_w_poly).
+// Rows are in the handle's SORTED order (by output, then by grid position), so the rows of
+// an output are contiguous; F is degree-major, F[j * n + i].
+#pragma once
+#include "rl_device.h"
+#include "rl_lowrank.h"
+
+#define RL_RP_TILE 128                   // data rows per LDS tile
+#define RL_RP_LD (RL_RP_TILE + 4)        // padded LDS row: (4 i + k) mod 32 banks, two-way at worst
+#define RL_RP_VG 16                      // vectors per matrix-core block (the instruction's N)
+// vector blocks a workgroup walks per tile (accumulators: NG x degree tiles x 4 doubles per lane):
+// 5 (80 vectors: nine, for the 129 vectors of C5 in one block, spill 83 vector registers at rank 24)
+#define RL_RP_NG(R) ((R) <= 32 ? 5 : 3)
+#define RL_RP_RMAX 48
+
+// ---------------------------------------------------------------------------
+// k_rp_build: F[j][i] = sum_e w_i[e] q_j(n_i + e)   (unnormalised q, as everywhere: the
+// normalisation nu rides in k_lr_mix).  One thread per data row, four recurrences.
+//   grid (ceil(n / 256))   block 256
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rp_build(const int* __restrict__ base, const double* __restrict__ w4, int n, int m, int R,
+           const double* __restrict__ beta, double* __restrict__ F) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = base[i], d = b / m, n0 = b - d * m;
+    double w[4], s[4], qm[4], q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // (a base column near the end of an output plus its entries: zero weights there)
+        const int ne = n0 + e < m ? n0 + e : m - 1;
+        w[e] = n0 + e < m ? w4[(size_t)4 * i + e] : 0.0;
+        s[e] = lr_point(ne, m);
+        qm[e] = 0.0;
+        q[e] = 1.0;
+    }
+    for (int j = 0; j < R; ++j) {
+        double f = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f = fma(w[e], q[e], f);
+        F[(size_t)j * n + i] = f;
+        const double bj = beta[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double qn = fma(s[e], q[e], -bj * qm[e]);
+            qm[e] = q[e];
+            q[e] = qn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_rp_project<R>: part[run][v][j] = sum_{i in run} F[j][i] Y[v][i].
+//   grid (nruns, ceil(nvec / (RL_RP_NG(R) * RL_RP_VG)))   block 256 (four waves)
+//   runs: [nruns][3] = first row, end row, output -- contiguous rows of ONE output
+//   LDS: F tile [32][LD] + two Y tiles [16][LD]   (2 workgroups per CU)
+// A run is walked in tiles of 128 rows.  Per tile the F values go to LDS once and serve all
+// the workgroup's vector blocks; a block of 16 vectors is staged (coalesced: 64 consecutive
+// rows of one vector per wave-load; the next block's loads in flight meanwhile) and
+// multiplied on the matrix cores, v_mfma_f64_16x16x4_f64: D(16 x 16) += A(16 x 4) B(4 x 16) with
+// A = F (degrees x rows), B = Y (rows x vectors); wave w owns rows 32 w .. 32 w + 31 of the
+// tile (8 instructions per degree tile), accumulators stay in registers over the whole run
+// (2 degree tiles x 4 doubles per vector block).  Operand layouts (tools/mfma_f64_layout.hip,
+// measured on gfx950): A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D[row][col] in
+// register row / 4 of lane col + 16 (row % 4) (RL_RP_DROW).  The four waves' results meet in LDS at the end.
+// (emulator: no matrix instruction -- a thread owns two entries of the 32 x 16 result and
+// sums the tile's rows itself; staging, masks and indexing are shared)
+// ---------------------------------------------------------------------------
+#if !defined(RL_EMU)
+typedef double rp_double4 __attribute__((ext_vector_type(4)));
+// D layout: register r of lane l holds row RL_RP_DROW(l, r), column l & 15
+#define RL_RP_DROW(l, r) (((l) >> 4) + 4 * (r))
+#define RL_RP_PROJECT_ATTR __attribute__((amdgpu_waves_per_eu(2)))
+#else
+#define RL_RP_PROJECT_ATTR
+#endif
+
+template <int R>
+__global__ void __launch_bounds__(256) RL_RP_PROJECT_ATTR
+k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __restrict__ F,
+             const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump) {
+    static_assert(R <= RL_RP_RMAX, "rank");
+    // (the solver's round counter: bumped by the first kernel of a round)
+    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
+    constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG, NG = RL_RP_NG(R);
+    constexpr int NT = (R + 15) / 16;                 // degree tiles of 16
+    RL_SMEM(smem);
+    double* Fs = reinterpret_cast<double*>(smem);      // [16 NT][LD]
+    double* Ys = Fs + (size_t)16 * NT * LD;            // [2][VG][LD]
+    const int tid = threadIdx.x;
+    const int run = blockIdx.x, r0 = runs[3 * run], r1 = runs[3 * run + 1];
+    const int vbase = blockIdx.y * (NG * VG);
+    const int nvb = nvec - vbase < NG * VG ? nvec - vbase : NG * VG;
+    const int ng = (nvb + VG - 1) / VG;
+#if !defined(RL_EMU)
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    rp_double4 C[NG][NT];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) C[g][t] = rp_double4{0.0, 0.0, 0.0, 0.0};
+#else
+    double C[NG][2 * NT];                              // entries tid, tid + 256 (, ...) of [16 NT][16]
+    for (int g = 0; g < NG; ++g)
+        for (int t = 0; t < 2 * NT; ++t) C[g][t] = 0.0;
+#endif
+    // staging registers of one vector block: value idx = tid + 256 u -> vector idx / 128, row idx % 128
+    // (one block ahead; two blocks ahead measured the same: 471 vs 457 us)
+    constexpr int NU = VG * TILE / 256;
+    double yr[1][NU];
+    auto request = [&](int t0, int g, int slot) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
+            int v = vbase + g * VG + jv;
+            v = v < nvec ? v : nvec - 1;
+            int row = t0 + rr;
+            row = row < r1 ? row : r1 - 1;
+            yr[slot][u] = Y[(size_t)v * n + row];
+        }
+    };
+    for (int t0 = r0; t0 < r1; t0 += TILE) {
+        request(t0, 0, 0);
+        // the tile's F values: degree-major in memory, 128 consecutive rows per degree.
+        // (All loads first, unconditional from clamped positions, masked afterwards: a
+        // conditional load is a branch with a full memory wait behind it -- the first version
+        // paid a round trip per value: 457 us per C5 round)
+        {
+            constexpr int NF = R * TILE / 256;         // R even: exact
+            static_assert((R * TILE) % 256 == 0, "tile of F divides over the threads");
+            constexpr int NB = NF <= 12 ? NF : (NF + 1) / 2;      // values per batch (registers)
+#pragma unroll
+            for (int u0 = 0; u0 < NF; u0 += NB) {
+                double fr[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int uu = u0 + u < NF ? u0 + u : NF - 1;
+                    const int idx = tid + 256 * uu, deg = idx / TILE, rr = idx - deg * TILE;
+                    int row = t0 + rr;
+                    row = row < r1 ? row : r1 - 1;
+                    fr[u] = F[(size_t)deg * n + row];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (u0 + u < NF) {
+                        const int idx = tid + 256 * (u0 + u), deg = idx / TILE, rr = idx - deg * TILE;
+                        Fs[deg * LD + rr] = t0 + rr < r1 ? fr[u] : 0.0;
+                    }
+                }
+            }
+            // degrees R .. 16 NT - 1 of the last degree tile: zero (written once would do; the
+            // tile is small)
+            for (int idx = R * TILE + tid; idx < 16 * NT * TILE; idx += 256) {
+                const int deg = idx / TILE, rr = idx - deg * TILE;
+                Fs[deg * LD + rr] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g < ng) {
+                double* yb = Ys + (size_t)(g & 1) * VG * LD;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
+                    const bool live = vbase + g * VG + jv < nvec && t0 + rr < r1;
+                    yb[jv * LD + rr] = live ? yr[0][u] : 0.0;
+                }
+                __syncthreads();
+                if (g + 1 < ng) request(t0, g + 1, 0);
+#if !defined(RL_EMU)
+                const double* fa = Fs + li * LD + 32 * wave + lk;
+                const double* yv = yb + li * LD + 32 * wave + lk;
+#pragma unroll
+                for (int s = 0; s < TILE / 16; ++s) {          // 8 steps of 4 rows per wave
+                    const double b = yv[4 * s];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        C[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[(size_t)16 * t * LD + 4 * s],
+                                                                       b, C[g][t], 0, 0, 0);
+                }
+#else
+                for (int t = 0; t < 2 * NT; ++t) {
+                    const int e = tid + 256 * t;
+                    if (e < 16 * NT * 16) {
+                        const int deg = e / 16, jv = e - deg * 16;
+                        double sum = C[g][t];
+                        for (int rr = 0; rr < TILE; ++rr) sum = fma(Fs[deg * LD + rr], yb[jv * LD + rr], sum);
+                        C[g][t] = sum;
+                    }
+                }
+#endif
+            }
+        }
+        __syncthreads();        // every read of Fs and of both Y tiles is done before the next tile
+    }
+    // results: the four waves' blocks summed through LDS (the Y tiles' space), then written
+#if !defined(RL_EMU)
+    double* scr = Ys;                                   // [4 waves][16 NT][16]
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g < ng) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    scr[((size_t)wave * 16 * NT + 16 * t + RL_RP_DROW(lane, r)) * 16 + li] = C[g][t][r];
+            __syncthreads();
+            for (int e = tid; e < 16 * NT * 16; e += 256) {
+                const int deg = e / 16, jv = e - deg * 16, v = vbase + g * VG + jv;
+                if (deg < R && v < nvec) {
+                    const double s01 = scr[e] + scr[(size_t)16 * NT * 16 + e];
+                    const double s23 = scr[(size_t)2 * 16 * NT * 16 + e] + scr[(size_t)3 * 16 * NT * 16 + e];
+                    part[((size_t)run * nvec + v) * R + deg] = s01 + s23;
+                }
+            }
+            __syncthreads();
+        }
+    }
+#else
+    for (int g = 0; g < ng; ++g)
+        for (int t = 0; t < 2 * NT; ++t) {
+            const int e = tid + 256 * t;
+            if (e < 16 * NT * 16) {
+                const int deg = e / 16, jv = e - deg * 16, v = vbase + g * VG + jv;
+                if (deg < R && v < nvec) part[((size_t)run * nvec + v) * R + deg] = C[g][t];
+            }
+        }
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// k_rp_expand<R>: Q[v][i] = sum_j F[j][i] Zhat[v D + d(i)][j]  (+ diag[i] X2[v][i]).
+//   grid (ceil(n / 256))   block 256
+// A thread owns a data row and keeps its R values of F in registers for all the vectors;
+// a wave's 64 rows lie in one output except at an output border, so a vector's coefficient
+// row is wave-uniform and comes through scalar loads (the structure of k_lr_expand; the wave
+// at a border loads per lane).  Workgroups start at different vectors (v0 = 7 block mod nvec)
+// so that the chip does not write the same few vectors in lockstep (k_lr_expand's finding).
+//   out_end [D]: end row (sorted order) of each output
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rp_output_of(const int* __restrict__ out_end, int D, int i) {
+    int lo = 0, hi = D - 1;                 // first d with i < out_end[d]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (i < out_end[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256)
+k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n, int nvec, int D,
+            const int* __restrict__ out_end, double* __restrict__ Q,
+            const double* __restrict__ diag, const double* __restrict__ X2, int stagger) {
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    const int ic = i < n ? i : n - 1;
+    double p[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) p[j] = F[(size_t)j * n + ic];
+    const double dg = diag != nullptr ? diag[ic] : 0.0;
+    const int wf = blockIdx.x * 256 + (tid & ~63);
+    const int wl = wf + 63 < n ? wf + 63 : n - 1;
+    const int dfirst = RL_LR_UNIFORM(rp_output_of(out_end, D, wf < n ? wf : n - 1));
+    const int dlast = RL_LR_UNIFORM(rp_output_of(out_end, D, wl));
+    const int dmine = dfirst == dlast ? dfirst : rp_output_of(out_end, D, ic);
+    int v = (int)(((unsigned)stagger * blockIdx.x) % (unsigned)nvec);
+    // Two separate loops (not one loop with a select on the pointer: the compiler then loads
+    // the coefficients per lane in both cases -- twelve dependent 16-byte vector loads per
+    // vector, 800 us per C5 round instead of the scalar loads' 2xx)
+    if (dfirst == dlast) {
+        for (int it = 0; it < nvec; ++it) {
+            const double* z = Zhat + ((size_t)v * D + dfirst) * R;      // wave-uniform: scalar loads
+            double ev = 0.0, od = 0.0;
+#pragma unroll
+            for (int j = 0; j + 1 < R; j += 2) {
+                ev = fma(z[j], p[j], ev);
+                od = fma(z[j + 1], p[j + 1], od);
+            }
+            double acc = ev + od;
+            if (diag != nullptr) acc = fma(dg, X2[(size_t)v * n + ic], acc);
+            if (i < n) Q[(size_t)v * n + i] = acc;
+            v = v + 1 < nvec ? v + 1 : 0;
+        }
+    } else {
+        for (int it = 0; it < nvec; ++it) {
+            const double* z = Zhat + ((size_t)v * D + dmine) * R;
+            double ev = 0.0, od = 0.0;
+#pragma unroll
+            for (int j = 0; j + 1 < R; j += 2) {
+                ev = fma(z[j], p[j], ev);
+                od = fma(z[j + 1], p[j + 1], od);
+            }
+            double acc = ev + od;
+            if (diag != nullptr) acc = fma(dg, X2[(size_t)v * n + ic], acc);
+            if (i < n) Q[(size_t)v * n + i] = acc;
+            v = v + 1 < nvec ? v + 1 : 0;
+        }
+    }
+}

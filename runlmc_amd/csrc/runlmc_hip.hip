@@ -14,6 +14,7 @@
 #include "rl_kernels2.h"
 #include "rl_kernels3.h"
 #include "rl_lowrank.h"
+#include "rl_rowpoly.h"
 #include "rl_filter.h"
 
 // ---------------------------------------------------------------------------
@@ -100,6 +101,8 @@ struct RlKnobs {
     bool staged_wt = false;      // RUNLMC_STAGED_WT: LDS-staged SpMVs whatever the size
     bool no_staged_wt = false;   // RUNLMC_NO_STAGED_WT
     bool no_w_poly = false;      // RUNLMC_NO_W_POLY: the W product reads the expanded grid vector
+    bool no_rp = false;          // RUNLMC_NO_RP: no row-polynomial form of large solver rounds (rl_rowpoly.h)
+    int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
     int w_poly_rmax = 32;        // RUNLMC_W_POLY_RMAX: largest rank whose expansion the W kernel takes over
                                  // (36 measured: 791 us against 186 + 473 for expansion + staged W per C5 round)
     bool no_sort = false;        // RUNLMC_NO_SORT: caller's data order inside the SKI handle
@@ -134,6 +137,8 @@ static RlKnobs read_knobs() {
     k.staged_wt = flag("RUNLMC_STAGED_WT");
     k.no_staged_wt = flag("RUNLMC_NO_STAGED_WT");
     k.no_w_poly = flag("RUNLMC_NO_W_POLY");
+    k.no_rp = flag("RUNLMC_NO_RP");
+    k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
     k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
     k.no_sort = flag("RUNLMC_NO_SORT");
     k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
@@ -1523,7 +1528,7 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
     const int chunks = lr_project<R>(g, X, nrows, st);
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
               (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
-              (const double*)g->lr_nu, g->lr_zhat);
+              (const double*)g->lr_nu, g->lr_zhat, (const int*)nullptr);
     // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
     // the evaluation costs more than the two vector passes it saves -- measured, C5
     // periodic: 5.03 against 4.17 ms per solver round)
@@ -2544,6 +2549,13 @@ struct rl_ski {
     int poly_nblk = 0;              // 0: not built yet, -1: not applicable
     double* poly_part = nullptr;
     size_t poly_part_cap = 0;
+    // row-polynomial form of large solver rounds (rl_rowpoly.h): F = W Phi, built per rank
+    double* rp_F = nullptr;
+    int rp_R = 0;                   // rank F was built for (0: none)
+    int *rp_runs = nullptr, *rp_run_ptr = nullptr, *rp_out_end = nullptr;
+    int rp_nruns = 0;
+    double* rp_part = nullptr;
+    size_t rp_part_cap = 0;
     std::vector<int> eps_end;       // noise in runs: rows [eps_end[k-1], eps_end[k]) carry eps_val[k]
     std::vector<double> eps_val;    // (empty: more than RL_MAX_D runs)
     bool permuted = false;
@@ -2805,7 +2817,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
-                    s->poly_part};
+                    s->poly_part, s->rp_F, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -3007,13 +3019,129 @@ static int ski_w_poly(rl_ski* s, double* Yp, int nvec, const double* diag, const
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
+// ---------------------------------------------------------------------------
+// Row-polynomial form of large solver rounds (rl_rowpoly.h)
+// ---------------------------------------------------------------------------
+// may this handle's operator run as F M F^T for a batch of nvec vectors?  (single term,
+// structured W on a 1-D grid, every top row in the polynomial form, a large system)
+static bool rp_ok(const rl_ski* s, int nvec) {
+    const rl_gridop* g = s->g;
+    return s->extra.empty() && s->W4_base != nullptr && !s->h_base.empty() && !g->wide &&
+           g->lr_try && !g->lr_dirty && g->lr_ok && s->ngrid == g->D * g->m &&
+           ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) &&
+           // (F is read twice per product whatever the batch: at ranks above 32 a batch of a
+           // few dozen vectors is level with the interpolation products or behind them --
+           // C5, 17 vectors, rank 36: 0.615 against 0.587 ms per round; rank 24: 0.49 against 0.53)
+           (g->lr_r <= 32 || nvec >= 48 || s->kn.staged_wt) &&
+           !s->kn.no_staged_wt && !s->kn.no_rp;
+}
+// F for the operator's current rank, the runs of rows k_rp_project walks, the partial sums
+// of nvec vectors.  Allocates: never inside a stream capture (the solver calls it before).
+static int rp_prepare(rl_ski* s, int nvec) {
+    rl_gridop* g = s->g;
+    const int R = g->lr_r, n = s->n, D = g->D, m = g->m;
+    if (s->rp_R != R) {
+        if (s->rp_F) RL_HIP(hipFree(s->rp_F));
+        s->rp_F = nullptr;
+        s->rp_R = 0;
+        RL_HIP(hipMalloc((void**)&s->rp_F, (size_t)R * n * sizeof(double)));
+        RL_LAUNCH(k_rp_build, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t) nullptr,
+                  (const int*)s->W4_base, (const double*)s->W4_w, n, m, R,
+                  (const double*)g->lr_beta, s->rp_F);
+        RL_HIP(hipGetLastError());
+        RL_HIP(hipDeviceSynchronize());
+        s->rp_R = R;
+    }
+    if (!s->rp_runs) {
+        // rows of an output are contiguous in the sorted order; runs of whole tiles, about a
+        // thousand of them (two rounds of resident workgroups with room for imbalance)
+        std::vector<int> out_end(D, 0), run_ptr(D + 1, 0), runs;
+        int len = ((n + 1023) / 1024 + RL_RP_TILE - 1) / RL_RP_TILE * RL_RP_TILE;
+        len = std::max(RL_RP_TILE, std::min(len, 64 * RL_RP_TILE));
+        int i = 0;
+        for (int d = 0; d < D; ++d) {
+            const int start = i;
+            while (i < n && s->h_base[i] < (d + 1) * m) ++i;
+            out_end[d] = i;
+            run_ptr[d] = (int)runs.size() / 3;
+            for (int r0 = start; r0 < i; r0 += len) {
+                runs.push_back(r0);
+                runs.push_back(std::min(r0 + len, i));
+                runs.push_back(d);
+            }
+        }
+        run_ptr[D] = (int)runs.size() / 3;
+        if (i != n) return fail(RL_EINVAL, "row-polynomial form: rows are not sorted by output");
+        if (runs.empty()) return fail(RL_EINVAL, "row-polynomial form: no rows");
+        RL_TRY(upload_raw((void**)&s->rp_runs, runs.data(), runs.size() * sizeof(int)));
+        RL_TRY(upload_raw((void**)&s->rp_run_ptr, run_ptr.data(), run_ptr.size() * sizeof(int)));
+        RL_TRY(upload_raw((void**)&s->rp_out_end, out_end.data(), out_end.size() * sizeof(int)));
+        s->rp_nruns = run_ptr[D];
+    }
+    const size_t need = (size_t)s->rp_nruns * nvec * R;
+    if (s->rp_part_cap < need) {
+        if (s->rp_part) RL_HIP(hipFree(s->rp_part));
+        s->rp_part = nullptr;
+        s->rp_part_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->rp_part, need * sizeof(double)));
+        s->rp_part_cap = need;
+    }
+    RL_TRY(lr_reserve(g, nvec));             // (the mixed coefficients live on the grid handle)
+    return RL_OK;
+}
+static bool rp_ready(const rl_ski* s, int nvec) {
+    return s->rp_F != nullptr && s->rp_R == s->g->lr_r && s->rp_runs != nullptr &&
+           s->rp_part_cap >= (size_t)s->rp_nruns * nvec * s->rp_R &&
+           s->g->lr_zhat_cap >= (size_t)nvec * s->g->D * RL_LR_RMAX;
+}
+template <int R>
+static void rp_launch(rl_ski* s, const double* Xp, double* Yp, int nvec, const double* diag,
+                      hipStream_t st, int* bump) {
+    rl_gridop* g = s->g;
+    constexpr int NT = (R + 15) / 16;
+    const size_t lds = ((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD * sizeof(double);
+    const int vblk = RL_RP_NG(R) * RL_RP_VG;
+    RL_LAUNCH((k_rp_project<R>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds, st,
+              Xp, s->n, nvec, (const double*)s->rp_F, (const int*)s->rp_runs, s->rp_part, bump);
+    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
+              (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
+              (const double*)g->lr_B, (const double*)g->lr_nu, g->lr_zhat,
+              (const int*)s->rp_run_ptr);
+    RL_LAUNCH((k_rp_expand<R>), dim3((s->n + 255) / 256), dim3(256), 0, st,
+              (const double*)g->lr_zhat, (const double*)s->rp_F, s->n, nvec, g->D,
+              (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger);
+}
+static int ski_rp_mvm(rl_ski* s, const double* Xp, double* Yp, int nvec, const double* diag,
+                      hipStream_t st, int* bump) {
+    trace_once("K~ product: row-polynomial form (k_rp_project / k_lr_mix / k_rp_expand)");
+    switch (s->g->lr_r) {
+        case 24: rp_launch<24>(s, Xp, Yp, nvec, diag, st, bump); break;
+        case 32: rp_launch<32>(s, Xp, Yp, nvec, diag, st, bump); break;
+        case 36: rp_launch<36>(s, Xp, Yp, nvec, diag, st, bump); break;
+        case 40: rp_launch<40>(s, Xp, Yp, nvec, diag, st, bump); break;
+        case 48: rp_launch<48>(s, Xp, Yp, nvec, diag, st, bump); break;
+        default: return fail(RL_EINVAL, "row-polynomial form: bad basis size");
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 // Yp = K~ Xp, both in internal row order (what the solver iterates on)
 // (noise = false: Yp = W K_UU W^T Xp only -- the caller adds eps (.) Xp itself)
 static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st,
                        int* bump = nullptr, bool noise = true) {
     RL_TRY(ski_reserve(s, nvec));
-    RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     const double* diag = s->has_noise && noise ? s->noise_diag : nullptr;
+    // every top row in the polynomial form, a large system: F M F^T, no interpolation
+    // products, no grid vector (rl_rowpoly.h).  (Buffers: the solver prepares them before it
+    // captures; a plain product outside a capture prepares them here.)
+    if (rp_ok(s, nvec)) {
+        if (!rp_ready(s, nvec) && !stream_capturing(st)) RL_TRY(rp_prepare(s, nvec));
+        if (rp_ready(s, nvec)) {
+            return ski_rp_mvm(s, Xp, Yp, nvec, diag, st, bump);
+        }
+    }
+    RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     // a polynomial-form operator hands its mixed coefficients to the W kernel instead of
     // writing the grid vector (the grid handle says whether it took that path)
     s->g->expand_deferred = false;
@@ -3471,6 +3599,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     RL_TRY(ski_reserve(s, nrhs));
     RL_TRY(gridop_prepare(s->g, nrhs));
     for (const SkiTerm& t : s->extra) RL_TRY(gridop_prepare(t.g, nrhs));
+    if (rp_ok(s, nrhs)) RL_TRY(rp_prepare(s, nrhs));       // (row-polynomial rounds: F, runs, partial sums)
     int active = nrhs;
     int done = 0;          // iterations issued so far
 

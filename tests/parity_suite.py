@@ -1637,6 +1637,79 @@ def check_w_poly_product():
                 os.environ[k_] = v
 
 
+def check_row_polynomial_form():
+    """The row-polynomial form of a polynomial-form SKI operator (rl_rowpoly.h: K~ = F M F^T
+    + eps with F = W Phi built once per rank; k_rp_project on the fp64 matrix cores, k_rp_expand
+    with scalar-loaded coefficients), forced onto small systems: against the same operator
+    through the interpolation products (RUNLMC_NO_RP: agreement to roundoff, another
+    summation order), against the oracle, through a solve.  Ragged outputs and an EMPTY
+    output (runs and tiles end inside a tile), batches that are no multiple of the
+    16-vector block and above one workgroup's 144 vectors (two vector blocks of
+    workgroups), rank 24 (rbf) and a larger rank (periodic: three degree tiles)."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch
+    from oracle.kernels import KernelSpec, RBFSpec, StdPeriodicSpec
+    rng = np.random.RandomState(29)
+    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_RP', 'RUNLMC_NO_FUSE_W', 'RUNLMC_NO_FUSE_WT')
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    try:
+        os.environ['RUNLMC_STAGED_WT'] = '1'
+        os.environ['RUNLMC_NO_FUSE_W'] = '1'
+        os.environ['RUNLMC_NO_FUSE_WT'] = '1'
+        for D, Q, m_data, k, kern in ((3, 2, 2600, 37, 'rbf'), (4, 2, 700, 150, 'rbf'),
+                                      (2, 2, 2600, 11, 'periodic')):
+            p = synth.make_problem(D, Q, 1, m_data, eps=1.0, kern=kern)
+            # ragged: cut the outputs to different lengths, one of them to nothing
+            lens = [m_data, m_data // 3 + 5, 0, m_data - 131][:D]
+            if D == 2:
+                lens = [m_data - 77, 129]
+            Xs = [x[:l] for x, l in zip(p.Xs, lens)]
+            Ys = [y[:l] for y, l in zip(p.Ys, lens)]
+            from runlmc_amd.approx.interpolation import multi_interpolant
+            W = multi_interpolant(Xs, p.grid)
+            WT = W.transpose().tocsr()
+            fk = synth.functional_kernel(p)
+            ad = (0,)
+            n = sum(lens)
+            V = rng.randn(k, n)
+
+            def run(no_rp):
+                os.environ.pop('RUNLMC_NO_RP', None)
+                if no_rp:
+                    os.environ['RUNLMC_NO_RP'] = '1'
+                K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (W, WT)}, lens)
+                op = K.device_operator()
+                op.grid.set_form_gate(0)
+                assert op.grid.top_forms() == ([1] * Q, True)
+                Y = op.matmat_host(V)
+                # (six iterations: before the Lanczos vectors of these systems are roundoff-
+                # determined -- after thirty the two summation orders are 1e-3 apart)
+                X = solve_batch(op, torch.from_numpy(V[:3]).to(op.device), tol=1e-6,
+                                maxiter=6)[0].cpu().numpy()
+                Y2 = op.matmat_host(V[:5])           # (a smaller batch on the same handle)
+                return Y, X, Y2, op.grid.form()[0]
+            Yr, Xr, Y2r, rank = run(False)
+            Yu, Xu, Y2u, _ = run(True)
+            assert rank == 24 if kern == 'rbf' else rank in (32, 36, 40, 48), rank
+            scale = np.abs(Yu).max()
+            assert np.abs(Yr - Yu).max() <= 1e-13 * scale, np.abs(Yr - Yu).max() / scale
+            assert not np.array_equal(Yr, Yu)        # (another summation order: the form ran)
+            assert np.abs(Y2r - Y2u).max() <= 1e-13 * scale
+            assert np.abs(Xr - Xu).max() <= 1e-9 * np.abs(Xu).max()
+            make = {'rbf': RBFSpec, 'periodic': StdPeriodicSpec}
+            spec = KernelSpec(D, [make[d_[0]](*d_[1:]) for d_ in p.kern_desc], list(p.coreg_vecs),
+                              list(p.coreg_diags), p.noise)
+            spec.set_input_dim(1)
+            oop = olik.LMCOperatorOracle(spec, p.grid_dists, W, WT, lens)
+            for v in (0, k - 1):
+                _close(Yr[v], oop.matvec(V[v]), 1e-11)
+    finally:
+        for k_, v in saved.items():
+            os.environ.pop(k_, None)
+            if v is not None:
+                os.environ[k_] = v
+
+
 def check_generate_probe_dtypes():
     """StochasticDerivService.generate puts the right-hand sides together on the device;
     +-1 probes cross as one byte per entry whatever integer width they come in.  The

@@ -145,6 +145,10 @@ def test_w_poly_product():
     ps.check_w_poly_product()
 
 
+def test_row_polynomial_form():
+    ps.check_row_polynomial_form()
+
+
 def test_generate_probe_dtypes():
     ps.check_generate_probe_dtypes()
 

@@ -484,6 +484,51 @@ def test_c5_family_gradient_at_fixed_iterations(native, kern):
     assert _rel(alphas['structured'], xo) < 1e-8
 
 
+@pytest.mark.parametrize('kern', ['rbf', 'periodic'])
+def test_c5_row_polynomial_rounds(native, kern, monkeypatch):
+    """The row-polynomial form of the C5 operator (rl_rowpoly.h: K~ = F M F^T + eps, F = W Phi;
+    k_rp_project on the fp64 matrix cores over 980 runs of 1024 rows and two blocks of
+    vectors, k_rp_expand) -- what the solver's rounds run at this size: the 129-vector
+    product against the oracle's operator on three vectors (1e-11) and against the same
+    handle's interpolation-product path (RUNLMC_NO_RP) on all of them (1e-12); MINRES
+    iterates after CAP iterations against that path (1e-8) and the oracle's MINRES."""
+    from runlmc_amd.util import synth
+    from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
+    from runlmc_amd._native import solve_batch
+    from oracle.kernels import StdPeriodicSpec
+    p = synth.make_problem(10, 5, 1, 100000, kern=kern)
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    gen = torch.Generator().manual_seed(41)
+    X = torch.randn(129, p.n, dtype=torch.float64, generator=gen)
+    out = {}
+    for mode in ('rp', 'interp'):
+        monkeypatch.delenv('RUNLMC_NO_RP', raising=False)
+        if mode == 'interp':
+            monkeypatch.setenv('RUNLMC_NO_RP', '1')
+        K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+        op = K.device_operator()
+        assert op.grid.form()[0] == (24 if kern == 'rbf' else 36)
+        Y = op.mvm(X.to(op.device)).cpu().numpy()
+        Xs, it = solve_batch(op, X[:17].to(op.device), tol=1e-4, maxiter=CAP)[:2]
+        assert np.all(np.array(it) == CAP)
+        out[mode] = (Y, Xs.cpu().numpy())
+    Yr, Sr = out['rp']
+    Yi, Si = out['interp']
+    assert not np.array_equal(Yr, Yi)
+    assert (np.abs(Yr - Yi) / np.abs(Yi).max(axis=1, keepdims=True)).max() < 1e-12
+    assert (np.abs(Sr - Si) / np.abs(Si).max(axis=1, keepdims=True)).max() < 1e-8
+    make = {'rbf': RBFSpec, 'periodic': StdPeriodicSpec}
+    spec = KernelSpec(p.D, [make[d[0]](*d[1:]) for d in p.kern_desc], list(p.coreg_vecs),
+                      list(p.coreg_diags), p.noise)
+    spec.set_input_dim(1)
+    oop = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    for v in (0, 80, 128):
+        assert _rel(Yr[v], oop.matvec(X[v].numpy())) < REL, v
+    xo = minres_ps(oop.matvec, X[0].numpy(), rtol=1e-10, maxiter=CAP)[0]
+    assert _rel(Sr[0], xo) < 1e-8
+
+
 def test_polynomial_gate_boundary_full_size():
     """The acceptance gate at its boundary on the C5 grid (100 004 points): see
     parity_suite.check_polynomial_gate_boundary."""
