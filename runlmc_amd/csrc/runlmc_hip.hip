@@ -2552,6 +2552,8 @@ struct rl_ski {
     // row-polynomial form of large solver rounds (rl_rowpoly.h): F = W Phi, built per rank
     double* rp_F = nullptr;
     int rp_R = 0;                   // rank F was built for (0: none)
+    double* rp_Fc = nullptr;        // the same in the CALLER's row order (rl_ski_mvm: no row permutations)
+    int rp_Fc_R = 0;
     int *rp_runs = nullptr, *rp_run_ptr = nullptr, *rp_out_end = nullptr;
     int rp_nruns = 0;
     double* rp_part = nullptr;
@@ -2817,7 +2819,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
-                    s->poly_part, s->rp_F, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part};
+                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -3095,31 +3097,31 @@ static bool rp_ready(const rl_ski* s, int nvec) {
            s->g->lr_zhat_cap >= (size_t)nvec * s->g->D * RL_LR_RMAX;
 }
 template <int R>
-static void rp_launch(rl_ski* s, const double* Xp, double* Yp, int nvec, const double* diag,
-                      hipStream_t st, int* bump) {
+static void rp_launch(rl_ski* s, const double* F, const double* Xp, double* Yp, int nvec,
+                      const double* diag, hipStream_t st, int* bump) {
     rl_gridop* g = s->g;
     constexpr int NT = (R + 15) / 16;
     const size_t lds = ((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
     RL_LAUNCH((k_rp_project<R>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds, st,
-              Xp, s->n, nvec, (const double*)s->rp_F, (const int*)s->rp_runs, s->rp_part, bump);
+              Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump);
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
               (const double*)g->lr_B, (const double*)g->lr_nu, g->lr_zhat,
               (const int*)s->rp_run_ptr);
     RL_LAUNCH((k_rp_expand<R>), dim3((s->n + 255) / 256), dim3(256), 0, st,
-              (const double*)g->lr_zhat, (const double*)s->rp_F, s->n, nvec, g->D,
+              (const double*)g->lr_zhat, F, s->n, nvec, g->D,
               (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger);
 }
-static int ski_rp_mvm(rl_ski* s, const double* Xp, double* Yp, int nvec, const double* diag,
-                      hipStream_t st, int* bump) {
+static int ski_rp_mvm(rl_ski* s, const double* F, const double* Xp, double* Yp, int nvec,
+                      const double* diag, hipStream_t st, int* bump) {
     trace_once("K~ product: row-polynomial form (k_rp_project / k_lr_mix / k_rp_expand)");
     switch (s->g->lr_r) {
-        case 24: rp_launch<24>(s, Xp, Yp, nvec, diag, st, bump); break;
-        case 32: rp_launch<32>(s, Xp, Yp, nvec, diag, st, bump); break;
-        case 36: rp_launch<36>(s, Xp, Yp, nvec, diag, st, bump); break;
-        case 40: rp_launch<40>(s, Xp, Yp, nvec, diag, st, bump); break;
-        case 48: rp_launch<48>(s, Xp, Yp, nvec, diag, st, bump); break;
+        case 24: rp_launch<24>(s, F, Xp, Yp, nvec, diag, st, bump); break;
+        case 32: rp_launch<32>(s, F, Xp, Yp, nvec, diag, st, bump); break;
+        case 36: rp_launch<36>(s, F, Xp, Yp, nvec, diag, st, bump); break;
+        case 40: rp_launch<40>(s, F, Xp, Yp, nvec, diag, st, bump); break;
+        case 48: rp_launch<48>(s, F, Xp, Yp, nvec, diag, st, bump); break;
         default: return fail(RL_EINVAL, "row-polynomial form: bad basis size");
     }
     RL_HIP(hipGetLastError());
@@ -3132,13 +3134,16 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
                        int* bump = nullptr, bool noise = true) {
     RL_TRY(ski_reserve(s, nvec));
     const double* diag = s->has_noise && noise ? s->noise_diag : nullptr;
+    // (a pending form decision is taken here, so that the path does not depend on whether an
+    // earlier product happened to trigger it)
+    if (s->extra.empty() && !s->g->wide && !stream_capturing(st)) RL_TRY(lr_prepare(s->g, nvec));
     // every top row in the polynomial form, a large system: F M F^T, no interpolation
     // products, no grid vector (rl_rowpoly.h).  (Buffers: the solver prepares them before it
     // captures; a plain product outside a capture prepares them here.)
     if (rp_ok(s, nvec)) {
         if (!rp_ready(s, nvec) && !stream_capturing(st)) RL_TRY(rp_prepare(s, nvec));
         if (rp_ready(s, nvec)) {
-            return ski_rp_mvm(s, Xp, Yp, nvec, diag, st, bump);
+            return ski_rp_mvm(s, s->rp_F, Xp, Yp, nvec, diag, st, bump);
         }
     }
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
@@ -3236,6 +3241,28 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
     RL_HIP(hipSetDevice(s->g->device));
     hipStream_t st = (hipStream_t)stream;
     if (!s->permuted) return ski_mvm_int(s, X, Y, nvec, st);
+    // Row-polynomial form in the CALLER's row order: F's columns permuted once per rank, no
+    // row permutation of the batch (they were half of this product's time at C5).  The rows of
+    // an output are contiguous in both orders, so runs, output borders and the noise array
+    // (constant per output) serve both.
+    if (s->extra.empty() && !s->g->wide && !stream_capturing(st)) {
+        RL_TRY(lr_prepare(s->g, nvec));
+        if (rp_ok(s, nvec)) {
+            RL_TRY(rp_prepare(s, nvec));
+            if (s->rp_Fc_R != s->rp_R) {
+                if (s->rp_Fc) RL_HIP(hipFree(s->rp_Fc));
+                s->rp_Fc = nullptr;
+                s->rp_Fc_R = 0;
+                RL_HIP(hipMalloc((void**)&s->rp_Fc, (size_t)s->rp_R * s->n * sizeof(double)));
+                permute_rows(s, s->rp_F, s->rp_Fc, s->rp_R, 1, (hipStream_t) nullptr);
+                RL_HIP(hipGetLastError());
+                RL_HIP(hipDeviceSynchronize());
+                s->rp_Fc_R = s->rp_R;
+            }
+            return ski_rp_mvm(s, s->rp_Fc, X, Y, nvec, s->has_noise ? s->noise_diag : nullptr, st,
+                              nullptr);
+        }
+    }
     RL_TRY(ski_reserve_perm(s, nvec));
     permute_rows(s, X, s->P1, nvec, 0, st);
     RL_TRY(ski_mvm_int(s, s->P1, s->P2, nvec, st));

@@ -1524,6 +1524,8 @@ def check_staged_wt_product():
     from runlmc_amd._native import solve_batch
     rng = np.random.RandomState(17)
     saved = os.environ.pop('RUNLMC_STAGED_WT', None)
+    saved_rp = os.environ.get('RUNLMC_NO_RP')
+    os.environ['RUNLMC_NO_RP'] = '1'        # (the interpolation products are what is tested here)
     try:
         for kind in ('uniform', 'clustered', 'gappy'):
             p = synth.make_problem(3, 2, 1, 400, eps=1.0)
@@ -1579,8 +1581,11 @@ def check_staged_wt_product():
             assert np.array_equal(Y1, Y0), kind
     finally:
         os.environ.pop('RUNLMC_STAGED_WT', None)
+        os.environ.pop('RUNLMC_NO_RP', None)
         if saved is not None:
             os.environ['RUNLMC_STAGED_WT'] = saved
+        if saved_rp is not None:
+            os.environ['RUNLMC_NO_RP'] = saved_rp
 
 
 def check_w_poly_product():
@@ -1594,10 +1599,11 @@ def check_w_poly_product():
     from runlmc_amd.util import synth
     from runlmc_amd._native import solve_batch
     rng = np.random.RandomState(23)
-    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_W_POLY', 'RUNLMC_W_POLY_RMAX')
+    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_W_POLY', 'RUNLMC_W_POLY_RMAX', 'RUNLMC_NO_RP')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     try:
         os.environ['RUNLMC_STAGED_WT'] = '1'
+        os.environ['RUNLMC_NO_RP'] = '1'             # (the row-polynomial form would take these products)
         os.environ['RUNLMC_W_POLY_RMAX'] = '36'      # (default 32: rank 36 measured slower fused)
         # (rbf: rank 24; the periodic family's period-1 kernel: one of the larger ranks the W
         # kernel takes, 32 or 36)
