@@ -451,10 +451,14 @@ def time_full_operator(g, p, batch, gen, steps, world, dev, alg):
             'steps': fsteps, 'n': p.n,
             'roofline_frac': full_alg / (fwall * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'algorithmic_bytes_per_step': full_alg,
-            'what': 'W (K_UU (W^T x)) + eps * x on %d data-space vectors, in the CALLER\'s row '
-                    'order: the two row permutations of the batch (caller <-> grid-sorted order) '
-                    'are inside this time -- about half of it at C5 -- and a solve pays them '
-                    'once, not per round (DESIGN.md section 3, item 6)' % batch}
+            'what': 'K~ x = W (K_UU (W^T x)) + eps * x on %d data-space vectors in the CALLER\'s row '
+                    'order.  With every top row in the polynomial form this runs as F M F^T + eps, '
+                    'F = W Phi in the caller\'s order (csrc/rl_rowpoly.h: k_rp_project on the fp64 '
+                    'matrix cores, k_lr_mix, k_rp_expand; no interpolation product, no grid vector, '
+                    'no row permutation of the batch -- until round 4 the two permutations were half '
+                    'of this time); other operators: permute, W^T, grid product, W, permute.  The '
+                    'algorithmic byte count is that of the interpolation-product algorithm '
+                    '(SURVEY 8d); the row-polynomial form moves fewer' % batch}
 
 
 FORM_NAMES = {0: 'transform', 1: 'polynomial', 2: 'filter'}
