@@ -14,8 +14,10 @@
 //                                    staged through LDS)
 //     k_lr_mix       Zhat = nu (.) sum_q B_q C_q (nu (.) Z)          (rl_lowrank.h)
 //     k_rp_expand    Q = F Zhat (+ eps (.) Y)                         (scalar-loaded coefficients)
-// i.e. one read of Y, one write of Q and two reads of F, against W^T (read Y, write g),
-// projection (read g), mix, W with expansion (write Q) before: 1.16 -> see DESIGN.md section 6.
+// i.e. one read of Y, one write of Q and one read of F (the expansion computes its rows of F
+// from the interpolation entries, FLY below), against W^T (read Y, write g), projection
+// (read g), mix, W with expansion (write Q) before: 1.18 -> 0.60 ms per C5 round, DESIGN.md
+// section 6.
 // Same operator, another summation order (roundoff-level agreement, as k_spmv_w_poly).
 // Rows are in the handle's SORTED order (by output, then by grid position), so the rows of
 // an output are contiguous; F is degree-major, F[j * n + i].
@@ -67,6 +69,49 @@ k_rp_build(const int* __restrict__ base, const double* __restrict__ w4, int n, i
     }
 }
 
+// A row's values of F straight from its interpolation entry (base column, four weights):
+// f(j) called for j = 0 .. R - 1 in order.  (FLY variants of the kernels below: no table --
+// F costs a 17-vector batch as much HBM traffic as its vectors do.)
+struct RpRow {
+    double w[4], s[4], qm[4], q[4];
+    __device__ __forceinline__ void start(int b, int m, const double* __restrict__ w4row) {
+        const int d = b / m, n0 = b - d * m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ne = n0 + e < m ? n0 + e : m - 1;
+            w[e] = n0 + e < m ? w4row[e] : 0.0;
+            s[e] = lr_point(ne, m);
+            qm[e] = 0.0;
+            q[e] = 1.0;
+        }
+    }
+    __device__ __forceinline__ double next(double bj) {
+        double f = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f = fma(w[e], q[e], f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double qn = fma(s[e], q[e], -bj * qm[e]);
+            qm[e] = q[e];
+            q[e] = qn;
+        }
+        return f;
+    }
+};
+
+// scatter of the interpolation entries into the caller's row order (rl_ski_mvm)
+__global__ void __launch_bounds__(256)
+k_rp_permute_entries(const int* __restrict__ base, const double* __restrict__ w4,
+                     const int* __restrict__ perm, int n, int* __restrict__ base_c,
+                     double* __restrict__ w4_c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int dst = perm[i];
+    base_c[dst] = base[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w4_c[(size_t)4 * dst + e] = w4[(size_t)4 * i + e];
+}
+
 // ---------------------------------------------------------------------------
 // k_rp_project<R>: part[run][v][j] = sum_{i in run} F[j][i] Y[v][i].
 //   grid (nruns, ceil(nvec / (RL_RP_NG(R) * RL_RP_VG)))   block 256 (four waves)
@@ -93,10 +138,12 @@ typedef double rp_double4 __attribute__((ext_vector_type(4)));
 #define RL_RP_PROJECT_ATTR
 #endif
 
-template <int R>
+template <int R, bool FLY>
 __global__ void __launch_bounds__(256) RL_RP_PROJECT_ATTR
 k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __restrict__ F,
-             const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump) {
+             const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump,
+             const int* __restrict__ base, const double* __restrict__ w4, int m,
+             const double* __restrict__ beta) {
     static_assert(R <= RL_RP_RMAX, "rank");
     // (the solver's round counter: bumped by the first kernel of a round)
     if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
@@ -143,7 +190,27 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
         // (All loads first, unconditional from clamped positions, masked afterwards: a
         // conditional load is a branch with a full memory wait behind it -- the first version
         // paid a round trip per value: 457 us per C5 round)
-        {
+        if (FLY) {
+            // the tile's F values computed from the rows' interpolation entries: waves 0-1 run
+            // a row each (four recurrences), waves 2-3 clear the padding degrees
+            if (tid < TILE) {
+                int row = t0 + tid;
+                const bool live = row < r1;
+                row = live ? row : r1 - 1;
+                RpRow rw;
+                rw.start(base[row], m, w4 + (size_t)4 * row);
+#pragma unroll 4
+                for (int j = 0; j < R; ++j) {
+                    const double f = rw.next(beta[j]);
+                    Fs[j * LD + tid] = live ? f : 0.0;
+                }
+            } else {
+                for (int idx = R * TILE + tid - TILE; idx < 16 * NT * TILE; idx += 256 - TILE) {
+                    const int deg = idx / TILE, rr = idx - deg * TILE;
+                    Fs[deg * LD + rr] = 0.0;
+                }
+            }
+        } else {
             constexpr int NF = R * TILE / 256;         // R even: exact
             static_assert((R * TILE) % 256 == 0, "tile of F divides over the threads");
             constexpr int NB = NF <= 12 ? NF : (NF + 1) / 2;      // values per batch (registers)
@@ -265,17 +332,26 @@ __device__ __forceinline__ int rp_output_of(const int* __restrict__ out_end, int
     return lo;
 }
 
-template <int R>
+template <int R, bool FLY>
 __global__ void __launch_bounds__(256)
 k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n, int nvec, int D,
             const int* __restrict__ out_end, double* __restrict__ Q,
-            const double* __restrict__ diag, const double* __restrict__ X2, int stagger) {
+            const double* __restrict__ diag, const double* __restrict__ X2, int stagger,
+            const int* __restrict__ base, const double* __restrict__ w4, int m,
+            const double* __restrict__ beta) {
     const int tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
     const int ic = i < n ? i : n - 1;
     double p[R];
+    if (FLY) {
+        RpRow rw;
+        rw.start(base[ic], m, w4 + (size_t)4 * ic);
 #pragma unroll
-    for (int j = 0; j < R; ++j) p[j] = F[(size_t)j * n + ic];
+        for (int j = 0; j < R; ++j) p[j] = rw.next(beta[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) p[j] = F[(size_t)j * n + ic];
+    }
     const double dg = diag != nullptr ? diag[ic] : 0.0;
     const int wf = blockIdx.x * 256 + (tid & ~63);
     const int wl = wf + 63 < n ? wf + 63 : n - 1;

@@ -103,6 +103,10 @@ struct RlKnobs {
     bool no_w_poly = false;      // RUNLMC_NO_W_POLY: the W product reads the expanded grid vector
     bool no_rp = false;          // RUNLMC_NO_RP: no row-polynomial form of large solver rounds (rl_rowpoly.h)
     int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
+    int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
+                                 // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
+                                 // expansion 257 -> 236 us at 129 vectors, 61 -> 42 at 17; projection level at rank
+                                 // 24 (339 vs 347, 95 vs 92), behind at rank 36 (697 vs 610)
     int w_poly_rmax = 32;        // RUNLMC_W_POLY_RMAX: largest rank whose expansion the W kernel takes over
                                  // (36 measured: 791 us against 186 + 473 for expansion + staged W per C5 round)
     bool no_sort = false;        // RUNLMC_NO_SORT: caller's data order inside the SKI handle
@@ -139,6 +143,7 @@ static RlKnobs read_knobs() {
     k.no_w_poly = flag("RUNLMC_NO_W_POLY");
     k.no_rp = flag("RUNLMC_NO_RP");
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
+    k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
     k.no_sort = flag("RUNLMC_NO_SORT");
     k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
@@ -2554,6 +2559,8 @@ struct rl_ski {
     int rp_R = 0;                   // rank F was built for (0: none)
     double* rp_Fc = nullptr;        // the same in the CALLER's row order (rl_ski_mvm: no row permutations)
     int rp_Fc_R = 0;
+    int* rp_base_c = nullptr;       // interpolation entries in the caller's row order (FLY kernels)
+    double* rp_w4_c = nullptr;
     int *rp_runs = nullptr, *rp_run_ptr = nullptr, *rp_out_end = nullptr;
     int rp_nruns = 0;
     double* rp_part = nullptr;
@@ -2819,7 +2826,8 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
-                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part};
+                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part,
+                    s->rp_base_c, s->rp_w4_c};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -3042,6 +3050,9 @@ static bool rp_ok(const rl_ski* s, int nvec) {
 static int rp_prepare(rl_ski* s, int nvec) {
     rl_gridop* g = s->g;
     const int R = g->lr_r, n = s->n, D = g->D, m = g->m;
+    if (s->rp_R != R && (s->kn.rp_fly & 2)) {
+        s->rp_R = R;                 // (no table: both kernels compute F from the entries)
+    }
     if (s->rp_R != R) {
         if (s->rp_F) RL_HIP(hipFree(s->rp_F));
         s->rp_F = nullptr;
@@ -3092,42 +3103,52 @@ static int rp_prepare(rl_ski* s, int nvec) {
     return RL_OK;
 }
 static bool rp_ready(const rl_ski* s, int nvec) {
-    return s->rp_F != nullptr && s->rp_R == s->g->lr_r && s->rp_runs != nullptr &&
+    return (s->rp_F != nullptr || (s->kn.rp_fly & 2)) && s->rp_R == s->g->lr_r && s->rp_runs != nullptr &&
            s->rp_part_cap >= (size_t)s->rp_nruns * nvec * s->rp_R &&
            s->g->lr_zhat_cap >= (size_t)nvec * s->g->D * RL_LR_RMAX;
 }
-template <int R>
-static void rp_launch(rl_ski* s, const double* F, const double* Xp, double* Yp, int nvec,
-                      const double* diag, hipStream_t st, int* bump) {
+template <int R, bool FLYP, bool FLYE>
+static void rp_launch(rl_ski* s, const double* F, const int* base, const double* w4,
+                      const double* Xp, double* Yp, int nvec, const double* diag, hipStream_t st,
+                      int* bump) {
     rl_gridop* g = s->g;
     constexpr int NT = (R + 15) / 16;
     const size_t lds = ((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
-    RL_LAUNCH((k_rp_project<R>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds, st,
-              Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump);
+    RL_LAUNCH((k_rp_project<R, FLYP>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds,
+              st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
+              (const double*)g->lr_beta);
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
               (const double*)g->lr_B, (const double*)g->lr_nu, g->lr_zhat,
               (const int*)s->rp_run_ptr);
-    RL_LAUNCH((k_rp_expand<R>), dim3((s->n + 255) / 256), dim3(256), 0, st,
+    RL_LAUNCH((k_rp_expand<R, FLYE>), dim3((s->n + 255) / 256), dim3(256), 0, st,
               (const double*)g->lr_zhat, F, s->n, nvec, g->D,
-              (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger);
+              (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
+              (const double*)g->lr_beta);
 }
-static int ski_rp_mvm(rl_ski* s, const double* F, const double* Xp, double* Yp, int nvec,
+// caller_order: the batch is in the caller's row order (F / entries permuted accordingly)
+static int ski_rp_mvm(rl_ski* s, bool caller_order, const double* Xp, double* Yp, int nvec,
                       const double* diag, hipStream_t st, int* bump) {
     trace_once("K~ product: row-polynomial form (k_rp_project / k_lr_mix / k_rp_expand)");
+    const bool flyp = (s->kn.rp_fly & 2) != 0, flye = (s->kn.rp_fly & 1) != 0;
+    const double* F = caller_order ? s->rp_Fc : s->rp_F;
+    const int* base = caller_order ? s->rp_base_c : s->W4_base;
+    const double* w4 = caller_order ? s->rp_w4_c : s->W4_w;
+#define RL_RP_CASE(R_)                                                                         \
+    case R_:                                                                                    \
+        if (flyp) rp_launch<R_, true, true>(s, F, base, w4, Xp, Yp, nvec, diag, st, bump);     \
+        else if (flye) rp_launch<R_, false, true>(s, F, base, w4, Xp, Yp, nvec, diag, st, bump); \
+        else rp_launch<R_, false, false>(s, F, base, w4, Xp, Yp, nvec, diag, st, bump);         \
+        break
     switch (s->g->lr_r) {
-        case 24: rp_launch<24>(s, F, Xp, Yp, nvec, diag, st, bump); break;
-        case 32: rp_launch<32>(s, F, Xp, Yp, nvec, diag, st, bump); break;
-        case 36: rp_launch<36>(s, F, Xp, Yp, nvec, diag, st, bump); break;
-        case 40: rp_launch<40>(s, F, Xp, Yp, nvec, diag, st, bump); break;
-        case 48: rp_launch<48>(s, F, Xp, Yp, nvec, diag, st, bump); break;
+        RL_RP_CASE(24); RL_RP_CASE(32); RL_RP_CASE(36); RL_RP_CASE(40); RL_RP_CASE(48);
         default: return fail(RL_EINVAL, "row-polynomial form: bad basis size");
     }
+#undef RL_RP_CASE
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
-
 // Yp = K~ Xp, both in internal row order (what the solver iterates on)
 // (noise = false: Yp = W K_UU W^T Xp only -- the caller adds eps (.) Xp itself)
 static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStream_t st,
@@ -3143,7 +3164,7 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
     if (rp_ok(s, nvec)) {
         if (!rp_ready(s, nvec) && !stream_capturing(st)) RL_TRY(rp_prepare(s, nvec));
         if (rp_ready(s, nvec)) {
-            return ski_rp_mvm(s, s->rp_F, Xp, Yp, nvec, diag, st, bump);
+            return ski_rp_mvm(s, false, Xp, Yp, nvec, diag, st, bump);
         }
     }
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
@@ -3249,7 +3270,18 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
         RL_TRY(lr_prepare(s->g, nvec));
         if (rp_ok(s, nvec)) {
             RL_TRY(rp_prepare(s, nvec));
-            if (s->rp_Fc_R != s->rp_R) {
+            if (s->kn.rp_fly && !s->rp_base_c) {
+                {
+                    RL_HIP(hipMalloc((void**)&s->rp_base_c, (size_t)s->n * sizeof(int)));
+                    RL_HIP(hipMalloc((void**)&s->rp_w4_c, (size_t)4 * s->n * sizeof(double)));
+                    RL_LAUNCH(k_rp_permute_entries, dim3((s->n + 255) / 256), dim3(256), 0,
+                              (hipStream_t) nullptr, (const int*)s->W4_base, (const double*)s->W4_w,
+                              (const int*)s->perm, s->n, s->rp_base_c, s->rp_w4_c);
+                    RL_HIP(hipGetLastError());
+                    RL_HIP(hipDeviceSynchronize());
+                }
+            }
+            if (!(s->kn.rp_fly & 2) && s->rp_Fc_R != s->rp_R) {
                 if (s->rp_Fc) RL_HIP(hipFree(s->rp_Fc));
                 s->rp_Fc = nullptr;
                 s->rp_Fc_R = 0;
@@ -3259,7 +3291,7 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
                 RL_HIP(hipDeviceSynchronize());
                 s->rp_Fc_R = s->rp_R;
             }
-            return ski_rp_mvm(s, s->rp_Fc, X, Y, nvec, s->has_noise ? s->noise_diag : nullptr, st,
+            return ski_rp_mvm(s, true, X, Y, nvec, s->has_noise ? s->noise_diag : nullptr, st,
                               nullptr);
         }
     }
