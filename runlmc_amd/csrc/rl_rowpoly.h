@@ -152,11 +152,19 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
     RL_SMEM(smem);
     double* Fs = reinterpret_cast<double*>(smem);      // [16 NT][LD]
     double* Ys = Fs + (size_t)16 * NT * LD;            // [2][VG][LD]
+    double* Yt = Ys + (size_t)2 * VG * LD;             // [TILE]: the lone last vector (below)
     const int tid = threadIdx.x;
     const int run = blockIdx.x, r0 = runs[3 * run], r1 = runs[3 * run + 1];
     const int vbase = blockIdx.y * (NG * VG);
     const int nvb = nvec - vbase < NG * VG ? nvec - vbase : NG * VG;
-    const int ng = (nvb + VG - 1) / VG;
+    // A probe batch is N + 1 vectors, N a multiple of 16: its last vector would cost a whole
+    // block of 16 (staging, a barrier, 8 NT matrix instructions) for one column.  A LONE last
+    // vector takes the vector pipe instead: thread (degree slot t & 63, row part t >> 6)
+    // keeps one running sum over the run, 32 multiply-adds per tile out of LDS.
+    const bool lone = nvb > 1 && (nvb % VG) == 1;
+    const int vlone = vbase + nvb - 1;
+    const int ng = (nvb - (lone ? 1 : 0) + VG - 1) / VG;
+    double tacc = 0.0, ytr = 0.0;
 #if !defined(RL_EMU)
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     rp_double4 C[NG][NT];
@@ -186,6 +194,10 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
     };
     for (int t0 = r0; t0 < r1; t0 += TILE) {
         request(t0, 0, 0);
+        if (lone && tid < TILE) {
+            const int row = t0 + tid < r1 ? t0 + tid : r1 - 1;
+            ytr = Y[(size_t)vlone * n + row];
+        }
         // the tile's F values: degree-major in memory, 128 consecutive rows per degree.
         // (All loads first, unconditional from clamped positions, masked afterwards: a
         // conditional load is a branch with a full memory wait behind it -- the first version
@@ -240,6 +252,7 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
                 Fs[deg * LD + rr] = 0.0;
             }
         }
+        if (lone && tid < TILE) Yt[tid] = t0 + tid < r1 ? ytr : 0.0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g < ng) {
@@ -252,6 +265,14 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
                 }
                 __syncthreads();
                 if (g + 1 < ng) request(t0, g + 1, 0);
+                if (g == 0 && lone) {
+                    const int deg = tid & 63, p0 = (tid >> 6) * (TILE / 4);
+                    if (deg < R) {
+                        const double* fr_ = Fs + deg * LD + p0;
+#pragma unroll 2
+                        for (int rr = 0; rr < TILE / 4; ++rr) tacc = fma(fr_[rr], Yt[p0 + rr], tacc);
+                    }
+                }
 #if !defined(RL_EMU)
                 const double* fa = Fs + li * LD + 32 * wave + lk;
                 const double* yv = yb + li * LD + 32 * wave + lk;
@@ -277,6 +298,16 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
             }
         }
         __syncthreads();        // every read of Fs and of both Y tiles is done before the next tile
+    }
+    // the lone last vector: its four row parts summed through LDS
+    if (lone) {
+        double* sl = Ys;                                // [4][64]
+        sl[tid] = tacc;
+        __syncthreads();
+        if (tid < R)
+            part[((size_t)run * nvec + vlone) * R + tid] =
+                (sl[tid] + sl[64 + tid]) + (sl[128 + tid] + sl[192 + tid]);
+        __syncthreads();
     }
     // results: the four waves' blocks summed through LDS (the Y tiles' space), then written
 #if !defined(RL_EMU)

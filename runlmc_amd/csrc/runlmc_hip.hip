@@ -3113,7 +3113,7 @@ static void rp_launch(rl_ski* s, const double* F, const int* base, const double*
                       int* bump) {
     rl_gridop* g = s->g;
     constexpr int NT = (R + 15) / 16;
-    const size_t lds = ((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD * sizeof(double);
+    const size_t lds = (((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
     RL_LAUNCH((k_rp_project<R, FLYP>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds,
               st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,

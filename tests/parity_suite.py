@@ -1693,14 +1693,19 @@ def check_row_polynomial_form():
                 X = solve_batch(op, torch.from_numpy(V[:3]).to(op.device), tol=1e-6,
                                 maxiter=6)[0].cpu().numpy()
                 Y2 = op.matmat_host(V[:5])           # (a smaller batch on the same handle)
-                return Y, X, Y2, op.grid.form()[0]
+                # (16 j + 1 vectors -- every probe batch: the lone last vector runs on the
+                # vector pipe; 97 = a full block of 80 and a second block of 17, 81 = 80 + 1)
+                Y3 = [op.matmat_host(np.tile(V, (4, 1))[:kk]) for kk in (17, 33, 81, 97)]
+                return Y, X, (Y2, Y3), op.grid.form()[0]
             Yr, Xr, Y2r, rank = run(False)
             Yu, Xu, Y2u, _ = run(True)
             assert rank == 24 if kern == 'rbf' else rank in (32, 36, 40, 48), rank
             scale = np.abs(Yu).max()
             assert np.abs(Yr - Yu).max() <= 1e-13 * scale, np.abs(Yr - Yu).max() / scale
             assert not np.array_equal(Yr, Yu)        # (another summation order: the form ran)
-            assert np.abs(Y2r - Y2u).max() <= 1e-13 * scale
+            assert np.abs(Y2r[0] - Y2u[0]).max() <= 1e-13 * scale
+            for a, b in zip(Y2r[1], Y2u[1]):
+                assert np.abs(a - b).max() <= 1e-13 * scale, len(a)
             assert np.abs(Xr - Xu).max() <= 1e-9 * np.abs(Xu).max()
             make = {'rbf': RBFSpec, 'periodic': StdPeriodicSpec}
             spec = KernelSpec(D, [make[d_[0]](*d_[1:]) for d_ in p.kern_desc], list(p.coreg_vecs),
