@@ -3038,6 +3038,9 @@ static bool rp_ok(const rl_ski* s, int nvec) {
     const rl_gridop* g = s->g;
     return s->extra.empty() && s->W4_base != nullptr && !s->h_base.empty() && !g->wide &&
            g->lr_try && !g->lr_dirty && g->lr_ok && s->ngrid == g->D * g->m &&
+           // (the batch gate of the structured forms also gates this one: rl_gridop_set_form_gate
+           // with a huge value puts the whole operator back on the transform kernels)
+           (size_t)nvec * g->D * g->m >= g->lr_min &&
            ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) &&
            // (F is read twice per product whatever the batch: at ranks above 32 a batch of a
            // few dozen vectors is level with the interpolation products or behind them --
