@@ -957,6 +957,10 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     if (g == nullptr) {
         // long systems (operator output in q): the remaining rows PF at a time,
         // every load of a group requested before the first is used
+        // (round 4, measured and dropped: two ADJACENT rows per thread and stream, twelve
+        // 16-byte loads per group instead of twenty-four 8-byte ones, block borders kept even:
+        // 1741 vs 1725-1860 us at 129 systems, 245 vs 244-252 at 17 -- inside the box-to-box
+        // range; the kernel moves its nine streams at 5.2-5.4 TB/s either way)
         for (; it0 + (PF - 1) * (int)blockDim.x < hi; it0 += PF * blockDim.x) {
             double tr2[PF], tr1[PF], tq[PF], tw1[PF], tw2[PF], tx[PF];
 #pragma unroll
