@@ -345,6 +345,182 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
 }
 
 // ---------------------------------------------------------------------------
+// k_rp_project1<R>: the same for ONE block of at most 16 vectors plus a lone last one -- the
+// 17 vectors of one rank's share of an 8-way probe split.  With a single block per tile the
+// big kernel's tile is all latency (loads of F and Y, a barrier, 16 matrix instructions):
+// here the NEXT tile's loads are in flight while the current tile is multiplied, and the
+// smaller footprint (one Y tile, 8 accumulator registers) admits three workgroups per CU.
+// C5, 17 vectors: 72 us against the general kernel's 84 (same box); with F computed from the
+// interpolation entries (FLY) 74 -- the table stays.
+//   grid (nruns)   block 256   LDS: F tile [16 NT][LD] + Y tile [16][LD] + lone [TILE]
+// ---------------------------------------------------------------------------
+template <int R, bool FLY>
+__global__ void __launch_bounds__(256)
+k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __restrict__ F,
+              const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump,
+              const int* __restrict__ base, const double* __restrict__ w4, int m,
+              const double* __restrict__ beta) {
+    static_assert(R <= 32, "small-batch projection: ranks up to 32");
+    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
+    constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG;
+    constexpr int NT = (R + 15) / 16, NF = R * TILE / 256, NU = VG * TILE / 256;
+    RL_SMEM(smem);
+    double* Fs = reinterpret_cast<double*>(smem);      // [16 NT][LD]
+    double* Ys = Fs + (size_t)16 * NT * LD;            // [VG][LD]
+    double* Yt = Ys + (size_t)VG * LD;                 // [TILE]
+    const int tid = threadIdx.x;
+    const int run = blockIdx.x, r0 = runs[3 * run], r1 = runs[3 * run + 1];
+    const bool lone = nvec > 1 && (nvec % VG) == 1;
+    const int vlone = nvec - 1;
+    double tacc = 0.0;
+#if !defined(RL_EMU)
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    rp_double4 C[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) C[t] = rp_double4{0.0, 0.0, 0.0, 0.0};
+#else
+    double C[2 * NT];
+    for (int t = 0; t < 2 * NT; ++t) C[t] = 0.0;
+#endif
+    // the padding degrees of the last degree tile never change
+    for (int idx = R * TILE + tid; idx < 16 * NT * TILE; idx += 256) {
+        const int deg = idx / TILE, rr = idx - deg * TILE;
+        Fs[deg * LD + rr] = 0.0;
+    }
+    double fr[FLY ? 4 : NF], yr[NU], ytr = 0.0;
+    int fb = 0;
+    auto load_tile = [&](int t0) {
+        if (FLY) {
+            // (the row's interpolation entry instead of its R values of F)
+            const int row = t0 + (tid & (TILE - 1)) < r1 ? t0 + (tid & (TILE - 1)) : r1 - 1;
+            fb = base[row];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fr[e] = w4[(size_t)4 * row + e];
+        } else {
+#pragma unroll
+            for (int u = 0; u < (FLY ? 4 : NF); ++u) {
+                const int idx = tid + 256 * u, deg = idx / TILE, rr = idx - deg * TILE;
+                int row = t0 + rr;
+                row = row < r1 ? row : r1 - 1;
+                fr[u] = F[(size_t)deg * n + row];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
+            const int v = jv < nvec ? jv : nvec - 1;
+            int row = t0 + rr;
+            row = row < r1 ? row : r1 - 1;
+            yr[u] = Y[(size_t)v * n + row];
+        }
+        if (tid < TILE) {
+            const int row = t0 + tid < r1 ? t0 + tid : r1 - 1;
+            ytr = Y[(size_t)vlone * n + row];
+        }
+    };
+    load_tile(r0);
+    const int nfull = lone ? nvec - 1 : nvec;           // vectors of the matrix-core block
+    for (int t0 = r0; t0 < r1; t0 += TILE) {
+        if (FLY) {
+            // waves 0-1: a row each, four recurrences; degrees j = 0 .. R - 1 in order
+            if (tid < TILE) {
+                RpRow rw;
+                rw.start(fb, m, fr);
+                const bool live = t0 + tid < r1;
+#pragma unroll 4
+                for (int j = 0; j < R; ++j) {
+                    const double f = rw.next(beta[j]);
+                    Fs[j * LD + tid] = live ? f : 0.0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < (FLY ? 4 : NF); ++u) {
+                const int idx = tid + 256 * u, deg = idx / TILE, rr = idx - deg * TILE;
+                Fs[deg * LD + rr] = t0 + rr < r1 ? fr[u] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
+            Ys[jv * LD + rr] = (jv < nfull && t0 + rr < r1) ? yr[u] : 0.0;
+        }
+        if (tid < TILE) Yt[tid] = (lone && t0 + tid < r1) ? ytr : 0.0;
+        __syncthreads();
+        load_tile(t0 + TILE < r1 ? t0 + TILE : t0);     // (the last request repeats: no branch)
+        if (lone) {
+            const int deg = tid & 63, p0 = (tid >> 6) * (TILE / 4);
+            if (deg < R) {
+                const double* fq = Fs + deg * LD + p0;
+#pragma unroll 2
+                for (int rr = 0; rr < TILE / 4; ++rr) tacc = fma(fq[rr], Yt[p0 + rr], tacc);
+            }
+        }
+#if !defined(RL_EMU)
+        {
+            const double* fa = Fs + li * LD + 32 * wave + lk;
+            const double* yv = Ys + li * LD + 32 * wave + lk;
+#pragma unroll
+            for (int s = 0; s < TILE / 16; ++s) {
+                const double b = yv[4 * s];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[(size_t)16 * t * LD + 4 * s], b,
+                                                                C[t], 0, 0, 0);
+            }
+        }
+#else
+        for (int t = 0; t < 2 * NT; ++t) {
+            const int e = tid + 256 * t;
+            if (e < 16 * NT * 16) {
+                const int deg = e / 16, jv = e - deg * 16;
+                double sum = C[t];
+                for (int rr = 0; rr < TILE; ++rr) sum = fma(Fs[deg * LD + rr], Ys[jv * LD + rr], sum);
+                C[t] = sum;
+            }
+        }
+#endif
+        __syncthreads();
+    }
+    if (lone) {
+        double* sl = Ys;
+        sl[tid] = tacc;
+        __syncthreads();
+        if (tid < R)
+            part[((size_t)run * nvec + vlone) * R + tid] =
+                (sl[tid] + sl[64 + tid]) + (sl[128 + tid] + sl[192 + tid]);
+        __syncthreads();
+    }
+#if !defined(RL_EMU)
+    {
+        double* scr = Fs;                                // [4 waves][16 NT][16]: 16 KB at NT = 2
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                scr[((size_t)wave * 16 * NT + 16 * t + RL_RP_DROW(lane, r)) * 16 + li] = C[t][r];
+        __syncthreads();
+        for (int e = tid; e < 16 * NT * 16; e += 256) {
+            const int deg = e / 16, jv = e - deg * 16;
+            if (deg < R && jv < nfull) {
+                const double s01 = scr[e] + scr[(size_t)16 * NT * 16 + e];
+                const double s23 = scr[(size_t)2 * 16 * NT * 16 + e] + scr[(size_t)3 * 16 * NT * 16 + e];
+                part[((size_t)run * nvec + jv) * R + deg] = s01 + s23;
+            }
+        }
+    }
+#else
+    for (int t = 0; t < 2 * NT; ++t) {
+        const int e = tid + 256 * t;
+        if (e < 16 * NT * 16) {
+            const int deg = e / 16, jv = e - deg * 16;
+            if (deg < R && jv < nfull) part[((size_t)run * nvec + jv) * R + deg] = C[t];
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // k_rp_expand<R>: Q[v][i] = sum_j F[j][i] Zhat[v D + d(i)][j]  (+ diag[i] X2[v][i]).
 //   grid (ceil(n / 256))   block 256
 // A thread owns a data row and keeps its R values of F in registers for all the vectors;

@@ -103,6 +103,7 @@ struct RlKnobs {
     bool no_w_poly = false;      // RUNLMC_NO_W_POLY: the W product reads the expanded grid vector
     bool no_rp = false;          // RUNLMC_NO_RP: no row-polynomial form of large solver rounds (rl_rowpoly.h)
     int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
+    bool no_rp_small = false;    // RUNLMC_NO_RP_SMALL: batches of <= 17 vectors through the general k_rp_project
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
                                  // expansion 257 -> 236 us at 129 vectors, 61 -> 42 at 17; projection level at rank
@@ -144,6 +145,7 @@ static RlKnobs read_knobs() {
     k.no_rp = flag("RUNLMC_NO_RP");
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
+    k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
     k.no_sort = flag("RUNLMC_NO_SORT");
     k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
@@ -3118,9 +3120,22 @@ static void rp_launch(rl_ski* s, const double* F, const int* base, const double*
     constexpr int NT = (R + 15) / 16;
     const size_t lds = (((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
+    if constexpr (R <= 32 && !FLYP) {
+        // at most one block of 16 vectors and a lone last one (a rank's share of an 8-way probe
+        // split): the small-batch kernel, next tile's loads in flight during the current one
+        if (nvec <= RL_RP_VG + 1 && (nvec <= RL_RP_VG || nvec % RL_RP_VG == 1) && !s->kn.no_rp_small) {
+            const size_t lds1 = (((size_t)16 * NT + RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
+            // (F from the table: computed on the fly here it measured 74 against 72 us)
+            RL_LAUNCH((k_rp_project1<R, false>), dim3(s->rp_nruns), dim3(256), lds1, st, Xp, s->n,
+                      nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
+                      (const double*)g->lr_beta);
+            goto projected;
+        }
+    }
     RL_LAUNCH((k_rp_project<R, FLYP>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds,
               st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
               (const double*)g->lr_beta);
+projected:
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
               (const double*)g->lr_B, (const double*)g->lr_nu, g->lr_zhat,
