@@ -192,8 +192,9 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
             yr[slot][u] = Y[(size_t)v * n + row];
         }
     };
+    request(r0, 0, 0);
     for (int t0 = r0; t0 < r1; t0 += TILE) {
-        request(t0, 0, 0);
+        // (block 0 of this tile was requested behind the previous tile's last barrier)
         if (lone && tid < TILE) {
             const int row = t0 + tid < r1 ? t0 + tid : r1 - 1;
             ytr = Y[(size_t)vlone * n + row];
@@ -265,6 +266,7 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
                 }
                 __syncthreads();
                 if (g + 1 < ng) request(t0, g + 1, 0);
+                else if (t0 + TILE < r1) request(t0 + TILE, 0, 0);    // next tile's first block
                 if (g == 0 && lone) {
                     const int deg = tid & 63, p0 = (tid >> 6) * (TILE / 4);
                     if (deg < R) {
