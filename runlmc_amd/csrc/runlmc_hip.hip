@@ -3641,7 +3641,10 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
     const double rtol = rule_only ? -1.0 : (tol < 1e-10 ? tol : 1e-10);
     const int rows_per_blk = 1024;       // (512 / 320 / 256 measured slower at C2)
     int nblk = (n + rows_per_blk - 1) / rows_per_blk;
-    int max_blk = 64;       // <= RL_SOLVER_THREADS: the partial sums are read one per thread
+    // <= RL_SOLVER_THREADS: the partial sums are read one per thread.  (64 until round 4; at C5
+    // 120 blocks per system measured 0.460-0.467 against 0.489 ms per 17-system round and
+    // 2.99-3.02 against 3.04-3.06 per 129-system round: 17 x 64 workgroups are 4.25 per CU)
+    int max_blk = 120;
     if (s->kn.solver_maxblk > 0) max_blk = std::max(1, std::min(s->kn.solver_maxblk, RL_SOLVER_THREADS));
     nblk = std::max(1, std::min(nblk, max_blk));
     // small single-term MINRES solves of a smooth kernel: polynomial rounds, whose
