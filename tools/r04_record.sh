@@ -1,13 +1,14 @@
 #!/bin/bash
 # GPU box: the round's record run -> gpurun_out/r04/ (what is kept is copied to profiles/r04/)
 #   tools/r04_record.sh [quick]
+mode=$1      # (kept apart: `set --` below reuses the positional parameters)
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/r04; mkdir -p $out
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 SQ3="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 cd /tmp && export TMPDIR=/tmp
-if [ "$1" != "quick" ]; then
+if [ "$mode" != "quick" ]; then
   (cd $root && timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -5) > $out/gputest.txt
   cat $out/gputest.txt
 fi
@@ -74,7 +75,7 @@ python3 $root/tools/families.py c2 2>/dev/null > $out/families_c2.txt
 python3 $root/tools/families.py c2 1024 2>/dev/null > $out/families_c2_1024.txt
 python3 $root/tools/setup_time.py 2>/dev/null > $out/setup_time.txt; cat $out/setup_time.txt
 timeout 900 python3 $root/tools/time_to_tolerance.py c5 rbf 12000 0 2>/dev/null > $out/time_to_tolerance_c5.txt; cat $out/time_to_tolerance_c5.txt
-if [ "$1" != "quick" ]; then
+if [ "$mode" != "quick" ]; then
   python3 $root/tools/sweep.py rbf 2>/dev/null > $out/sweep_dqm_rbf.txt
   python3 $root/tools/sweep.py matern 2>/dev/null > $out/sweep_dqm_matern.txt
   tail -9 $out/sweep_dqm_matern.txt
