@@ -88,6 +88,80 @@ def test_two_rank_probe_sharding():
     assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
 
 
+def _grads_structured(world_group=None):
+    """The same on a synthetic model whose operator runs in the STRUCTURED forms (polynomial
+    form verified at rank 24, solver rounds in the row-polynomial form F M F^T: forced onto
+    this small system by the batch gate and RUNLMC_STAGED_WT)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from runlmc_amd.util import synth
+    from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
+    from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+    from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
+    p = synth.make_problem(3, 2, 1, 700, eps=1.0)
+    p.noise = p.noise + 0.5
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    assert K.device_operator().grid.top_forms() == ([1, 1], True)
+    rs = np.random.RandomState(6).randint(0, 2, (5, p.n)) * 2 - 1
+    svc = StochasticDerivService(None, None, len(rs), 1e-6, group=world_group)
+    lik = ApproxLMCLikelihood(fk, K, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.Ys, svc, probes=rs)
+    flat = np.concatenate([np.ravel(g) for g in lik.coreg_vec_gradients()] +
+                          [np.ravel(g) for g in lik.coreg_diags_gradients()] +
+                          [np.ravel(g) for g in lik.kernel_gradients()] +
+                          [lik.noise_gradient()])
+    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy()
+
+
+_STRUCTURED_ENV = {'RUNLMC_STAGED_WT': '1', 'RUNLMC_NO_FUSE_W': '1', 'RUNLMC_NO_FUSE_WT': '1',
+                   'RUNLMC_LR_MIN': '0', 'RUNLMC_NO_POLY_ROUND': '1'}
+
+
+def _worker_structured(rank, world, port, q):
+    os.environ.update(_STRUCTURED_ENV)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.EMU_LIB)
+    flat, nloc, alpha = _grads_structured()
+    q.put((rank, flat, nloc, alpha))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_probe_sharding_structured_forms(monkeypatch):
+    """Two ranks with 3 and 2 of 5 probes (batches of 5 and 3 right-hand sides, both through
+    the small-batch projection of the row-polynomial rounds): alpha and the assembled
+    gradient are the SAME BITS on both ranks (rank 0's alpha broadcast, one all-reduce) and
+    agree with the one-rank step to the solver's tolerance."""
+    for k, v in _STRUCTURED_ENV.items():
+        monkeypatch.setenv(k, v)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.build_emu())
+    try:
+        ref, nall, alpha_ref = _grads_structured()
+    finally:
+        _lib.use_library(None)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_structured, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert got[0][2] + got[1][2] == nall and got[0][2] == 3
+    assert np.array_equal(got[0][3], got[1][3])
+    assert np.array_equal(got[0][1], got[1][1])
+    assert np.abs(got[0][3] - alpha_ref).max() < 1e-6 * np.abs(alpha_ref).max()
+    assert np.abs(got[0][1] - ref).max() < 1e-4 * np.abs(ref).max()
+
+
 def _block_solve():
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
