@@ -114,7 +114,7 @@ k_rp_permute_entries(const int* __restrict__ base, const double* __restrict__ w4
 
 // ---------------------------------------------------------------------------
 // k_rp_project<R>: part[run][v][j] = sum_{i in run} F[j][i] Y[v][i].
-//   grid (nruns, ceil(nvec / (RL_RP_NG(R) * RL_RP_VG)))   block 256 (four waves)
+//   grid (8 ceil(nruns / 8) x ceil(nvec / (RL_RP_NG(R) * RL_RP_VG)))   block 256 (four waves)
 //   runs: [nruns][3] = first row, end row, output -- contiguous rows of ONE output
 //   LDS: F tile [32][LD] + two Y tiles [16][LD]   (2 workgroups per CU)
 // A run is walked in tiles of 128 rows.  Per tile the F values go to LDS once and serve all
@@ -141,12 +141,12 @@ typedef double rp_double4 __attribute__((ext_vector_type(4)));
 template <int R, bool FLY>
 __global__ void __launch_bounds__(256) RL_RP_PROJECT_ATTR
 k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __restrict__ F,
-             const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump,
-             const int* __restrict__ base, const double* __restrict__ w4, int m,
-             const double* __restrict__ beta) {
+             const int* __restrict__ runs, int nruns, double* __restrict__ part,
+             int* __restrict__ bump, const int* __restrict__ base, const double* __restrict__ w4,
+             int m, const double* __restrict__ beta) {
     static_assert(R <= RL_RP_RMAX, "rank");
     // (the solver's round counter: bumped by the first kernel of a round)
-    if (bump != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;
+    if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
     constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG, NG = RL_RP_NG(R);
     constexpr int NT = (R + 15) / 16;                 // degree tiles of 16
     RL_SMEM(smem);
@@ -154,8 +154,16 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
     double* Ys = Fs + (size_t)16 * NT * LD;            // [2][VG][LD]
     double* Yt = Ys + (size_t)2 * VG * LD;             // [TILE]: the lone last vector (below)
     const int tid = threadIdx.x;
-    const int run = blockIdx.x, r0 = runs[3 * run], r1 = runs[3 * run + 1];
-    const int vbase = blockIdx.y * (NG * VG);
+    // 1-D launch of 8 ceil(nruns / 8) x nyb workgroups.  The vector blocks of a run read the
+    // SAME tiles of F: workgroups b and b + 8 -- the same XCD under the dispatcher's round
+    // robin, started together -- take the same run and neighbouring vector blocks, so the
+    // second read of a tile finds it in that XCD's L2.  (Only speed depends on the placement.)
+    const int nyb = (nvec + NG * VG - 1) / (NG * VG);
+    const int bb = blockIdx.x, grp = bb / (8 * nyb), rem = bb - grp * (8 * nyb);
+    const int run = grp * 8 + (rem & 7), yb = rem >> 3;
+    if (run >= nruns) return;
+    const int r0 = runs[3 * run], r1 = runs[3 * run + 1];
+    const int vbase = yb * (NG * VG);
     const int nvb = nvec - vbase < NG * VG ? nvec - vbase : NG * VG;
     // A probe batch is N + 1 vectors, N a multiple of 16: its last vector would cost a whole
     // block of 16 (staging, a barrier, 8 NT matrix instructions) for one column.  A LONE last

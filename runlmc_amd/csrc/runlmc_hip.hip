@@ -3132,9 +3132,9 @@ static void rp_launch(rl_ski* s, const double* F, const int* base, const double*
             goto projected;
         }
     }
-    RL_LAUNCH((k_rp_project<R, FLYP>), dim3(s->rp_nruns, (nvec + vblk - 1) / vblk), dim3(256), lds,
-              st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
-              (const double*)g->lr_beta);
+    RL_LAUNCH((k_rp_project<R, FLYP>), dim3(8 * ((s->rp_nruns + 7) / 8) * ((nvec + vblk - 1) / vblk)),
+              dim3(256), lds, st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_nruns, s->rp_part,
+              bump, base, w4, g->m, (const double*)g->lr_beta);
 projected:
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
