@@ -370,7 +370,7 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
               const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump,
               const int* __restrict__ base, const double* __restrict__ w4, int m,
               const double* __restrict__ beta) {
-    static_assert(R <= 32, "small-batch projection: ranks up to 32");
+    static_assert(R <= RL_RP_RMAX, "rank");
     if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
     constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG;
     constexpr int NT = (R + 15) / 16, NF = R * TILE / 256, NU = VG * TILE / 256;

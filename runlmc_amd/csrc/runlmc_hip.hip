@@ -3047,7 +3047,9 @@ static bool rp_ok(const rl_ski* s, int nvec) {
            // (F is read twice per product whatever the batch: at ranks above 32 a batch of a
            // few dozen vectors is level with the interpolation products or behind them --
            // C5, 17 vectors, rank 36: 0.615 against 0.587 ms per round; rank 24: 0.49 against 0.53)
-           (g->lr_r <= 32 || nvec >= 48 || s->kn.staged_wt) &&
+           // (... except batches of at most 17, which take the small-batch projection:
+           // rank 36, 17 vectors: see profiles/r04/rp_ab.txt)
+           (g->lr_r <= 32 || nvec >= 48 || nvec <= RL_RP_VG + 1 || s->kn.staged_wt) &&
            !s->kn.no_staged_wt && !s->kn.no_rp;
 }
 // F for the operator's current rank, the runs of rows k_rp_project walks, the partial sums
@@ -3120,7 +3122,7 @@ static void rp_launch(rl_ski* s, const double* F, const int* base, const double*
     constexpr int NT = (R + 15) / 16;
     const size_t lds = (((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
-    if constexpr (R <= 32 && !FLYP) {
+    if constexpr (!FLYP) {
         // at most one block of 16 vectors and a lone last one (a rank's share of an 8-way probe
         // split): the small-batch kernel, next tile's loads in flight during the current one
         if (nvec <= RL_RP_VG + 1 && (nvec <= RL_RP_VG || nvec % RL_RP_VG == 1) && !s->kn.no_rp_small) {
