@@ -1714,6 +1714,29 @@ def check_row_polynomial_form():
             oop = olik.LMCOperatorOracle(spec, p.grid_dists, W, WT, lens)
             for v in (0, k - 1):
                 _close(Yr[v], oop.matvec(V[v]), 1e-11)
+            if kern == 'rbf' and D == 3:
+                # a parameter update that changes the RANK on the same SKI handle (F = W Phi
+                # is rebuilt, in both row orders): short length scales -> rank 36 / 40
+                os.environ.pop('RUNLMC_NO_RP', None)
+                K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (W, WT)}, lens)
+                op = K.device_operator()
+                op.grid.set_form_gate(0)
+                first = op.matmat_host(V[:17])
+                assert op.grid.form()[0] == 24
+                from runlmc_amd.kern.stationary import RBF
+                fk2 = FunctionalKernel(D=D, lmc_kernels=[RBF(55.0), RBF(70.0)], lmc_ranks=[1, 1])
+                fk2.coreg_vecs, fk2.coreg_diags, fk2.noise = fk.coreg_vecs, fk.coreg_diags, fk.noise
+                fk2.set_input_dim(1)
+                gks[ad].update(fk2, p.grid_dists)
+                op.grid.set_form_gate(0)
+                second = op.matmat_host(V[:17])
+                assert op.grid.form()[0] in (36, 40, 48), op.grid.form()
+                spec2 = KernelSpec(D, [RBFSpec(55.0), RBFSpec(70.0)], list(p.coreg_vecs),
+                                   list(p.coreg_diags), p.noise)
+                spec2.set_input_dim(1)
+                oop2 = olik.LMCOperatorOracle(spec2, p.grid_dists, W, WT, lens)
+                _close(second[16], oop2.matvec(V[16]), 1e-11)
+                _close(first[16], oop.matvec(V[16]), 1e-11)
     finally:
         for k_, v in saved.items():
             os.environ.pop(k_, None)
