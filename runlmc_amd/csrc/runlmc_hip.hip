@@ -103,6 +103,7 @@ struct RlKnobs {
     bool no_w_poly = false;      // RUNLMC_NO_W_POLY: the W product reads the expanded grid vector
     bool no_rp = false;          // RUNLMC_NO_RP: no row-polynomial form of large solver rounds (rl_rowpoly.h)
     int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
+    int rp_runlen = 0;           // RUNLMC_RP_RUNLEN: rows per run of k_rp_project (default: about n / 1024)
     bool no_rp_small = false;    // RUNLMC_NO_RP_SMALL: batches of <= 17 vectors through the general k_rp_project
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
@@ -146,6 +147,7 @@ static RlKnobs read_knobs() {
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
+    k.rp_runlen = (int)num("RUNLMC_RP_RUNLEN", 0);
     k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
     k.no_sort = flag("RUNLMC_NO_SORT");
     k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
@@ -3073,11 +3075,13 @@ static int rp_prepare(rl_ski* s, int nvec) {
         s->rp_R = R;
     }
     if (!s->rp_runs) {
-        // rows of an output are contiguous in the sorted order; runs of whole tiles, about a
-        // thousand of them (two rounds of resident workgroups with room for imbalance)
+        // rows of an output are contiguous in the sorted order; runs of whole tiles, about five
+        // hundred of them (C5, rows per run 512 ... 2048: the projection 344-371 us at 129
+        // vectors, 74-76 at 17; k_lr_mix, which sums the runs, 32 -> 18 us: the longest wins)
         std::vector<int> out_end(D, 0), run_ptr(D + 1, 0), runs;
-        int len = ((n + 1023) / 1024 + RL_RP_TILE - 1) / RL_RP_TILE * RL_RP_TILE;
+        int len = ((n + 511) / 512 + RL_RP_TILE - 1) / RL_RP_TILE * RL_RP_TILE;
         len = std::max(RL_RP_TILE, std::min(len, 64 * RL_RP_TILE));
+        if (s->kn.rp_runlen > 0) len = (s->kn.rp_runlen + RL_RP_TILE - 1) / RL_RP_TILE * RL_RP_TILE;
         int i = 0;
         for (int d = 0; d < D; ++d) {
             const int start = i;
