@@ -487,7 +487,7 @@ def test_c5_family_gradient_at_fixed_iterations(native, kern):
 @pytest.mark.parametrize('kern', ['rbf', 'periodic'])
 def test_c5_row_polynomial_rounds(native, kern, monkeypatch):
     """The row-polynomial form of the C5 operator (rl_rowpoly.h: K~ = F M F^T + eps, F = W Phi;
-    k_rp_project on the fp64 matrix cores over 980 runs of 1024 rows and two blocks of
+    k_rp_project on the fp64 matrix cores over 490 runs of 2048 rows and two blocks of
     vectors, k_rp_expand) -- what the solver's rounds run at this size: the 129-vector
     product against the oracle's operator on three vectors (1e-11) and against the same
     handle's interpolation-product path (RUNLMC_NO_RP) on all of them (1e-12); MINRES
