@@ -26,7 +26,7 @@
 #include "rl_lowrank.h"
 
 #define RL_RP_TILE 128                   // data rows per LDS tile
-#define RL_RP_LD (RL_RP_TILE + 4)        // padded LDS row: (4 i + k) mod 32 banks, two-way at worst
+#define RL_RP_LD (RL_RP_TILE + 1)        // padded LDS row, ODD: the compiler reads the matrix-core operands with ds_read2_b64 (16-lane groups, 32 dword banks): lanes i = 0..15 land on banks 2 i (+1)
 #define RL_RP_VG 16                      // vectors per matrix-core block (the instruction's N)
 // vector blocks a workgroup walks per tile (accumulators: NG x degree tiles x 4 doubles per lane):
 // 5 (80 vectors: nine, for the 129 vectors of C5 in one block, spill 83 vector registers at rank 24)
