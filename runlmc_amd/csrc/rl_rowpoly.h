@@ -31,6 +31,8 @@
 // vector blocks a workgroup walks per tile (accumulators: NG x degree tiles x 4 doubles per lane):
 // 5 (80 vectors: nine, for the 129 vectors of C5 in one block, spill 83 vector registers at rank 24)
 #define RL_RP_NG(R) ((R) <= 32 ? 5 : 3)
+// (with the solver's update inside -- FB: a second operand, the Gram accumulators -- fewer)
+#define RL_RP_NG_FB(R) ((R) <= 32 ? 3 : 2)
 #define RL_RP_RMAX 48
 
 // ---------------------------------------------------------------------------
@@ -138,16 +140,42 @@ typedef double rp_double4 __attribute__((ext_vector_type(4)));
 #define RL_RP_PROJECT_ATTR
 #endif
 
-template <int R, bool FLY>
+// The solver's vector update inside the projection (FB; rl_solver.h, k_minres2_b): the batch is
+// MINRES's y' and the projection is wanted of  y_r = y' - coef[v] y_{r-1}.  The tile loader
+// forms y_r from the two operands, stores it over y' (every element of the batch is staged by
+// exactly one thread of one workgroup) and the block's squared norms come out of the matrix
+// cores as the diagonal of one more product of the staged block with itself:
+//   nrm[v][run] = sum_{i in run} y_r[v][i]^2   (deterministic: fixed order of rows and waves).
+// A frozen system has coef 0: its values are rewritten unchanged, its norm is not read.
+struct RpFuse {
+    const double* r2;       // y_{r-1}, [nvec][n]
+    const double* coef;     // [nvec]
+    double* nrm;            // [nvec][nruns]
+};
+// sum of v over the workgroup's 256 threads in a fixed order (LDS scratch of 256 doubles)
+__device__ __forceinline__ double rp_block_sum(double v, double* scr, int tid) {
+    scr[tid] = v;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (tid < h) scr[tid] += scr[tid + h];
+        __syncthreads();
+    }
+    const double r = scr[0];
+    __syncthreads();
+    return r;
+}
+
+template <int R, bool FLY, bool FB = false>
 __global__ void __launch_bounds__(256) RL_RP_PROJECT_ATTR
-k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __restrict__ F,
+k_rp_project(const double* Y, int n, int nvec, const double* __restrict__ F,
              const int* __restrict__ runs, int nruns, double* __restrict__ part,
              int* __restrict__ bump, const int* __restrict__ base, const double* __restrict__ w4,
-             int m, const double* __restrict__ beta) {
+             int m, const double* __restrict__ beta, RpFuse fz = RpFuse{nullptr, nullptr, nullptr}) {
     static_assert(R <= RL_RP_RMAX, "rank");
+    double* Yw = const_cast<double*>(Y);     // (FB only: y_r stored over y')
     // (the solver's round counter: bumped by the first kernel of a round)
     if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
-    constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG, NG = RL_RP_NG(R);
+    constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG, NG = FB ? RL_RP_NG_FB(R) : RL_RP_NG(R);
     constexpr int NT = (R + 15) / 16;                 // degree tiles of 16
     RL_SMEM(smem);
     double* Fs = reinterpret_cast<double*>(smem);      // [16 NT][LD]
@@ -172,32 +200,49 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
     const bool lone = nvb > 1 && (nvb % VG) == 1;
     const int vlone = vbase + nvb - 1;
     const int ng = (nvb - (lone ? 1 : 0) + VG - 1) / VG;
-    double tacc = 0.0, ytr = 0.0;
+    double tacc = 0.0, ytr = 0.0, ytr2 = 0.0, tn = 0.0;
 #if !defined(RL_EMU)
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     rp_double4 C[NG][NT];
+    rp_double4 G[FB ? NG : 1];                         // FB: Gram blocks of the staged vectors
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int t = 0; t < NT; ++t) C[g][t] = rp_double4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < (FB ? NG : 1); ++g) G[g] = rp_double4{0.0, 0.0, 0.0, 0.0};
+    // (vector of staging value u: (tid >> 7) + 2 u -- wave-uniform: coefficients by scalar loads)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 7);
 #else
     double C[NG][2 * NT];                              // entries tid, tid + 256 (, ...) of [16 NT][16]
-    for (int g = 0; g < NG; ++g)
+    double G[NG];                                      // FB: thread jv < 16 sums its vector's squares
+    for (int g = 0; g < NG; ++g) {
+        G[g] = 0.0;
         for (int t = 0; t < 2 * NT; ++t) C[g][t] = 0.0;
+    }
+    const int wv = tid >> 7;
 #endif
+    const double cfl = FB && lone ? fz.coef[vlone] : 0.0;
     // staging registers of one vector block: value idx = tid + 256 u -> vector idx / 128, row idx % 128
     // (one block ahead; two blocks ahead measured the same: 471 vs 457 us)
     constexpr int NU = VG * TILE / 256;
-    double yr[1][NU];
+    double yr[1][NU], yr2[1][FB ? NU : 1], cfr[FB ? NU : 1];
+    // (staging value u of a thread: vector wv + 2 u of the block -- uniform over the wave, so a
+    // vector's base address is a scalar -- and row tid % 128 of the tile for every u: ONE
+    // per-lane offset serves all the loads)
+    static_assert(TILE == 128, "staging index: idx = tid + 256 u -> vector idx / 128, row idx % 128");
     auto request = [&](int t0, int g, int slot) {
+        int row = t0 + (tid & (TILE - 1));
+        row = row < r1 ? row : r1 - 1;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
-            int v = vbase + g * VG + jv;
-            v = v < nvec ? v : nvec - 1;
-            int row = t0 + rr;
-            row = row < r1 ? row : r1 - 1;
-            yr[slot][u] = Y[(size_t)v * n + row];
+            int vu = vbase + g * VG + wv + 2 * u;
+            vu = vu < nvec ? vu : nvec - 1;
+            yr[slot][u] = (Y + (size_t)vu * n)[row];
+            if constexpr (FB) {
+                yr2[slot][u] = (fz.r2 + (size_t)vu * n)[row];
+                cfr[u] = fz.coef[vu];
+            }
         }
     };
     request(r0, 0, 0);
@@ -206,6 +251,7 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
         if (lone && tid < TILE) {
             const int row = t0 + tid < r1 ? t0 + tid : r1 - 1;
             ytr = Y[(size_t)vlone * n + row];
+            if constexpr (FB) ytr2 = fz.r2[(size_t)vlone * n + row];
         }
         // the tile's F values: degree-major in memory, 128 consecutive rows per degree.
         // (All loads first, unconditional from clamped positions, masked afterwards: a
@@ -261,16 +307,32 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
                 Fs[deg * LD + rr] = 0.0;
             }
         }
-        if (lone && tid < TILE) Yt[tid] = t0 + tid < r1 ? ytr : 0.0;
+        if (lone && tid < TILE) {
+            const bool live = t0 + tid < r1;
+            double yl = ytr;
+            if constexpr (FB) {
+                yl = ytr - cfl * ytr2;
+                if (live) {
+                    Yw[(size_t)vlone * n + t0 + tid] = yl;
+                    tn = fma(yl, yl, tn);
+                }
+            }
+            Yt[tid] = live ? yl : 0.0;
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g < ng) {
                 double* yb = Ys + (size_t)(g & 1) * VG * LD;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
+                    const int jv = wv + 2 * u, rr = tid & (TILE - 1);
                     const bool live = vbase + g * VG + jv < nvec && t0 + rr < r1;
-                    yb[jv * LD + rr] = live ? yr[0][u] : 0.0;
+                    double yv_ = yr[0][u];
+                    if constexpr (FB) {
+                        yv_ = yr[0][u] - cfr[u] * yr2[0][u];
+                        if (live) (Yw + (size_t)(vbase + g * VG + jv) * n)[t0 + rr] = yv_;
+                    }
+                    yb[jv * LD + rr] = live ? yv_ : 0.0;
                 }
                 __syncthreads();
                 if (g + 1 < ng) request(t0, g + 1, 0);
@@ -293,6 +355,8 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
                     for (int t = 0; t < NT; ++t)
                         C[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[(size_t)16 * t * LD + 4 * s],
                                                                        b, C[g][t], 0, 0, 0);
+                    // (the operand register of B is also that of A for the same (vector, row))
+                    if constexpr (FB) G[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, G[g], 0, 0, 0);
                 }
 #else
                 for (int t = 0; t < 2 * NT; ++t) {
@@ -303,6 +367,11 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
                         for (int rr = 0; rr < TILE; ++rr) sum = fma(Fs[deg * LD + rr], yb[jv * LD + rr], sum);
                         C[g][t] = sum;
                     }
+                }
+                if (FB && tid < VG) {
+                    double sum = G[g];
+                    for (int rr = 0; rr < TILE; ++rr) sum = fma(yb[tid * LD + rr], yb[tid * LD + rr], sum);
+                    G[g] = sum;
                 }
 #endif
             }
@@ -318,6 +387,34 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
             part[((size_t)run * nvec + vlone) * R + tid] =
                 (sl[tid] + sl[64 + tid]) + (sl[128 + tid] + sl[192 + tid]);
         __syncthreads();
+    }
+    if constexpr (FB) {
+        // squared norms: the lone vector's by a fixed-order sum over the workgroup, a block's
+        // from the diagonal of its Gram block (lane (i, k) holds entry (k + 4 reg, i): the
+        // diagonal of vector i sits in lane i + 16 (i % 4), register i / 4), the four waves'
+        // row parts summed through LDS
+        if (lone) {
+            const double t = rp_block_sum(tn, Ys, tid);
+            if (tid == 0) fz.nrm[(size_t)vlone * nruns + run] = t;
+        }
+#if !defined(RL_EMU)
+        double* gs = Ys;                                // [NG][4 waves][16]
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (g < ng && (li & 3) == lk) gs[(g * 4 + wave) * 16 + li] = G[g][li >> 2];
+        __syncthreads();
+        if (tid < 16 * NG) {
+            const int g = tid >> 4, jv = tid & 15, v = vbase + g * VG + jv;
+            if (g < ng && v < nvec)
+                fz.nrm[(size_t)v * nruns + run] = (gs[(g * 4 + 0) * 16 + jv] + gs[(g * 4 + 1) * 16 + jv]) +
+                                                  (gs[(g * 4 + 2) * 16 + jv] + gs[(g * 4 + 3) * 16 + jv]);
+        }
+        __syncthreads();
+#else
+        for (int g = 0; g < ng; ++g)
+            if (tid < VG && vbase + g * VG + tid < nvec)
+                fz.nrm[(size_t)(vbase + g * VG + tid) * nruns + run] = G[g];
+#endif
     }
     // results: the four waves' blocks summed through LDS (the Y tiles' space), then written
 #if !defined(RL_EMU)
@@ -364,13 +461,21 @@ k_rp_project(const double* __restrict__ Y, int n, int nvec, const double* __rest
 // interpolation entries (FLY) 74 -- the table stays.
 //   grid (nruns)   block 256   LDS: F tile [16 NT][LD] + Y tile [16][LD] + lone [TILE]
 // ---------------------------------------------------------------------------
-template <int R, bool FLY>
-__global__ void __launch_bounds__(256)
-k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __restrict__ F,
+#if !defined(RL_EMU)
+// (three workgroups per CU also with the solver's update inside, while the rank allows)
+#define RL_RP_PROJECT1_ATTR(R, FB) __attribute__((amdgpu_waves_per_eu(((FB) && (R) <= 24) ? 3 : 1)))
+#else
+#define RL_RP_PROJECT1_ATTR(R, FB)
+#endif
+template <int R, bool FLY, bool FB = false>
+__global__ void __launch_bounds__(256) RL_RP_PROJECT1_ATTR(R, FB)
+k_rp_project1(const double* Y, int n, int nvec, const double* __restrict__ F,
               const int* __restrict__ runs, double* __restrict__ part, int* __restrict__ bump,
               const int* __restrict__ base, const double* __restrict__ w4, int m,
-              const double* __restrict__ beta) {
+              const double* __restrict__ beta, RpFuse fz = RpFuse{nullptr, nullptr, nullptr}) {
     static_assert(R <= RL_RP_RMAX, "rank");
+    double* Yw = const_cast<double*>(Y);     // (FB: y_r stored over y', as in k_rp_project)
+    const int nruns = gridDim.x;
     if (bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
     constexpr int TILE = RL_RP_TILE, LD = RL_RP_LD, VG = RL_RP_VG;
     constexpr int NT = (R + 15) / 16, NF = R * TILE / 256, NU = VG * TILE / 256;
@@ -382,22 +487,35 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
     const int run = blockIdx.x, r0 = runs[3 * run], r1 = runs[3 * run + 1];
     const bool lone = nvec > 1 && (nvec % VG) == 1;
     const int vlone = nvec - 1;
-    double tacc = 0.0;
+    double tacc = 0.0, tn = 0.0;
 #if !defined(RL_EMU)
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     rp_double4 C[NT];
+    rp_double4 G = rp_double4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < NT; ++t) C[t] = rp_double4{0.0, 0.0, 0.0, 0.0};
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 7);
 #else
-    double C[2 * NT];
+    double C[2 * NT], G = 0.0;
     for (int t = 0; t < 2 * NT; ++t) C[t] = 0.0;
+    const int wv = tid >> 7;
 #endif
+    // (FB: the vectors' coefficients do not change over the run)
+    double cfr[FB ? VG * TILE / 256 : 1];
+    if constexpr (FB) {
+#pragma unroll
+        for (int u = 0; u < VG * TILE / 256; ++u) {
+            const int vu = wv + 2 * u;
+            cfr[u] = fz.coef[vu < nvec ? vu : nvec - 1];
+        }
+    }
+    const double cfl = FB && lone ? fz.coef[vlone] : 0.0;
     // the padding degrees of the last degree tile never change
     for (int idx = R * TILE + tid; idx < 16 * NT * TILE; idx += 256) {
         const int deg = idx / TILE, rr = idx - deg * TILE;
         Fs[deg * LD + rr] = 0.0;
     }
-    double fr[FLY ? 4 : NF], yr[NU], ytr = 0.0;
+    double fr[FLY ? 4 : NF], yr[NU], yr2[FB ? NU : 1], ytr = 0.0, ytr2 = 0.0;
     int fb = 0;
     auto load_tile = [&](int t0) {
         if (FLY) {
@@ -415,17 +533,19 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
                 fr[u] = F[(size_t)deg * n + row];
             }
         }
+        int yrow = t0 + (tid & (TILE - 1));
+        yrow = yrow < r1 ? yrow : r1 - 1;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
+            const int jv = wv + 2 * u;                      // (uniform: scalar base address)
             const int v = jv < nvec ? jv : nvec - 1;
-            int row = t0 + rr;
-            row = row < r1 ? row : r1 - 1;
-            yr[u] = Y[(size_t)v * n + row];
+            yr[u] = (Y + (size_t)v * n)[yrow];
+            if constexpr (FB) yr2[u] = (fz.r2 + (size_t)v * n)[yrow];
         }
         if (tid < TILE) {
             const int row = t0 + tid < r1 ? t0 + tid : r1 - 1;
             ytr = Y[(size_t)vlone * n + row];
+            if constexpr (FB) ytr2 = fz.r2[(size_t)vlone * n + row];
         }
     };
     load_tile(r0);
@@ -452,12 +572,32 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int idx = tid + 256 * u, jv = idx / TILE, rr = idx - jv * TILE;
-            Ys[jv * LD + rr] = (jv < nfull && t0 + rr < r1) ? yr[u] : 0.0;
+            const int jv = wv + 2 * u, rr = tid & (TILE - 1);
+            const bool live = jv < nfull && t0 + rr < r1;
+            double yv_ = yr[u];
+            if constexpr (FB) {
+                yv_ = yr[u] - cfr[u] * yr2[u];
+                if (live) (Yw + (size_t)jv * n)[t0 + rr] = yv_;
+            }
+            Ys[jv * LD + rr] = live ? yv_ : 0.0;
         }
-        if (tid < TILE) Yt[tid] = (lone && t0 + tid < r1) ? ytr : 0.0;
+        if (tid < TILE) {
+            const bool live = lone && t0 + tid < r1;
+            double yl = ytr;
+            if constexpr (FB) {
+                yl = ytr - cfl * ytr2;
+                if (live) {
+                    Yw[(size_t)vlone * n + t0 + tid] = yl;
+                    tn = fma(yl, yl, tn);
+                }
+            }
+            Yt[tid] = live ? yl : 0.0;
+        }
         __syncthreads();
-        load_tile(t0 + TILE < r1 ? t0 + TILE : t0);     // (the last request repeats: no branch)
+        // (FB: the last tile's request must not repeat -- its rows have just been rewritten;
+        // a request past the run would read another workgroup's rows: harmless, never used --
+        // but stay inside the run: repeat the tile only when FB is off)
+        if (!FB || t0 + TILE < r1) load_tile(t0 + TILE < r1 ? t0 + TILE : t0);
         if (lone) {
             const int deg = tid & 63, p0 = (tid >> 6) * (TILE / 4);
             if (deg < R) {
@@ -477,6 +617,7 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
                 for (int t = 0; t < NT; ++t)
                     C[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[(size_t)16 * t * LD + 4 * s], b,
                                                                 C[t], 0, 0, 0);
+                if constexpr (FB) G = __builtin_amdgcn_mfma_f64_16x16x4f64(b, b, G, 0, 0, 0);
             }
         }
 #else
@@ -489,6 +630,11 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
                 C[t] = sum;
             }
         }
+        if (FB && tid < VG) {
+            double sum = G;
+            for (int rr = 0; rr < TILE; ++rr) sum = fma(Ys[tid * LD + rr], Ys[tid * LD + rr], sum);
+            G = sum;
+        }
 #endif
         __syncthreads();
     }
@@ -500,6 +646,22 @@ k_rp_project1(const double* __restrict__ Y, int n, int nvec, const double* __res
             part[((size_t)run * nvec + vlone) * R + tid] =
                 (sl[tid] + sl[64 + tid]) + (sl[128 + tid] + sl[192 + tid]);
         __syncthreads();
+    }
+    if constexpr (FB) {
+        if (lone) {
+            const double t = rp_block_sum(tn, Ys, tid);
+            if (tid == 0) fz.nrm[(size_t)vlone * nruns + run] = t;
+        }
+#if !defined(RL_EMU)
+        double* gs = Ys;                                 // [4 waves][16]
+        if ((li & 3) == lk) gs[wave * 16 + li] = G[li >> 2];
+        __syncthreads();
+        if (tid < nfull)
+            fz.nrm[(size_t)tid * nruns + run] = (gs[tid] + gs[16 + tid]) + (gs[32 + tid] + gs[48 + tid]);
+        __syncthreads();
+#else
+        if (tid < nfull) fz.nrm[(size_t)tid * nruns + run] = G;
+#endif
     }
 #if !defined(RL_EMU)
     {

@@ -526,6 +526,14 @@ struct Minres2Bufs {
     const double* poly_beta;  // [r]
     int poly_D, poly_m;
     int* giter2;
+    // B's vector work inside the NEXT round's projection (row-polynomial operator,
+    // rl_rowpoly.h RpFuse; fuse_b != 0): B is its scalar head k_minres2_bh, which leaves
+    // coef[rhs] = alfa_r / beta_r (0 for a system that stops); the projection forms y_r and
+    // its partial squared norms nrmB[rhs][nrm_n], which P sums instead of partB.
+    int fuse_b;
+    double* coef;             // [nrhs]
+    double* nrmB;             // [nrhs][nrm_n]
+    int nrm_n;
 };
 
 #define RL_PT 5             // ints per entry of Minres2Bufs::poly_tab
@@ -708,7 +716,20 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     double part_a = 0.0, part_b = 0.0;
     if ((int)threadIdx.x < nblk) {
         part_a = mb.partA[p2][(size_t)rhs * nblk + threadIdx.x];
-        part_b = mb.partB[(size_t)rhs * nblk + threadIdx.x];
+        if (!mb.fuse_b) part_b = mb.partB[(size_t)rhs * nblk + threadIdx.x];
+    }
+    // (fused B: the projection's nrm_n partial norms of this system, RL_NRM_PF loads per thread
+    // requested here with everything else, the rare rest in a loop further down)
+    constexpr int RL_NRM_PF = 2;
+    double pnb[RL_NRM_PF];
+#pragma unroll
+    for (int k = 0; k < RL_NRM_PF; ++k) {
+        pnb[k] = 0.0;
+        if (mb.fuse_b) {
+            const int kk = threadIdx.x + k * blockDim.x;
+            const double v = mb.nrmB[(size_t)rhs * mb.nrm_n + (kk < mb.nrm_n ? kk : 0)];
+            pnb[k] = kk < mb.nrm_n ? v : 0.0;
+        }
     }
     // (all loads unconditional, from clamped rows / entries, masked afterwards:
     // a conditional load is a branch with a full memory wait behind it)
@@ -909,6 +930,12 @@ k_minres2_p(Minres2Bufs mb, int n, int par) {
     double tnorm2 = 0.0, delta = 0.0, gbar = 0.0, epsln = 0.0, dbar = 0.0, root = 0.0;
     double gamma = 1.0, cs = 0.0, sn = 0.0, phi = 0.0, phibar = 0.0, denom = 0.0, oldeps = 0.0;
     RL_STAMP(1);
+    if (mb.fuse_b) {
+#pragma unroll
+        for (int k = 0; k < RL_NRM_PF; ++k) part_b += pnb[k];
+        for (int k = threadIdx.x + RL_NRM_PF * blockDim.x; k < mb.nrm_n; k += blockDim.x)
+            part_b += mb.nrmB[(size_t)rhs * mb.nrm_n + k];
+    }
     block_reduce_sum2(part_a, part_b, red);
     RL_STAMP(2);
     if (fin) {
@@ -1240,6 +1267,36 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
         if (threadIdx.x == 0) mb.partB[(size_t)rhs * nblk + blockIdx.x] = acc;
     }
     RL_STAMP(41);
+}
+
+// B's scalar head (Minres2Bufs::fuse_b): the stopping tests of iteration round - 1 and the
+// coefficient of  y_r = y' - (alfa_r / beta_r) y_{r-1};  the vector update itself and
+// ||y_r||^2 are the next round's projection (rl_rowpoly.h, RpFuse).   grid (nrhs)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres2_bh(Minres2Bufs mb, int nblk, int par, double rtol, int maxiter) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.x;
+    const int p2 = par;
+    const double* so = mb.S[1 - p2] + (size_t)rhs * S_NFIELDS;
+    int* iv = mb.I + rhs * I_NFIELDS;
+    bool go = iv[I_ACTIVE] != 0;
+    double xx = 0.0, alfa = 0.0;
+    sum2_partials(go ? mb.partC + (size_t)rhs * nblk : nullptr,
+                  go ? mb.partA[1 - p2] + (size_t)rhs * nblk : nullptr, nblk, red, &xx, &alfa);
+    const int round = *mb.giter;
+    if (go && round >= 2) {
+        const int istop = minres_stop_test(so, sqrt(xx), round - 1, rtol, maxiter);
+        if (threadIdx.x == 0) {
+            iv[I_ITN] = round - 1;
+            if (istop != 0) {
+                iv[I_ISTOP] = istop;
+                iv[I_ACTIVE] = 0;
+            }
+        }
+        if (istop != 0) go = false;
+    }
+    if (threadIdx.x == 0) mb.coef[rhs] = go ? alfa / so[S_BETA] : 0.0;
 }
 
 // ---- CG ---------------------------------------------------------------------

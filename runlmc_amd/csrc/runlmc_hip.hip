@@ -105,6 +105,7 @@ struct RlKnobs {
     int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
     int rp_runlen = 0;           // RUNLMC_RP_RUNLEN: rows per run of k_rp_project (default: about n / 1024)
     bool no_rp_small = false;    // RUNLMC_NO_RP_SMALL: batches of <= 17 vectors through the general k_rp_project
+    bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
                                  // expansion 257 -> 236 us at 129 vectors, 61 -> 42 at 17; projection level at rank
@@ -147,6 +148,7 @@ static RlKnobs read_knobs() {
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
+    k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
     k.rp_runlen = (int)num("RUNLMC_RP_RUNLEN", 0);
     k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
     k.no_sort = flag("RUNLMC_NO_SORT");
@@ -2569,6 +2571,9 @@ struct rl_ski {
     int rp_nruns = 0;
     double* rp_part = nullptr;
     size_t rp_part_cap = 0;
+    double* rp_nrm = nullptr;       // fused B: [nrhs] coefficients + [nrhs][rp_nruns] partial norms
+    size_t rp_nrm_cap = 0;
+    RpFuse rp_fuse{nullptr, nullptr, nullptr};   // set by the solver around ONE operator product
     std::vector<int> eps_end;       // noise in runs: rows [eps_end[k-1], eps_end[k]) carry eps_val[k]
     std::vector<double> eps_val;    // (empty: more than RL_MAX_D runs)
     bool permuted = false;
@@ -2830,7 +2835,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
-                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part,
+                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part, s->rp_nrm,
                     s->rp_base_c, s->rp_w4_c};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -3126,21 +3131,35 @@ static void rp_launch(rl_ski* s, const double* F, const int* base, const double*
     constexpr int NT = (R + 15) / 16;
     const size_t lds = (((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
+    const RpFuse fz = s->rp_fuse;            // (by value: the solver clears the handle's copy)
     if constexpr (!FLYP) {
         // at most one block of 16 vectors and a lone last one (a rank's share of an 8-way probe
         // split): the small-batch kernel, next tile's loads in flight during the current one
         if (nvec <= RL_RP_VG + 1 && (nvec <= RL_RP_VG || nvec % RL_RP_VG == 1) && !s->kn.no_rp_small) {
             const size_t lds1 = (((size_t)16 * NT + RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
             // (F from the table: computed on the fly here it measured 74 against 72 us)
-            RL_LAUNCH((k_rp_project1<R, false>), dim3(s->rp_nruns), dim3(256), lds1, st, Xp, s->n,
-                      nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
-                      (const double*)g->lr_beta);
+            if (fz.r2 != nullptr)
+                RL_LAUNCH((k_rp_project1<R, false, true>), dim3(s->rp_nruns), dim3(256), lds1, st, Xp,
+                          s->n, nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
+                          (const double*)g->lr_beta, fz);
+            else
+                RL_LAUNCH((k_rp_project1<R, false>), dim3(s->rp_nruns), dim3(256), lds1, st, Xp, s->n,
+                          nvec, F, (const int*)s->rp_runs, s->rp_part, bump, base, w4, g->m,
+                          (const double*)g->lr_beta, RpFuse{nullptr, nullptr, nullptr});
+            goto projected;
+        }
+        if (fz.r2 != nullptr) {
+            const int vb = RL_RP_NG_FB(R) * RL_RP_VG;
+            RL_LAUNCH((k_rp_project<R, false, true>),
+                      dim3(8 * ((s->rp_nruns + 7) / 8) * ((nvec + vb - 1) / vb)), dim3(256), lds, st,
+                      Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_nruns, s->rp_part, bump, base,
+                      w4, g->m, (const double*)g->lr_beta, fz);
             goto projected;
         }
     }
     RL_LAUNCH((k_rp_project<R, FLYP>), dim3(8 * ((s->rp_nruns + 7) / 8) * ((nvec + vblk - 1) / vblk)),
               dim3(256), lds, st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_nruns, s->rp_part,
-              bump, base, w4, g->m, (const double*)g->lr_beta);
+              bump, base, w4, g->m, (const double*)g->lr_beta, RpFuse{nullptr, nullptr, nullptr});
 projected:
     RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
@@ -3550,10 +3569,18 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         RL_TRY(ski_wt_int(s, yin, s->G1, nrhs, st, mb.giter));
         RL_TRY(rl_gridop_mvm(s->g, s->G1, s->G2, nrhs, st));
     } else {
-        RL_TRY(ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter, mb.eps_runs == 0));
+        // row-polynomial operator: the previous round's B finishes inside this projection
+        // (y_{r-1} = y' - coef y_{r-2} formed and stored while the tile is staged; rl_rowpoly.h)
+        if (mb.fuse_b && round >= 2) s->rp_fuse = RpFuse{mb.tri[par], mb.coef, mb.nrmB};
+        const int rc = ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter, mb.eps_runs == 0);
+        s->rp_fuse = RpFuse{nullptr, nullptr, nullptr};
+        if (rc != RL_OK) return rc;
     }
     RL_LAUNCH(k_minres2_p, grid, blk, red, st, mb, n, par);
-    RL_LAUNCH(k_minres2_b, grid, blk, red, st, mb, n, par, rtol, maxiter);
+    if (mb.fuse_b)
+        RL_LAUNCH(k_minres2_bh, dim3(nrhs), blk, red, st, mb, nblk, par, rtol, maxiter);
+    else
+        RL_LAUNCH(k_minres2_b, grid, blk, red, st, mb, n, par, rtol, maxiter);
     return RL_OK;
 }
 
@@ -3772,6 +3799,28 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             RL_HIP(hipMemsetAsync(w.lanczos, 0, bytes, st));
             mb.lanczos = w.lanczos;
             mb.lanczos_cap = lanczos_cap;
+        }
+        // row-polynomial operator (every round of this solve takes it: the same test as the
+        // product's): B's vector work rides in the next round's projection
+        mb.fuse_b = 0;
+        mb.coef = nullptr;
+        mb.nrmB = nullptr;
+        mb.nrm_n = 0;
+        if (mb.W_indptr == nullptr && mb.poly_part == nullptr && rp_ok(s, nrhs) && rp_ready(s, nrhs) &&
+            !(s->kn.rp_fly & 2) && !s->kn.no_rp_fuse) {
+            const size_t need = (size_t)nrhs * (s->rp_nruns + 1);
+            if (s->rp_nrm_cap < need) {
+                if (s->rp_nrm) RL_HIP(hipFree(s->rp_nrm));
+                s->rp_nrm = nullptr;
+                s->rp_nrm_cap = 0;
+                RL_HIP(hipMalloc((void**)&s->rp_nrm, need * sizeof(double)));
+                s->rp_nrm_cap = need;
+            }
+            mb.fuse_b = 1;
+            mb.coef = s->rp_nrm;
+            mb.nrmB = s->rp_nrm + nrhs;
+            mb.nrm_n = s->rp_nruns;
+            trace_once("minres round: B inside the row-polynomial projection (k_minres2_bh)");
         }
         RL_LAUNCH(k_minres2_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], mb);
         if (mb.poly_part != nullptr)        // projection of W^T y_0 for the first round's P

@@ -1656,7 +1656,8 @@ def check_row_polynomial_form():
     from runlmc_amd._native import solve_batch
     from oracle.kernels import KernelSpec, RBFSpec, StdPeriodicSpec
     rng = np.random.RandomState(29)
-    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_RP', 'RUNLMC_NO_FUSE_W', 'RUNLMC_NO_FUSE_WT')
+    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_RP', 'RUNLMC_NO_FUSE_W', 'RUNLMC_NO_FUSE_WT',
+             'RUNLMC_NO_RP_FUSE')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     try:
         os.environ['RUNLMC_STAGED_WT'] = '1'
@@ -1707,6 +1708,35 @@ def check_row_polynomial_form():
             for a, b in zip(Y2r[1], Y2u[1]):
                 assert np.abs(a - b).max() <= 1e-13 * scale, len(a)
             assert np.abs(Xr - Xu).max() <= 1e-9 * np.abs(Xu).max()
+            # MINRES's vector update y_r = y' - (alfa / beta) y_{r-1} and ||y_r||^2 inside the
+            # projection (k_rp_project / k_rp_project1 with FB, k_minres2_bh) against the same
+            # rounds with B as its own kernel: the whole batch (several vector blocks, a lone
+            # last vector when k = 16 j + 1) and one rank's share of 17
+            def solve(nofuse, kk, maxiter, tol=1e-6):
+                os.environ.pop('RUNLMC_NO_RP', None)
+                os.environ.pop('RUNLMC_NO_RP_FUSE', None)
+                if nofuse:
+                    os.environ['RUNLMC_NO_RP_FUSE'] = '1'
+                K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (W, WT)}, lens)
+                op = K.device_operator()
+                op.grid.set_form_gate(0)
+                Bm = torch.from_numpy(np.tile(V, (2, 1))[:kk]).to(op.device)
+                out = solve_batch(op, Bm, tol=tol, maxiter=maxiter)
+                os.environ.pop('RUNLMC_NO_RP_FUSE', None)
+                return out[0].cpu().numpy(), np.asarray(out[1]), np.asarray(out[3])
+            for kk in (min(k, 49), 17):
+                Xf, itf, stf = solve(False, kk, 5)
+                Xn, itn, stn = solve(True, kk, 5)
+                assert np.abs(Xf - Xn).max() <= 1e-12 * np.abs(Xn).max(), (kk, np.abs(Xf - Xn).max())
+                assert np.array_equal(itf, itn) and np.array_equal(stf, stn)
+            if D == 3:
+                # ... and through a solve that ends: systems stop at different rounds (frozen:
+                # coefficient 0, their vectors rewritten unchanged) while the others go on
+                Xf, itf, stf = solve(False, 19, 400, tol=1e-3)
+                Xn, itn, stn = solve(True, 19, 400, tol=1e-3)
+                assert np.array_equal(stf, stn) and (stf == 1).all(), (stf, stn)
+                assert len(set(itf.tolist())) > 1 and np.abs(itf - itn).max() <= 6, (itf, itn)
+                assert np.abs(Xf - Xn).max() <= 1e-4 * np.abs(Xn).max()
             make = {'rbf': RBFSpec, 'periodic': StdPeriodicSpec}
             spec = KernelSpec(D, [make[d_[0]](*d_[1:]) for d_ in p.kern_desc], list(p.coreg_vecs),
                               list(p.coreg_diags), p.noise)

@@ -513,6 +513,25 @@ def test_c5_row_polynomial_rounds(native, kern, monkeypatch):
         Xs, it = solve_batch(op, X[:17].to(op.device), tol=1e-4, maxiter=CAP)[:2]
         assert np.all(np.array(it) == CAP)
         out[mode] = (Y, Xs.cpu().numpy())
+        if mode == 'rp':
+            # all 129 systems (k_rp_project with MINRES's vector update inside: three vector
+            # blocks, the lone last vector) against the same rounds with B as its own kernel
+            full = {}
+            for fuse in (True, False):
+                monkeypatch.delenv('RUNLMC_NO_RP_FUSE', raising=False)
+                if not fuse:
+                    monkeypatch.setenv('RUNLMC_NO_RP_FUSE', '1')
+                    K2, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+                    op = K2.device_operator()       # (switches are read when a handle is made)
+                Xa, ita = solve_batch(op, X.to(op.device), tol=1e-4, maxiter=CAP)[:2]
+                assert np.all(np.array(ita) == CAP)
+                full[fuse] = Xa.cpu().numpy()
+            monkeypatch.delenv('RUNLMC_NO_RP_FUSE', raising=False)
+            assert not np.array_equal(full[True], full[False])
+            assert (np.abs(full[True] - full[False]) /
+                    np.abs(full[False]).max(axis=1, keepdims=True)).max() < 1e-11
+            assert (np.abs(full[True][:17] - out['rp'][1]) /
+                    np.abs(out['rp'][1]).max(axis=1, keepdims=True)).max() < 1e-11
     Yr, Sr = out['rp']
     Yi, Si = out['interp']
     assert not np.array_equal(Yr, Yi)
