@@ -1,3 +1,6 @@
+"""GPU box: MINRES solves of a synthetic LMC problem three ways -- B inside the row-polynomial
+projection (default), B as its own kernel (RUNLMC_NO_RP_FUSE=1), interpolation products
+(RUNLMC_NO_RP=1): iterates, iteration counts, exit codes.   python tools/rp_fuse_check.py [nrhs] [maxiter]"""
 import sys, os
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 os.environ['RUNLMC_STAGED_WT']='1'; os.environ['RUNLMC_NO_FUSE_W']='1'; os.environ['RUNLMC_NO_FUSE_WT']='1'
