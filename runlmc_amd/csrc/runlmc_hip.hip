@@ -3210,6 +3210,9 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
             return ski_rp_mvm(s, false, Xp, Yp, nvec, diag, st, bump);
         }
     }
+    // (the solver asked for its vector update inside the projection: no other path does it)
+    if (s->rp_fuse.r2 != nullptr)
+        return fail(RL_EINVAL, "internal: MINRES update fused into a projection that does not run");
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     // a polynomial-form operator hands its mixed coefficients to the W kernel instead of
     // writing the grid vector (the grid handle says whether it took that path)

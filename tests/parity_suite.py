@@ -1721,19 +1721,23 @@ def check_row_polynomial_form():
                 op = K.device_operator()
                 op.grid.set_form_gate(0)
                 Bm = torch.from_numpy(np.tile(V, (2, 1))[:kk]).to(op.device)
-                out = solve_batch(op, Bm, tol=tol, maxiter=maxiter)
+                out = solve_batch(op, Bm, tol=tol, maxiter=maxiter, lanczos_cap=8)
                 os.environ.pop('RUNLMC_NO_RP_FUSE', None)
-                return out[0].cpu().numpy(), np.asarray(out[1]), np.asarray(out[3])
+                return out[0].cpu().numpy(), np.asarray(out[1]), np.asarray(out[3]), out[4]
             for kk in (min(k, 49), 17):
-                Xf, itf, stf = solve(False, kk, 5)
-                Xn, itn, stn = solve(True, kk, 5)
+                Xf, itf, stf, lzf = solve(False, kk, 5)
+                Xn, itn, stn, lzn = solve(True, kk, 5)
                 assert np.abs(Xf - Xn).max() <= 1e-12 * np.abs(Xn).max(), (kk, np.abs(Xf - Xn).max())
                 assert np.array_equal(itf, itn) and np.array_equal(stf, stn)
+                # (the recorded Lanczos coefficients -- the log-determinant's input: beta comes
+                # from the projection's partial norms now)
+                assert np.abs(lzf).max() > 0
+                assert np.abs(lzf - lzn).max() <= 1e-12 * np.abs(lzn).max()
             if D == 3:
                 # ... and through a solve that ends: systems stop at different rounds (frozen:
                 # coefficient 0, their vectors rewritten unchanged) while the others go on
-                Xf, itf, stf = solve(False, 19, 400, tol=1e-3)
-                Xn, itn, stn = solve(True, 19, 400, tol=1e-3)
+                Xf, itf, stf, _ = solve(False, 19, 400, tol=1e-3)
+                Xn, itn, stn, _ = solve(True, 19, 400, tol=1e-3)
                 assert np.array_equal(stf, stn) and (stf == 1).all(), (stf, stn)
                 assert len(set(itf.tolist())) > 1 and np.abs(itf - itn).max() <= 6, (itf, itn)
                 assert np.abs(Xf - Xn).max() <= 1e-4 * np.abs(Xn).max()
