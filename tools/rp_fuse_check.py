@@ -2,7 +2,8 @@
 projection (default), B as its own kernel (RUNLMC_NO_RP_FUSE=1), interpolation products
 (RUNLMC_NO_RP=1): iterates, iteration counts, exit codes.   python tools/rp_fuse_check.py [nrhs] [maxiter]"""
 import sys, os
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root); sys.path.insert(0, os.path.join(_root, 'tests'))
 os.environ['RUNLMC_STAGED_WT']='1'; os.environ['RUNLMC_NO_FUSE_W']='1'; os.environ['RUNLMC_NO_FUSE_WT']='1'
 os.environ['RUNLMC_TRACE']='1'
 from runlmc_amd import _lib
