@@ -491,7 +491,9 @@ def test_c5_row_polynomial_rounds(native, kern, monkeypatch):
     vectors, k_rp_expand) -- what the solver's rounds run at this size: the 129-vector
     product against the oracle's operator on three vectors (1e-11) and against the same
     handle's interpolation-product path (RUNLMC_NO_RP) on all of them (1e-12); MINRES
-    iterates after CAP iterations against that path (1e-8) and the oracle's MINRES."""
+    iterates after CAP iterations against that path (1e-8) and the oracle's MINRES; all 129
+    systems with MINRES's vector update inside the projection (three vector blocks per
+    workgroup there, k_minres2_bh) against the same rounds with B as its own kernel (1e-11)."""
     from runlmc_amd.util import synth
     from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
     from runlmc_amd._native import solve_batch
