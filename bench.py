@@ -63,6 +63,10 @@ def parse():
                     help='skip the full-operator (W K_UU W^T + eps) timing')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the second configuration (the "c2" key)')
+    ap.add_argument('--no-stall', action='store_true',
+                    help='skip the C5 step run on to the stall of the residuals (nll_grad_to_stall)')
+    ap.add_argument('--stall-iters', type=int, default=3000,
+                    help='iteration cap of that step (the C5 residuals stop falling there)')
     ap.add_argument('--cpu-seconds', type=float, default=8.0,
                     help='budget of each bounded CPU sample')
     # debugging aids for the multi-rank path on a one-GPU box
@@ -210,15 +214,34 @@ def cpu_child(spec_json):
                 waves = -(-len(rhs) // nproc)
                 _POOL_CAP = int(min(60, max(4, 20.0 / (waves * t_mv * 1.5))))
             ctx = mp.get_context('fork')
-            t0 = time.perf_counter()
-            with ctx.Pool(processes=nproc) as pool:
-                sols = pool.map(_pool_solve, rhs, chunksize=1)
-            solve_wall = time.perf_counter() - t0
+
+            def pool_pass():
+                t0 = time.perf_counter()
+                with ctx.Pool(processes=nproc) as pool:
+                    sols_ = pool.map(_pool_solve, rhs, chunksize=1)
+                return sols_, time.perf_counter() - t0
+            n_params = p.Q * p.R * p.D + p.Q * p.D + p.Q + p.D
+            runs = []
+            if not _POOL_CAP:
+                # SURVEY 8d / reference grad-grid/slurm-job.sh:52-54: 2 warm-up runs, then
+                # >= 5 timed, the MEDIAN reported (every run: the pool over the N+1 solves
+                # and the full gradient loops)
+                for it_ in range(2 + 5):
+                    sols, solve_wall = pool_pass()
+                    t1 = time.perf_counter()
+                    olik.stochastic_gradients(spec, p.grid_dists, p.W, p.WT, p.lens, sols[0][0],
+                                              probes, np.array([s_[0] for s_ in sols[1:]]))
+                    grad_wall = time.perf_counter() - t1
+                    if it_ >= 2:
+                        runs.append((solve_wall + grad_wall, solve_wall, grad_wall))
+                runs.sort()
+                _, solve_wall, grad_wall = runs[len(runs) // 2]
+            else:
+                sols, solve_wall = pool_pass()
             iters = np.array([s[1] for s in sols])
             per_it = float(np.mean([s[2] / max(s[1], 1) for s in sols]))
             alpha = sols[0][0]
             inv_rs = np.array([s[0] for s in sols[1:]])
-            n_params = p.Q * p.R * p.D + p.Q * p.D + p.Q + p.D
             info = dict(cores=cores, processes=nproc, rhs=len(rhs),
                         iterations_mean=float(iters.mean()),
                         residual_max=float(max(np.linalg.norm(r - op.matvec(s_[0]))
@@ -226,16 +249,16 @@ def cpu_child(spec_json):
                         solve_wall_s=solve_wall, per_iteration_s=per_it,
                         params=n_params)
             if not _POOL_CAP:
-                # the full gradient loops, timed
-                t1 = time.perf_counter()
-                olik.stochastic_gradients(spec, p.grid_dists, p.W, p.WT, p.lens, alpha,
-                                          probes, inv_rs)
-                info['grad_wall_s'] = time.perf_counter() - t1
-                info['seconds'] = solve_wall + info['grad_wall_s']
+                info['grad_wall_s'] = grad_wall
+                info['seconds'] = solve_wall + grad_wall
+                info['seconds_all_runs'] = [round(r[0], 4) for r in runs]
                 info['kind'] = 'timed in full'
+                info['equal_work'] = True
+                info['protocol'] = '2 warm-up runs, 5 timed, median (SURVEY 8d)'
                 info['sample'] = ('Pool(%d) over %d solves run to the reference stopping rule, '
                                   'then all %d parameters x %d right-hand sides of dK products '
-                                  'in the parent' % (nproc, len(rhs), n_params, len(rhs)))
+                                  'in the parent; median of 5 runs after 2 warm-ups'
+                                  % (nproc, len(rhs), n_params, len(rhs)))
             else:
                 # bounded sample: solves stopped after `cap` iterations and dK
                 # products timed on a subset; both scaled linearly (every MINRES
@@ -255,6 +278,12 @@ def cpu_child(spec_json):
                             iteration_cap=_POOL_CAP, iterations_target=target,
                             solve_est_s=solve_est, grad_est_s=grad_est,
                             seconds=solve_est + grad_est, kind='extrapolated from a bounded sample',
+                            # the pool's solves were STOPPED at the cap (residual_max is theirs,
+                            # not that of a finished solve): an iteration-rate sample scaled to
+                            # the device's iteration count, not the same result at the same work.
+                            # The full-length run it is checked against:
+                            # profiles/r05/cpu_full_length_c5.txt
+                            equal_work=False,
                             sample=('Pool(%d) over %d solves, each stopped after %d MINRES '
                                     'iterations (measured wall %.1f s) and scaled to the %.0f '
                                     'iterations the device solve took; gradient loops: %d dK '
@@ -370,13 +399,20 @@ def measured_traffic(config, batch, form='fft'):
     return (e['bytes_per_step'], e['source']) if e else (None, None)
 
 
-def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_exits=True):
+def flat_gradient(g):
+    """The four gradient families of a step as one vector (coreg vectors, coreg
+    diagonals, kernel parameters, noise)."""
+    return np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.hstack(g[2])] + [g[3]]])
+
+
+def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_exits=True,
+                 maxiter=0, keep_gradient=False):
     """One parameters_changed() equivalent on the device: operator update,
     alpha + probe solves, all four gradient families.  scipy_exits=False: the solves
-    run on to the reference's residual rule (RL_MINRES_RULE)."""
+    run on to the reference's residual rule (RL_MINRES_RULE), at most `maxiter`
+    iterations (0: n).  The stopping mode is an argument of the service, not a
+    process-wide switch: nothing to restore when a step fails."""
     import torch
-    from runlmc_amd.approx.iterative import Iterative
-    Iterative.SCIPY_EXITS = bool(scipy_exits)
     from runlmc_amd.util import synth
     from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
     from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
@@ -385,7 +421,8 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
     ad = (0,)
     K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens,
                              device_index=torch.cuda.current_device())
-    svc = StochasticDerivService(None, None, n_probes_global, 1e-4, group=group)
+    svc = StochasticDerivService(None, None, n_probes_global, 1e-4, group=group,
+                                 scipy_exits=bool(scipy_exits), maxiter=maxiter)
     best, info = None, None
     for _ in range(repeats + 1):          # first pass warms workspaces and graphs
         torch.cuda.synchronize()
@@ -406,8 +443,7 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
                         iterations_max=int(np.max(lik.deriv.iterations)),
                         residual_max=float(np.max(lik.deriv.residuals)),
                         residual_median=float(np.median(lik.deriv.residuals)),
-                        grad_norm=float(np.sqrt(sum(np.sum(np.square(x)) for x in
-                                                    g[0] + g[1] + [np.hstack(g[2])] + [g[3]]))),
+                        grad_norm=float(np.linalg.norm(flat_gradient(g))),
                         # a few entries, so that runs can be compared with each other
                         grad_sample=[float(v) for v in np.concatenate(
                             [np.ravel(g[3]), np.ravel(g[1][0]), np.ravel(g[0][0])])[:12]])
@@ -415,7 +451,7 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
         # the same BITS on every rank?  (64-bit checksums of alpha and of the gradient,
         # max and min over the ranks)
         import torch.distributed as tdist
-        flat = np.concatenate([np.ravel(x) for x in g[0] + g[1] + [np.hstack(g[2])] + [g[3]]])
+        flat = flat_gradient(g)
         sums = torch.stack([lik.deriv.alpha_dev.view(torch.int64).sum(),
                             torch.from_numpy(flat.copy()).view(torch.int64).sum().to(
                                 lik.deriv.alpha_dev.device)])
@@ -425,7 +461,8 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
         tdist.all_reduce(lo, op=tdist.ReduceOp.MIN, group=group)
         info['bits_equal_across_ranks'] = {'alpha': bool(hi[0] == lo[0]),
                                            'gradient': bool(hi[1] == lo[1])}
-    Iterative.SCIPY_EXITS = True
+    if keep_gradient:
+        info['_gradient'] = flat_gradient(g)      # (popped by the caller: not part of the line)
     info['seconds'] = best
     # (neither side converges at the reference's noise level -- SciPy's own tests stop
     # the solves --, so the per-iteration cost is the comparison that does not depend
@@ -514,7 +551,9 @@ def time_family(kern, name, args, rank, world, dev, steps, warmup):
            'mvm_per_s': batch * world / (wall_ms * 1e-3), 'ms_per_step': wall_ms,
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                        'traffic_source': source, 'kernel': kernel, 'form': form,
+                        'traffic_source': source,
+                        'traffic_kind': 'recorded' if traffic is not None else None,
+                        'kernel': kernel, 'form': form,
                         'algorithmic_bytes_per_step': alg,
                         'device_event_ms_per_step': max_over_ranks(ev_ms, world, dev)}}
     if form != 'fft':
@@ -567,6 +606,9 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'traffic_source': source,
+                     # (read from the committed rocprofv3 --pmc record, not counted in this
+                     # run: it cannot notice a regression of the traffic)
+                     'traffic_kind': 'recorded' if traffic is not None else None,
                      'kernel': kernel, 'form': form,
                      'algorithmic_bytes_per_step': alg,
                      'clock': 'wall, same region as value',
@@ -633,7 +675,8 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
             if args.force_dist or world > 1:
                 import torch.distributed as tdist
                 group = tdist.group.WORLD
-            info = gpu_nll_grad(pe, probes, n_probes, group=group)
+            info = gpu_nll_grad(pe, probes, n_probes, group=group, keep_gradient=True)
+            grad_scipy = info.pop('_gradient')
             info['seconds'] = max_over_ranks(info['seconds'], world, dev)
             info.update(n_probes_global=n_probes, scaling='strong', eps=eps,
                         probes_per_rank=-(-n_probes // world))
@@ -652,6 +695,31 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
                     'ceiling': info['seconds'] / sh['seconds'],
                     'iterations_max_share': sh['iterations_max']}
             out[key] = info
+            if name == 'c5' and key == 'nll_grad' and world == 1 and not args.no_stall:
+                # The honest companion of the step above (wall-clock at EQUAL
+                # residual tolerance).  SciPy 1.15's own test1 exit ends the C5 solves at
+                # residuals ~1e2 (||b|| = 1000) -- what the reference does today, hence the
+                # headline step.  Here MINRES's own tests are off (RL_MINRES_RULE) and the
+                # reference's rule (explicit residual < 1e-4 every 100 iterations,
+                # approx/iterative.py:36-42) runs until the fp64 residuals stall: no C5
+                # system reaches 1e-4, they stop falling at ~3e-3 from 3000 iterations on
+                # (profiles/r04/time_to_tolerance_c5.txt), so the step is capped there.
+                st = gpu_nll_grad(pe, probes, n_probes, group=None, repeats=1,
+                                  scipy_exits=False, maxiter=args.stall_iters,
+                                  keep_gradient=True)
+                grad_stall = st.pop('_gradient')
+                st.update(n_probes_global=n_probes, eps=eps, maxiter=args.stall_iters,
+                          stopping='reference residual rule only (RL_MINRES_RULE), capped at '
+                                   'the stall of the fp64 residuals',
+                          tolerance_reached=bool(st['residual_max'] < 1e-4),
+                          gradient_rel_distance_to_scipy_exit_step=float(
+                              np.linalg.norm(grad_stall - grad_scipy)
+                              / max(np.linalg.norm(grad_stall), 1e-300)),
+                          scipy_exit_step={'seconds': info['seconds'],
+                                           'residual_median': info['residual_median'],
+                                           'residual_max': info['residual_max'],
+                                           'iterations_max': info['iterations_max']})
+                out['nll_grad_to_stall'] = st
         if name != 'c5' and world == 1:
             # the same step with the solves run ON to the reference's tolerance: MINRES's
             # own stopping tests off (RL_MINRES_RULE), the reference's rule -- explicit
@@ -728,6 +796,7 @@ def main():
             out['cpu_baseline']['nll_grad'] = mine['nll_grad']
             out['nll_grad']['speedup_vs_cpu'] = mine['nll_grad']['seconds'] / out['nll_grad']['seconds']
             out['nll_grad']['cpu_kind'] = mine['nll_grad']['kind']
+            out['nll_grad']['cpu_equal_work'] = bool(mine['nll_grad'].get('equal_work', False))
             out['nll_grad']['cpu_seconds_per_iteration_per_solve'] = mine['nll_grad']['per_iteration_s']
         if other in cpu:
             o = cpu[other]

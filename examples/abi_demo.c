@@ -64,6 +64,11 @@ static double max_rel_err(const double* got, const double* ref, int n) {
 
 int main(void) {
     int ndev = 0;
+    if (rl_abi_version() != RL_ABI_VERSION) {
+        fprintf(stderr, "library implements ABI %d, header declares %d\n", rl_abi_version(),
+                RL_ABI_VERSION);
+        return 2;
+    }
     CHECK_RL(rl_device_count(&ndev));
     printf("backend %s, %d device(s)\n", rl_backend(), ndev);
 

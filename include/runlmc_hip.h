@@ -35,6 +35,13 @@ extern "C" {
 typedef struct rl_gridop rl_gridop;
 typedef struct rl_ski rl_ski;
 
+/* Version of this ABI: bumped whenever a declared signature changes (2: rl_solve_batch_lanczos
+ * gained `method`, round 4; callers built against version 1 must be rebuilt).  A binding
+ * compares rl_abi_version() with the RL_ABI_VERSION it was written against before its
+ * first call (runlmc_amd/_lib.py does) instead of finding out through shifted arguments. */
+#define RL_ABI_VERSION 2
+int rl_abi_version(void);
+
 const char* rl_last_error(void);
 /* "hip-gfx950" for the product library. */
 const char* rl_backend(void);

@@ -27,6 +27,7 @@ _d = ctypes.c_double
 
 # name -> argtypes; every function returns int unless listed in _RESTYPE
 _SIGNATURES = {
+    'rl_abi_version': [],
     'rl_device_count': [_c_int_p],
     'rl_gridop_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
     'rl_gridop_create_2d': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
@@ -54,6 +55,7 @@ _SIGNATURES = {
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 }
+ABI_VERSION = 2      # include/runlmc_hip.h: RL_ABI_VERSION
 _RESTYPE = {'rl_last_error': ctypes.c_char_p, 'rl_backend': ctypes.c_char_p}
 
 
@@ -90,6 +92,14 @@ class NativeLib:
             fn.argtypes = args
         self.backend = self.cdll.rl_backend().decode()
         self.is_hip = self.backend.startswith('hip')
+        # the signatures above are those of ABI version ABI_VERSION (include/runlmc_hip.h:
+        # RL_ABI_VERSION); a library of another version would take shifted arguments
+        ver = getattr(self.cdll, 'rl_abi_version', None)
+        have = int(ver()) if ver is not None else 1
+        if have != ABI_VERSION:
+            raise NativeError(
+                '%s implements ABI version %d, this binding is written against version %d: '
+                'rebuild it (`python -m runlmc_amd.build --force`)' % (path, have, ABI_VERSION))
 
     # -- error mapping -----------------------------------------------------
     def check(self, rc):

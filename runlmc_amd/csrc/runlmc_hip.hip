@@ -42,6 +42,7 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rl_last_error(void) { return g_err.c_str(); }
 extern "C" const char* rl_backend(void) { return RL_BACKEND_NAME; }
+extern "C" int rl_abi_version(void) { return RL_ABI_VERSION; }
 extern "C" int rl_device_count(int* count) {
     if (!count) return fail(RL_EINVAL, "count is NULL");
     RL_HIP(hipGetDeviceCount(count));
@@ -121,14 +122,39 @@ struct RlKnobs {
     bool minres_v1 = false;      // RUNLMC_MINRES_V1 (emulator build only: the four-kernel
                                  // iteration the tests hold the two-kernel rounds against)
 };
+// Three switches are the user's: RUNLMC_POW2_ONLY (the reference's embedding length),
+// RUNLMC_WS_CACHE_MB (memory the solver keeps between calls), RUNLMC_TRACE (prints which
+// kernels ran).  Every other one is an A/B or test hook and is read ONLY under
+// RUNLMC_DEBUG=1 -- without it the library runs its defaults whatever the environment says
+// (and says once, on stderr, that it ignored a hook).
 static RlKnobs read_knobs() {
     RlKnobs k;
-    auto flag = [](const char* n) { return getenv(n) != nullptr; };
-    auto num = [](const char* n, long long dflt) {
+    const char* dbg = getenv("RUNLMC_DEBUG");
+    const bool debug = dbg != nullptr && dbg[0] != '\0' && dbg[0] != '0';
+    auto ignored = [](const char* n) {
+        static bool told = false;
+        if (!told) {
+            told = true;
+            fprintf(stderr, "runlmc_hip: %s is a debug switch and is ignored without RUNLMC_DEBUG=1\n", n);
+        }
+    };
+    auto user_flag = [](const char* n) { return getenv(n) != nullptr; };
+    auto user_num = [](const char* n, long long dflt) {
         const char* e = getenv(n);
         return e ? atoll(e) : dflt;
     };
-    k.pow2_only = flag("RUNLMC_POW2_ONLY");
+    auto flag = [&](const char* n) {
+        if (getenv(n) == nullptr) return false;
+        if (!debug) ignored(n);
+        return debug;
+    };
+    auto num = [&](const char* n, long long dflt) {
+        const char* e = getenv(n);
+        if (e == nullptr) return dflt;
+        if (!debug) ignored(n);
+        return debug ? atoll(e) : dflt;
+    };
+    k.pow2_only = user_flag("RUNLMC_POW2_ONLY");
     k.chunk_mb = (int)num("RUNLMC_CHUNK_MB", 0);
     k.two_streams = (int)num("RUNLMC_TWO_STREAMS", -1);
     k.affine = (int)num("RUNLMC_AFFINE", -1);
@@ -150,9 +176,11 @@ static RlKnobs read_knobs() {
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
     k.rp_runlen = (int)num("RUNLMC_RP_RUNLEN", 0);
-    k.w_poly_rmax = (int)num("RUNLMC_W_POLY_RMAX", 32);
+    // (k_spmv_w_poly exists for ranks 24, 32 and 36: a larger value would hand it coefficients
+    // of a rank it has no instantiation for)
+    k.w_poly_rmax = std::min(36, (int)num("RUNLMC_W_POLY_RMAX", 32));
     k.no_sort = flag("RUNLMC_NO_SORT");
-    k.ws_cache_mb = num("RUNLMC_WS_CACHE_MB", -1);
+    k.ws_cache_mb = user_num("RUNLMC_WS_CACHE_MB", -1);
     k.solver_maxblk = (int)num("RUNLMC_SOLVER_MAXBLK", 0);
     k.no_fuse_w = flag("RUNLMC_NO_FUSE_W");
     k.no_fuse_wt = flag("RUNLMC_NO_FUSE_WT");
@@ -2579,6 +2607,12 @@ struct rl_ski {
     bool permuted = false;
     int* perm = nullptr;
     std::vector<int> h_perm;
+    // rl_ski_mvm's row-polynomial form in the CALLER's row order reuses the runs, the output
+    // borders and the noise array of the SORTED order: valid only when every output's rows
+    // occupy the same range in both orders (checked once on the host, caller_order_same) and
+    // the noise array reads the same in both (rl_ski_set_noise).  -1: not checked yet
+    int caller_ranges_same = -1;
+    bool caller_noise_same = true;
     double *P1 = nullptr, *P2 = nullptr;
     int pcap = 0;
     hipStream_t solver_stream = nullptr;   // capturable stream of rl_solve_batch
@@ -2853,9 +2887,12 @@ extern "C" int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens)
     }
     if ((int)diag.size() != s->n)
         return fail(RL_EINVAL, "rl_ski_set_noise: sum(lens) != n");
+    s->caller_noise_same = true;
     if (s->permuted) {
         std::vector<double> sorted(diag.size());
         for (int i = 0; i < s->n; ++i) sorted[i] = diag[s->h_perm[i]];
+        for (int i = 0; i < s->n && s->caller_noise_same; ++i)
+            s->caller_noise_same = sorted[i] == diag[i];
         diag.swap(sorted);
     }
     // runs of equal values in internal order (one per output when every output's
@@ -3030,9 +3067,11 @@ static int ski_w_poly(rl_ski* s, double* Yp, int nvec, const double* diag, const
     } else if (R == 32) {
         if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 32);
         else RL_W_POLY(2, 32);
-    } else {
+    } else if (R == 36) {
         if (s->w_xmax <= RL_THREADS) RL_W_POLY(1, 36);
         else RL_W_POLY(2, 36);
+    } else {
+        return fail(RL_EINVAL, "k_spmv_w_poly: no instantiation for this rank");
     }
 #undef RL_W_POLY
     RL_HIP(hipGetLastError());
@@ -3169,6 +3208,26 @@ projected:
               (const double*)g->lr_zhat, F, s->n, nvec, g->D,
               (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
               (const double*)g->lr_beta);
+}
+// Do the rows of every output occupy the SAME index range in the caller's order as in the
+// sorted one?  (True for W built output by output, multi_interpolant's block-diagonal layout,
+// runlmc/approx/interpolation.py:161-176; false when the caller interleaves outputs.)  Only
+// then do the sorted order's runs, output borders and per-output noise serve a batch in the
+// caller's order; otherwise rl_ski_mvm permutes the batch (correct for any row order).
+static bool caller_order_same(rl_ski* s) {
+    if (s->caller_ranges_same < 0) {
+        const int n = s->n, m = s->g->m;
+        bool same = (int)s->h_base.size() == n && (int)s->h_perm.size() == n;
+        for (int a = 0; a < n && same;) {
+            const int d = s->h_base[a] / m;
+            int b = a;
+            while (b < n && s->h_base[b] / m == d) ++b;
+            for (int i = a; i < b && same; ++i) same = s->h_perm[i] >= a && s->h_perm[i] < b;
+            a = b;
+        }
+        s->caller_ranges_same = same ? 1 : 0;
+    }
+    return s->caller_ranges_same == 1 && s->caller_noise_same;
 }
 // caller_order: the batch is in the caller's row order (F / entries permuted accordingly)
 static int ski_rp_mvm(rl_ski* s, bool caller_order, const double* Xp, double* Yp, int nvec,
@@ -3312,20 +3371,29 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
     // row permutation of the batch (they were half of this product's time at C5).  The rows of
     // an output are contiguous in both orders, so runs, output borders and the noise array
     // (constant per output) serve both.
-    if (s->extra.empty() && !s->g->wide && !stream_capturing(st)) {
+    if (s->extra.empty() && !s->g->wide && !stream_capturing(st) && caller_order_same(s)) {
         RL_TRY(lr_prepare(s->g, nvec));
         if (rp_ok(s, nvec)) {
             RL_TRY(rp_prepare(s, nvec));
-            if (s->kn.rp_fly && !s->rp_base_c) {
-                {
+            if (s->kn.rp_fly && (!s->rp_base_c || !s->rp_w4_c)) {
+                // (guarded one by one: a failed second allocation must not leave the first
+                // behind as a sign that both exist)
+                if (!s->rp_base_c)
                     RL_HIP(hipMalloc((void**)&s->rp_base_c, (size_t)s->n * sizeof(int)));
-                    RL_HIP(hipMalloc((void**)&s->rp_w4_c, (size_t)4 * s->n * sizeof(double)));
-                    RL_LAUNCH(k_rp_permute_entries, dim3((s->n + 255) / 256), dim3(256), 0,
-                              (hipStream_t) nullptr, (const int*)s->W4_base, (const double*)s->W4_w,
-                              (const int*)s->perm, s->n, s->rp_base_c, s->rp_w4_c);
-                    RL_HIP(hipGetLastError());
-                    RL_HIP(hipDeviceSynchronize());
+                if (!s->rp_w4_c) {
+                    const hipError_t e = hipMalloc((void**)&s->rp_w4_c, (size_t)4 * s->n * sizeof(double));
+                    if (e != hipSuccess) {
+                        s->rp_w4_c = nullptr;
+                        (void)hipFree(s->rp_base_c);
+                        s->rp_base_c = nullptr;
+                        RL_HIP(e);
+                    }
                 }
+                RL_LAUNCH(k_rp_permute_entries, dim3((s->n + 255) / 256), dim3(256), 0,
+                          (hipStream_t) nullptr, (const int*)s->W4_base, (const double*)s->W4_w,
+                          (const int*)s->perm, s->n, s->rp_base_c, s->rp_w4_c);
+                RL_HIP(hipGetLastError());
+                RL_HIP(hipDeviceSynchronize());
             }
             if (!(s->kn.rp_fly & 2) && s->rp_Fc_R != s->rp_R) {
                 if (s->rp_Fc) RL_HIP(hipFree(s->rp_Fc));

@@ -18,12 +18,16 @@ class StochasticDerivService:
     # Lanczos steps kept per system for the log-determinant quadrature
     LANCZOS_CAP = 256
 
-    def __init__(self, metrics, pool, n_it, tol, group=None):
+    def __init__(self, metrics, pool, n_it, tol, group=None, scipy_exits=None, maxiter=0):
+        # (the first four arguments are the reference's; scipy_exits / maxiter go to
+        # Iterative.solve_device unchanged: None = Iterative.SCIPY_EXITS, 0 = n iterations)
         self.metrics = metrics
         self._pool = pool          # interface compatibility only
         self._n_it = int(n_it)
         self._tol = tol
         self._group = group
+        self._scipy_exits = scipy_exits
+        self._maxiter = int(maxiter)
 
     def draw_probes(self, n):
         """+-1 probes from NumPy's legacy global RNG exactly as the reference
@@ -86,7 +90,8 @@ class StochasticDerivService:
                 Bfull[first:first + nm] = torch.from_numpy(
                     np.ascontiguousarray(mine_rows, dtype=np.float64)).to(dev)
         Xf, iters, resid, istop, lanczos = Iterative.solve_device(
-            K, Bfull, minres=True, tol=self._tol, lanczos_cap=self.LANCZOS_CAP)
+            K, Bfull, minres=True, tol=self._tol, maxiter=self._maxiter,
+            lanczos_cap=self.LANCZOS_CAP, scipy_exits=self._scipy_exits)
         idx = torch.tensor(order, device=dev)
         X, B = Xf[idx], Bfull[idx]
         iters, resid, istop = (np.asarray(a)[order] for a in (iters, resid, istop))

@@ -4,6 +4,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The tests force kernel paths through the library's A/B hooks (RUNLMC_NO_RP, RUNLMC_STAGED_WT,
+# ...), which the library reads only under this switch (runlmc_hip.hip: read_knobs).  Child
+# processes (multi-rank tests, the C ABI demo) inherit it.
+os.environ.setdefault('RUNLMC_DEBUG', '1')
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

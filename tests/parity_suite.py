@@ -1771,6 +1771,34 @@ def check_row_polynomial_form():
                 oop2 = olik.LMCOperatorOracle(spec2, p.grid_dists, W, WT, lens)
                 _close(second[16], oop2.matvec(V[16]), 1e-11)
                 _close(first[16], oop.matvec(V[16]), 1e-11)
+                # rows of the outputs INTERLEAVED in the caller's order (rl_ski_create takes any
+                # CSR W): the sorted order's runs, output borders and noise do not describe the
+                # caller's order then, and rl_ski_mvm has to permute the batch instead of running
+                # the row-polynomial form on it as it stands (caller_order_same; round-4 ADVICE:
+                # 2.3 relative error before the check)
+                shuffle = rng.permutation(n)
+                Wi = W[shuffle].tocsr()
+                WTi = Wi.transpose().tocsr()
+                oopi = olik.LMCOperatorOracle(spec, p.grid_dists, Wi, WTi, lens)
+                got = {}
+                for no_rp in (False, True):
+                    os.environ.pop('RUNLMC_NO_RP', None)
+                    if no_rp:
+                        os.environ['RUNLMC_NO_RP'] = '1'
+                    Ki, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (Wi, WTi)}, lens)
+                    opi = Ki.device_operator()
+                    opi.grid.set_form_gate(0)
+                    got[no_rp] = opi.matmat_host(V[:17])
+                    # ... while a solve on the same handle (internal, sorted order) still takes the form
+                    Xi = solve_batch(opi, torch.from_numpy(V[:3]).to(opi.device), tol=1e-6,
+                                     maxiter=6)[0].cpu().numpy()
+                    got[(no_rp, 'x')] = Xi
+                os.environ.pop('RUNLMC_NO_RP', None)
+                _close(got[False][16], oopi.matvec(V[16]), 1e-11)
+                _close(got[False][0], oopi.matvec(V[0]), 1e-11)
+                assert np.abs(got[False] - got[True]).max() <= 1e-13 * np.abs(got[True]).max()
+                assert np.abs(got[(False, 'x')] - got[(True, 'x')]).max() <= \
+                    1e-9 * np.abs(got[(True, 'x')]).max()
     finally:
         for k_, v in saved.items():
             os.environ.pop(k_, None)

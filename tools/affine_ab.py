@@ -7,6 +7,7 @@ transform kernels run whatever the kernel.
     python tools/affine_ab.py [c2|c5|D,Q,m] [batches...]
 """
 import os
+os.environ.setdefault('RUNLMC_DEBUG', '1')   # the switches below are debug hooks
 import sys
 import time
 

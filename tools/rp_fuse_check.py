@@ -5,7 +5,7 @@ import sys, os
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, _root); sys.path.insert(0, os.path.join(_root, 'tests'))
 os.environ['RUNLMC_STAGED_WT']='1'; os.environ['RUNLMC_NO_FUSE_W']='1'; os.environ['RUNLMC_NO_FUSE_WT']='1'
-os.environ['RUNLMC_TRACE']='1'
+os.environ['RUNLMC_TRACE']='1'; os.environ['RUNLMC_DEBUG']='1'   # (the switches are debug hooks)
 from runlmc_amd import _lib
 
 import numpy as np, torch
