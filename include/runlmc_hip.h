@@ -36,10 +36,11 @@ typedef struct rl_gridop rl_gridop;
 typedef struct rl_ski rl_ski;
 
 /* Version of this ABI: bumped whenever a declared signature changes (2: rl_solve_batch_lanczos
- * gained `method`, round 4; callers built against version 1 must be rebuilt).  A binding
+ * gained `method`, round 4; 3: rl_gridop_form_stats added, round 5; callers built against an
+ * older version must be rebuilt).  A binding
  * compares rl_abi_version() with the RL_ABI_VERSION it was written against before its
  * first call (runlmc_amd/_lib.py does) instead of finding out through shifted arguments. */
-#define RL_ABI_VERSION 2
+#define RL_ABI_VERSION 3
 int rl_abi_version(void);
 
 const char* rl_last_error(void);
@@ -93,6 +94,15 @@ int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements);
  * products (rl_gridop_mvm_top) take each top's own form either way.
  * RUNLMC_NO_FILTER=1 switches form 2 off.                                       */
 int rl_gridop_top_forms(const rl_gridop* g, int* forms, int* structured);
+/* What the last set-time verification of the polynomial form measured for top row q
+ * (host out4; zeros when the row was never a candidate): [0] max|T x - Phi C Phi^T x| /
+ * max|T x| for the fixed trial vector, [1] the largest response to the first omitted
+ * polynomials relative to the largest response inside the subspace, [2] the power
+ * iteration's estimate of ||T - Phi C Phi^T||_2 (8 steps through the two products of this
+ * handle), [3] the same iteration's ||T||_2.  The row is accepted when [0], [1] <= 2e-13 and
+ * [2] <= 2e-13 [3]: a bound on the form's error for every input, not for one draw.
+ * (Diagnostics of this library's own forms; the operator is bttb.py:144-148 either way.) */
+int rl_gridop_form_stats(const rl_gridop* g, int q, double* out4);
 /* Moves that batch gate for this handle (0: every batch; < 0: back to the
  * default, 2^20 elements or RUNLMC_LR_MIN).  Below the gate the polynomial
  * form is slower than the transform kernels (too few workgroups).           */

@@ -200,3 +200,51 @@ def exact_gradients_from_dense(K, y, dK_list):
     alpha = la.cho_solve(c, y)
     return [0.5 * (alpha.dot(dK.dot(alpha)) - (dK * Kinv).sum())
             for dK in dK_list]
+
+
+def exact_gradients(spec, Xs, y):
+    """The four gradient families of the EXACT dense likelihood -- the twin the reference's
+    `bench.py opt` holds the approximate gradients against (reference
+    runlmc/lmc/likelihood.py:48-96 loops over likelihood.py:137-217 ExactLMCLikelihood,
+    with exact_deriv.py:13-23:  dL/dt = 0.5 (alpha^T dK alpha - tr(K^-1 dK)) ).
+
+    Restated with  M = alpha alpha^T - K^-1:  dL/dt = 0.5 sum_ij M_ij dK_ij, and every dK of
+    the loops is  dB[d(i), d(j)] Kq[i, j]  (likelihood.py:197-206), so one D x D block sum
+    S_q[a, b] = sum_{i in a, j in b} M_ij Kq_ij  per kernel matrix gives all of its
+    derivatives:  0.5 sum_ab dB[a, b] S_q[a, b].  Returns (dict like stochastic_gradients,
+    alpha, K)."""
+    D, Q = spec.D, spec.Q
+    lens = [len(X) for X in Xs]
+    x = np.concatenate([np.asarray(X, dtype=np.float64).ravel() for X in Xs])
+    dist = np.abs(x[:, None] - x[None, :])
+    K = exact_kernel_dense(spec, Xs)
+    c = la.cho_factor(K)
+    M = -la.cho_solve(c, np.identity(K.shape[0]))
+    alpha = la.cho_solve(c, y)
+    M += np.outer(alpha, alpha)
+    ends = np.cumsum(lens)
+    begins = ends - np.asarray(lens)
+
+    def block_sums(Kq):
+        P = M * Kq
+        S = np.zeros((D, D))
+        for a in range(D):
+            for b in range(D):
+                S[a, b] = P[begins[a]:ends[a], begins[b]:ends[b]].sum()
+        return S
+
+    g_vec, g_diag, g_kern = [], [], []
+    dists = {(0,): dist}
+    grads = spec.eval_kernel_gradients(dists)
+    for q, (a_q, B, k) in enumerate(zip(spec.coreg_vecs, spec.coreg_mats(), spec._kernels)):
+        S = block_sums(k.from_dist(dist))
+        g = np.zeros(np.shape(a_q))
+        for i, ai in enumerate(np.atleast_2d(a_q)):
+            for j in range(D):
+                # dB = e_j a_i^T + a_i e_j^T  (likelihood.py:52-57)
+                g[i, j] = 0.5 * (ai.dot(S[j, :]) + ai.dot(S[:, j]))
+        g_vec.append(g)
+        g_diag.append(0.5 * np.diag(S).copy())              # dB = e_i e_i^T (likelihood.py:68-71)
+        g_kern.append([0.5 * np.sum(B * block_sums(dk)) for dk in grads[q]])   # likelihood.py:82-86
+    g_noise = np.array([0.5 * np.trace(M[b:e, b:e]) for b, e in zip(begins, ends)])  # :92-95
+    return dict(coreg_vec=g_vec, coreg_diag=g_diag, kernel=g_kern, noise=g_noise), alpha, K

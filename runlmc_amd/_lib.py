@@ -38,6 +38,7 @@ _SIGNATURES = {
     'rl_gridop_top_forms': [_vp, _c_int_p, _c_int_p],
     'rl_gridop_set_lmc': [_vp, _i, _vp, _vp, _vp, _vp],
     'rl_gridop_set_dense': [_vp, _i, _vp, _vp],
+    'rl_gridop_form_stats': [_vp, _i, _vp],
     'rl_gridop_mvm': [_vp, _vp, _vp, _i, _vp],
     'rl_gridop_mvm_top': [_vp, _i, _vp, _vp, _i, _vp],
     'rl_gridop_spectrum_host': [_vp, _i, _vp],
@@ -55,7 +56,7 @@ _SIGNATURES = {
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 }
-ABI_VERSION = 2      # include/runlmc_hip.h: RL_ABI_VERSION
+ABI_VERSION = 3      # include/runlmc_hip.h: RL_ABI_VERSION
 _RESTYPE = {'rl_last_error': ctypes.c_char_p, 'rl_backend': ctypes.c_char_p}
 
 

@@ -92,6 +92,14 @@ class GridOp:
         self.lib.call('rl_gridop_top_forms', self._h, forms, ctypes.byref(st))
         return [forms[q] for q in range(self.Q)], bool(st.value)
 
+    def form_stats(self, q):
+        """What the set-time verification of the polynomial form measured for top row q:
+        (trial ratio, tail ratio, estimate of ||T - Phi C Phi^T||_2, estimate of ||T||_2)
+        -- include/runlmc_hip.h: rl_gridop_form_stats."""
+        out = np.zeros(4)
+        self.lib.call('rl_gridop_form_stats', self._h, int(q), host_ptr(out))
+        return tuple(float(v) for v in out)
+
     def set_form_gate(self, min_elements):
         """Smallest batch (nvec*D*m elements) run in the polynomial form;
         0 = every batch, negative = the library default."""

@@ -96,6 +96,8 @@ struct RlKnobs {
     int v1p_min = 0;             // RUNLMC_V1P_MIN
     bool no_lowrank = false;     // RUNLMC_NO_LOWRANK: no polynomial-subspace form
     bool no_filter = false;      // RUNLMC_NO_FILTER: no recursive-filter form
+    bool no_lr_bound = false;    // RUNLMC_NO_LR_BOUND: the polynomial verification without its operator-norm
+                                 // bound (tests: what rounds 2-4 accepted)
     bool poly_round = false;     // RUNLMC_POLY_ROUND: polynomial rounds also on grids of 96..2047 points
     bool no_poly_round = false;  // RUNLMC_NO_POLY_ROUND
     long long lr_min = -1;       // RUNLMC_LR_MIN: batch gate of the structured forms
@@ -164,6 +166,7 @@ static RlKnobs read_knobs() {
     k.v1p_min = (int)num("RUNLMC_V1P_MIN", 0);
     k.no_lowrank = flag("RUNLMC_NO_LOWRANK");
     k.no_filter = flag("RUNLMC_NO_FILTER");
+    k.no_lr_bound = flag("RUNLMC_NO_LR_BOUND");
     k.poly_round = flag("RUNLMC_POLY_ROUND");
     k.no_poly_round = flag("RUNLMC_NO_POLY_ROUND");
     k.lr_min = num("RUNLMC_LR_MIN", -1);
@@ -405,6 +408,9 @@ struct rl_gridop {
     double* lr_zhat = nullptr;  // mixed coefficients [rows][r]
     size_t lr_zhat_cap = 0;
     double* lr_scr = nullptr;   // set-time scratch: 3 vectors of D*m + partial maxima
+    double* lr_pw = nullptr;    // the power iteration's vectors (lr_verify (iv))
+    std::vector<double> lr_vstat;   // host [max_tops][4]: the last verification's measurements per top
+                                    // (trial ratio, tail ratio, ||E v||, ||T w||: rl_gridop_form_stats)
     double* lr_Cc = nullptr;    // dev [max_tops][r][r]: C of the polynomial tops only, contiguous
     double* lr_Bc = nullptr;    // dev [max_tops][D][D]: their couplings (operators that mix forms)
     int lr_np = 0;              // polynomial tops among the Q
@@ -826,7 +832,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
-                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_Cc, g->lr_Bc,
+                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_Cc, g->lr_Bc,
                     g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
                     g->sf_E, g->sf_Cin, g->sf_next};
     for (void* p : ptrs)
@@ -884,6 +890,18 @@ extern "C" int rl_gridop_top_forms(const rl_gridop* gc, int* forms, int* structu
         for (int q = 0; q < g->Q; ++q)
             forms[q] = q < (int)g->top_form.size() ? g->top_form[q] : 0;
     if (structured) *structured = (g->lr_ok || g->st_ok) ? 1 : 0;
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_form_stats(const rl_gridop* gc, int q, double* out4) {
+    if (!gc || !out4) return fail(RL_EINVAL, "rl_gridop_form_stats: NULL argument");
+    if (gc->wide) return rl_gridop_form_stats(gc->child, q, out4);
+    rl_gridop* g = const_cast<rl_gridop*>(gc);      // (runs the pending verification)
+    if (g->Q < 1) return fail(RL_EINVAL, "grid operator has no parameters yet");
+    if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_form_stats: no such top row");
+    RL_TRY(lr_ensure(g));
+    for (int k = 0; k < 4; ++k)
+        out4[k] = (size_t)(4 * q + k) < g->lr_vstat.size() ? g->lr_vstat[4 * q + k] : 0.0;
     return RL_OK;
 }
 
@@ -1932,9 +1950,52 @@ k_lr_rowmax(const double* __restrict__ V, int m, double* __restrict__ out) {
     }
     if (tid == 0) out[blockIdx.x] = red[0];
 }
-// per-top verdict record on the device: RL_LR_NB x 3 comparison partials, then the
-// row maxima of T Phi_j, j < RL_LR_RMAX + 16
-#define RL_LR_STATW (RL_LR_NB * 3 + RL_LR_RMAX + 16)
+// Power iteration of the verification's operator-norm bound (below): two tiny kernels per
+// vector and step, no host round trip.
+//   k_lr_pw_diff   out = a - b (b may be NULL: out = a), part[block] = sum of out^2
+//   k_lr_pw_scale  v = d / ||d||_2 (d itself when the norm is 0 or not finite), *rec = ||d||_2
+//                  -- every workgroup sums the RL_LR_NB partials in the same fixed order
+#define RL_LR_NPOW 8           // steps
+#define RL_LR_TOL_OP 2e-13     // accepted estimate of ||T - Phi C Phi^T||_2 / ||T||_2
+__global__ void __launch_bounds__(256)
+k_lr_pw_diff(const double* a, const double* b, size_t n, double* out, double* __restrict__ part) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);       // [256]
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double d = b ? a[i] - b[i] : a[i];
+        out[i] = d;
+        s = fma(d, d, s);
+    }
+    const int tid = threadIdx.x;
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256)
+k_lr_pw_scale(const double* __restrict__ d, size_t n, const double* __restrict__ part, int nparts,
+              double* __restrict__ v, double* __restrict__ rec) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);       // [1]
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nparts; ++b) s += part[b];
+        red[0] = sqrt(s);
+    }
+    __syncthreads();
+    const double nrm = red[0];
+    const double inv = (nrm > 0.0 && nrm <= 1e300) ? 1.0 / nrm : 1.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        v[i] = d[i] * inv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rec = nrm;
+}
+// per-top verdict record on the device: RL_LR_NB x 3 comparison partials, the row maxima
+// of T Phi_j, j < RL_LR_RMAX + 16, then the power iteration's norms ||E v_k||, ||T w_k||
+#define RL_LR_STATW (RL_LR_NB * 3 + RL_LR_RMAX + 16 + 2 * RL_LR_NPOW)
 
 // Polynomial verification of the tops with want[q] != 0: builds C_q = Phi^T T_q Phi
 // with the transform kernels of this handle and accepts, per top and rank,
@@ -1945,7 +2006,17 @@ k_lr_rowmax(const double* __restrict__ V, int m, double* __restrict__ out) {
 //        RL_LR_TOL max_j max|T Phi_j|: the operator's action outside the subspace
 //        is at roundoff (this is the adversarial input of the form; a random
 //        vector only carries 1/sqrt(m) of its norm in any one direction),
-//   (iii) nothing in either product is NaN or infinite.
+//   (iii) nothing in either product is NaN or infinite,
+//   (iv) a BOUND instead of a draw (round 5): RL_LR_NPOW steps of the power iteration on
+//        E = T_q - Phi C_q Phi^T through the two products of this handle, started from the
+//        fixed random vector, against the same iteration on T_q itself:
+//        max_k ||E v_k||_2 <= RL_LR_TOL_OP ||T w||_2.  E is symmetric, so ||E v_k|| climbs
+//        monotonically to ||E||_2: whatever direction the form is worst in -- a component
+//        the fixed trial vector happens to miss, an omitted polynomial beyond the four of
+//        (ii) -- grows by the ratio of E's leading eigenvalues at every step, and the
+//        accepted quantity is the operator's error for EVERY input relative to ||T||_2.
+//        (tests: an RBF row plus a small cosine whose frequency the trial vector is blind
+//        to passes (i)-(iii) and is rejected here; RUNLMC_NO_LR_BOUND, debug, skips it.)
 // Tries r = 24, 32, 48: the first rank that every wanted top passes is used; if
 // none, rank 48 with whatever passes.  pass[q] is set for the tops in the form.
 static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<char>* pass) {
@@ -1968,6 +2039,8 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
         // scratch: a fixed random vector, two results, the packed T Phi block
         const size_t nvr = (RL_LR_RMAX + RL_LR_EXTRA + D - 1) / D;
         RL_HIP(hipMalloc((void**)&g->lr_scr, (3 + nvr) * vec * sizeof(double)));
+        // power iteration: [v | w], [T v | T w], partial sums
+        RL_HIP(hipMalloc((void**)&g->lr_pw, (4 * vec + 2 * RL_LR_NB) * sizeof(double)));
         std::vector<double> xr(vec);
         unsigned long long st = 0x9E3779B97F4A7C15ull;          // fixed seed: same trials every time
         for (size_t i = 0; i < vec; ++i) {
@@ -2019,6 +2092,33 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
             RL_TRY(lr_apply(g, xr, y2, 1, q, 1, g->lr_eye, st));
             RL_LAUNCH(k_lr_compare, dim3(RL_LR_NB), dim3(256), 3 * 256 * sizeof(double), st,
                       (const double*)y1, (const double*)y2, vec, stat);
+            // (iv) power iteration on E = T - Phi C Phi^T (vector v) and on T (vector w), both
+            // from the trial vector; the pair [v | w] is ONE two-vector transform product
+            {
+                double* vw = g->lr_pw;
+                double* Tvw = vw + 2 * vec;
+                double* parts = Tvw + 2 * vec;
+                double* rec = stat + RL_LR_NB * 3 + RL_LR_RMAX + 16;
+                RL_HIP(hipMemcpyAsync(vw, xr, vec * sizeof(double), hipMemcpyDeviceToDevice, st));
+                RL_HIP(hipMemcpyAsync(vw + vec, xr, vec * sizeof(double), hipMemcpyDeviceToDevice, st));
+                for (int k = 0; k < RL_LR_NPOW; ++k) {
+                    g->lr_bypass = true;
+                    rc = mvm_with_mix(g, mp, vw, Tvw, 2, st);
+                    g->lr_bypass = false;
+                    if (rc != RL_OK) return rc;
+                    RL_TRY(lr_apply(g, vw, y2, 1, q, 1, g->lr_eye, st));
+                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_NB), dim3(256), 256 * sizeof(double), st,
+                              (const double*)Tvw, (const double*)y2, vec, Tvw, parts);
+                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_NB), dim3(256), sizeof(double), st,
+                              (const double*)Tvw, vec, (const double*)parts, RL_LR_NB, vw, rec + k);
+                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_NB), dim3(256), 256 * sizeof(double), st,
+                              (const double*)(Tvw + vec), (const double*)nullptr, vec, Tvw + vec,
+                              parts + RL_LR_NB);
+                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_NB), dim3(256), sizeof(double), st,
+                              (const double*)(Tvw + vec), vec, (const double*)(parts + RL_LR_NB),
+                              RL_LR_NB, vw + vec, rec + RL_LR_NPOW + k);
+                }
+            }
         }
         RL_HIP(hipGetLastError());
         // the one round trip of this rank: verdict records of all tops + their C
@@ -2044,7 +2144,21 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
             }
             const bool trial = dmax <= RL_LR_TOL * ymax || (ymax == 0.0 && dmax == 0.0);
             const bool tail = outside <= RL_LR_TOL * inside || (inside == 0.0 && outside == 0.0);
-            ok[q] = finite && trial && tail;
+            // (iv): the largest ||E v_k|| against ||T w|| after the last step
+            const double* rec = rm + RL_LR_RMAX + 16;
+            double sigE = 0.0, sigT = 0.0;
+            for (int k = 0; k < RL_LR_NPOW; ++k) {
+                if (!std::isfinite(rec[k]) || !std::isfinite(rec[RL_LR_NPOW + k])) finite = false;
+                sigE = std::max(sigE, rec[k]);
+                sigT = std::max(sigT, rec[RL_LR_NPOW + k]);
+            }
+            const bool bound = g->kn.no_lr_bound || sigE <= RL_LR_TOL_OP * sigT || (sigE == 0.0 && sigT == 0.0);
+            if ((int)g->lr_vstat.size() < 4 * g->max_tops) g->lr_vstat.assign((size_t)4 * g->max_tops, 0.0);
+            g->lr_vstat[4 * q + 0] = ymax > 0.0 ? dmax / ymax : dmax;
+            g->lr_vstat[4 * q + 1] = inside > 0.0 ? outside / inside : outside;
+            g->lr_vstat[4 * q + 2] = sigE;
+            g->lr_vstat[4 * q + 3] = sigT;
+            ok[q] = finite && trial && tail && bound;
             all = all && ok[q];
         }
         best = ok;

@@ -883,6 +883,80 @@ def check_polynomial_form():
                 os.environ[kn] = saved[kn]
 
 
+def _verification_trial_vector(n):
+    """The fixed trial vector of the polynomial form's set-time verification
+    (runlmc_hip.hip: lr_verify -- a 64-bit LCG, entries in [-1, 1))."""
+    st, mask = 0x9E3779B97F4A7C15, (1 << 64) - 1
+    x = np.empty(n)
+    for i in range(n):
+        st = (st * 6364136223846793005 + 1442695040888963407) & mask
+        x[i] = ((st >> 11) / 9007199254740992.0) * 2.0 - 1.0
+    return x
+
+
+def check_polynomial_bound():
+    """The polynomial form is accepted on a BOUND, not on a draw (round 5, lr_verify (iv)): an
+    RBF top row plus eps cos(omega i) with eps = 2e-12 and omega chosen where the verification's
+    fixed trial vector has (almost) no component -- |sum_i x_i e^{i omega i}| = 0.10 against a
+    typical 29 -- and far above what 52 polynomials resolve.  T - Phi C Phi^T then has an
+    eigenvalue eps m / 2 = 2.6e-9 (||T||_2 = 2.2e3) in a direction neither the trial vector
+    nor the first four omitted polynomials see: trial ratio 1.6e-13 <= 2e-13, tail ratio
+    1e-14 -- rounds 2-4 accepted it (RUNLMC_NO_LR_BOUND=1 reproduces that) and answered the
+    input cos(omega i) with an error of 7e-9 of the result.  Eight power-iteration steps on
+    the difference of the two products find the direction: 2.6e-9 > 2e-13 ||T||_2, the row
+    stays on the transform kernels, the same input is answered to 1e-13."""
+    from runlmc_amd._native import GridOp
+    m, eps, omega = 2600, 2e-12, 1.352564875153917
+    idx = np.arange(m)
+    xr = _verification_trial_vector(m)
+    blind = abs(np.exp(1j * omega * idx) @ xr)
+    assert blind < 0.11, blind                       # (the trial vector's blind spot)
+    t = np.linspace(0, 1, m)
+    top = np.exp(-0.5 * (1.5 * t) ** 2) + eps * np.cos(omega * idx)
+    worst = np.cos(omega * idx)
+    ref = ops.BTTBOracle(top).matvec(worst)
+    saved = os.environ.pop('RUNLMC_NO_LR_BOUND', None)
+    try:
+        out = {}
+        for nobound in (True, False):
+            os.environ.pop('RUNLMC_NO_LR_BOUND', None)
+            if nobound:
+                os.environ['RUNLMC_NO_LR_BOUND'] = '1'
+            g = GridOp(1, m, 1)
+            g.set_lmc(top[None, :], [np.zeros((1, 1))], [np.ones(1)])
+            g.set_form_gate(0)
+            forms, structured = g.top_forms()
+            trial, tail, sig_e, sig_t = g.form_stats(0)
+            y = g.matmat_host(worst[None, :])[0]
+            out[nobound] = (forms, g.form()[0], trial, tail, sig_e, sig_t,
+                            np.abs(y - ref).max() / np.abs(ref).max())
+        os.environ.pop('RUNLMC_NO_LR_BOUND', None)
+        f0, r0, trial, tail, sig_e, sig_t, err0 = out[True]
+        # what rounds 2-4 accepted: every sampled test passes ...
+        assert f0 == [1] and r0 == 24, out[True]
+        assert trial <= 2e-13 and tail <= 2e-13, (trial, tail)
+        # ... although the operator's error is eps m / 2 for the right input
+        assert abs(sig_e - eps * m / 2) < 0.05 * eps * m / 2, sig_e
+        assert abs(sig_t - 2213.5) < 1.0, sig_t
+        assert err0 > 1e-9, err0
+        f1, r1, _, _, sig_e1, sig_t1, err1 = out[False]
+        assert f1 == [0] and r1 == 0, out[False]          # the bound rejects the row
+        assert sig_e1 > 2e-13 * sig_t1
+        assert err1 < 1e-12, err1
+        # an honest row is far inside the bound (RBF: the difference is the transform
+        # kernels' own roundoff)
+        g = GridOp(1, m, 1)
+        g.set_lmc(np.exp(-0.5 * (1.5 * t) ** 2)[None, :], [np.zeros((1, 1))], [np.ones(1)])
+        g.set_form_gate(0)
+        assert g.top_forms() == ([1], True)
+        trial, tail, sig_e, sig_t = g.form_stats(0)
+        assert sig_e < 1e-14 * sig_t and trial < 5e-14, (trial, sig_e, sig_t)
+    finally:
+        os.environ.pop('RUNLMC_NO_LR_BOUND', None)
+        if saved is not None:
+            os.environ['RUNLMC_NO_LR_BOUND'] = saved
+
+
 def check_slfm_identity_quirk(golden_dir=None):
     """The reference's 'slfm' representation adds an identity on the grid for
     pure-SLFM and pure-independent models (grid_kernel.py:87-88,104-105;

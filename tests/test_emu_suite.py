@@ -177,6 +177,10 @@ def test_cross_dots():
     ps.check_cross_dots()
 
 
+def test_polynomial_bound():
+    ps.check_polynomial_bound()
+
+
 def test_polynomial_form():
     ps.check_polynomial_form()
 

@@ -88,6 +88,82 @@ def test_two_rank_probe_sharding():
     assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
 
 
+def _grads_n(n_probes):
+    """The step on `lmc_small` with a seeded matrix of n_probes probes (every rank draws the
+    same matrix and keeps its own rows: rank, rank + world, ...)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import parity_suite as ps
+    from cases import Case
+    from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+    from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
+    c = Case('lmc_small')
+    fk, K, gk = ps.build_operator(c)
+    ad = (0,)
+    rs = np.random.RandomState(77).randint(0, 2, (n_probes, c.n)) * 2 - 1
+    svc = StochasticDerivService(None, None, n_probes, 1e-4)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
+                              c.Ys, svc, probes=rs)
+    flat = np.concatenate([np.ravel(g) for g in lik.coreg_vec_gradients()] +
+                          [np.ravel(g) for g in lik.coreg_diags_gradients()] +
+                          [np.ravel(g) for g in lik.kernel_gradients()] +
+                          [lik.noise_gradient()])
+    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy()
+
+
+def _worker_n(rank, world, port, q, n_probes):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.EMU_LIB)
+    flat, nloc, alpha = _grads_n(n_probes)
+    q.put((rank, flat, nloc, alpha))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_probes', [5, 128])
+def test_eight_rank_probe_sharding(n_probes):
+    """The 8-GPU layout of BASELINE config 5 on CPU (gloo, kernels under the emulator;
+    reference axis runlmc/lmc/stochastic_deriv.py:39-52): N = 5 probes over 8 ranks -- three
+    ranks own NO probe and still solve alpha, take part in the broadcast and the all-reduce
+    -- and N = 128, the C5 deal of 16 probes + y per rank.  alpha and the assembled gradient
+    are the SAME BITS on all eight ranks and agree with the one-rank step."""
+    world = 8
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.build_emu())
+    try:
+        ref, nall, alpha_ref = _grads_n(n_probes)
+    finally:
+        _lib.use_library(None)
+    assert nall == n_probes
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, q, n_probes))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    owned = [g[2] for g in got]
+    assert sum(owned) == n_probes                              # every probe owned once
+    assert owned == [len(range(r, n_probes, world)) for r in range(world)]
+    if n_probes < world:
+        assert owned.count(0) == world - n_probes              # ranks with y only
+    for g in got[1:]:
+        assert np.array_equal(g[3], got[0][3])                 # alpha: rank 0's, broadcast
+        assert np.array_equal(g[1], got[0][1])                 # gradient: one all-reduce
+    assert np.abs(got[0][3] - alpha_ref).max() < 1e-6 * np.abs(alpha_ref).max()
+    scale = np.abs(ref).max()
+    assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
+
+
 def _grads_structured(world_group=None):
     """The same on a synthetic model whose operator runs in the STRUCTURED forms (polynomial
     form verified at rank 24, solver rounds in the row-polynomial form F M F^T: forced onto

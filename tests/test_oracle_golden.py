@@ -139,6 +139,36 @@ def test_dense_and_logdet():
                                float(c.g['logdet_dense']), rtol=1e-12)
 
 
+def test_exact_dense_twin():
+    """oracle.likelihood.exact_gradients against the reference's own ExactLMCLikelihood
+    (likelihood.py:137-217, exact_deriv.py) run on a small seeded model (exact_small.npz,
+    make_golden.py: gen_exact): the dense twin the reference's `bench.py opt` measures its
+    err:grad and alpha error columns against (benchmarks/benchlib/bench.py:235-283)."""
+    from oracle.kernels import KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec
+    g = np.load(os.path.join(GOLDEN, 'exact_small.npz'), allow_pickle=True)
+    D, Q = int(g['D']), int(g['Q'])
+    make = {'rbf': RBFSpec, 'matern': Matern32Spec, 'periodic': StdPeriodicSpec}
+    kerns = []
+    for d in g['kdesc']:
+        parts = str(d).split(';')
+        kerns.append(make[parts[0]](*[float(v) for v in parts[1:]]))
+    spec = KernelSpec(D, kerns, [g[f'A{q}'] for q in range(Q)],
+                      [g[f'kappa{q}'] for q in range(Q)], g['noise'])
+    spec.set_input_dim(1)
+    Xs = [g[f'X{d}'] for d in range(D)]
+    got, alpha, K = lik.exact_gradients(spec, Xs, g['y'])
+    np.testing.assert_allclose(K, g['K'], rtol=0, atol=1e-13 * np.abs(g['K']).max())
+    np.testing.assert_allclose(alpha, g['alpha'], rtol=0, atol=1e-9 * np.abs(g['alpha']).max())
+    for q in range(Q):
+        for mine, key in ((got['coreg_vec'][q], f'grad_A{q}'),
+                          (got['coreg_diag'][q], f'grad_kappa{q}'),
+                          (np.array(got['kernel'][q]), f'grad_kern{q}')):
+            ref = g[key]
+            np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-9 * max(1, np.abs(ref).max()))
+    np.testing.assert_allclose(got['noise'], g['grad_noise'], rtol=0,
+                               atol=1e-9 * np.abs(g['grad_noise']).max())
+
+
 @pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
 def test_gradients_fixed_probes(name):
     """Reference gradient loops fed dense solves + stored probes: fully
