@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r04', 'traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05', 'traffic.json')
 
 
 def parse():
@@ -76,6 +76,11 @@ def parse():
                          "step's broadcast / all-reduce through it (RCCL on a one-GPU box)")
     ap.add_argument('--same-gpu', action='store_true',
                     help='every rank uses cuda:0 (only meaningful with gloo)')
+    ap.add_argument('--cpu-full-length', type=int, default=0, metavar='ITERATIONS',
+                    help='no GPU: ONE full-length CPU NLL+gradient run of --config (every solve '
+                         'this many MINRES iterations, all gradient loops) next to the bounded '
+                         "sample's extrapolation; prints a JSON record (profiles/r05/"
+                         'cpu_full_length_c5.txt)')
     # internal: the CPU-baseline child process (never imports torch)
     ap.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -204,6 +209,11 @@ def cpu_child(spec_json):
             nproc = min(cores, len(rhs))
             _POOL_CAP = 0
             _POOL_RULE = bool(job.get('rule'))
+            full_length = int(job.get('full_length_iterations', 0))
+            if full_length:
+                # every solve runs `full_length` iterations (the device's count), then ALL the
+                # gradient loops: the run the bounded sample's extrapolation is checked against
+                _POOL_CAP = full_length
             if job.get('bounded'):
                 # bounded sample: about 20 s of wall for the pool -- time two
                 # operator products here, then cap every solve accordingly
@@ -222,17 +232,18 @@ def cpu_child(spec_json):
                 return sols_, time.perf_counter() - t0
             n_params = p.Q * p.R * p.D + p.Q * p.D + p.Q + p.D
             runs = []
-            if not _POOL_CAP:
+            if not _POOL_CAP or full_length:
                 # SURVEY 8d / reference grad-grid/slurm-job.sh:52-54: 2 warm-up runs, then
                 # >= 5 timed, the MEDIAN reported (every run: the pool over the N+1 solves
                 # and the full gradient loops)
-                for it_ in range(2 + 5):
+                warm, timed = (0, 1) if full_length else (2, 5)
+                for it_ in range(warm + timed):
                     sols, solve_wall = pool_pass()
                     t1 = time.perf_counter()
                     olik.stochastic_gradients(spec, p.grid_dists, p.W, p.WT, p.lens, sols[0][0],
                                               probes, np.array([s_[0] for s_ in sols[1:]]))
                     grad_wall = time.perf_counter() - t1
-                    if it_ >= 2:
+                    if it_ >= warm:
                         runs.append((solve_wall + grad_wall, solve_wall, grad_wall))
                 runs.sort()
                 _, solve_wall, grad_wall = runs[len(runs) // 2]
@@ -248,7 +259,15 @@ def cpu_child(spec_json):
                                                for r, s_ in zip(rhs[:3], sols[:3]))),
                         solve_wall_s=solve_wall, per_iteration_s=per_it,
                         params=n_params)
-            if not _POOL_CAP:
+            if full_length:
+                info.update(grad_wall_s=grad_wall, seconds=solve_wall + grad_wall,
+                            iteration_cap=_POOL_CAP, kind='full length, one run',
+                            equal_work=True,
+                            sample=('Pool(%d) over %d solves of %d MINRES iterations each (the '
+                                    "device's count), then all %d parameters x %d right-hand "
+                                    'sides of dK products in the parent; ONE run, no warm-up'
+                                    % (nproc, len(rhs), _POOL_CAP, n_params, len(rhs))))
+            elif not _POOL_CAP:
                 info['grad_wall_s'] = grad_wall
                 info['seconds'] = solve_wall + grad_wall
                 info['seconds_all_runs'] = [round(r[0], 4) for r in runs]
@@ -738,6 +757,20 @@ def main():
     args = parse()
     if args.cpu_child is not None:
         cpu_child(args.cpu_child)
+        return
+    if args.cpu_full_length:
+        it = args.cpu_full_length
+        jobs = {'full': dict(config=args.config, nll=True, kern=args.kern,
+                             full_length_iterations=it),
+                'bounded': dict(config=args.config, nll=True, kern=args.kern, bounded=True,
+                                iterations_target=float(it))}
+        cpu = run_cpu_child(jobs, args.cpu_seconds)
+        full, est = cpu['full']['nll_grad'], cpu['bounded']['nll_grad']
+        print(json.dumps({'config': args.config, 'kern': args.kern, 'iterations': it,
+                          'cpu_model': cpu['cpu_model'], 'cores': cpu['cores'],
+                          'host_cpu_count': cpu['cpu_count_reported'],
+                          'full_length': full, 'bounded_sample': est,
+                          'extrapolation_over_full_length': est['seconds'] / full['seconds']}))
         return
     # (before anything touches the GPU) one rank per GPU: --gpus N needs N ranks
     world_env = int(os.environ.get('WORLD_SIZE', '1'))

@@ -82,6 +82,7 @@ struct SfParams {
     const double* facA;       // [nfac][D]
     const double* facAW;      // [nfac][D]: w_f A_f
     const int* facJ;          // [nfac]: top of factor f
+    const double* pwp;        // [NF][2 G]: the chunk states' parity weights (k_sf_carries2)
 };
 
 // one grid step of a causal state (the same code runs the anti-causal one over
@@ -228,6 +229,112 @@ __device__ __forceinline__ void sf_request_rows(double (&xv)[NK][RB], const doub
             const SfPair pr = *reinterpret_cast<const SfPair*>(xr + sf_pair_base(g0 + 128 * k, lane, m));
             xv[2 * k][r] = pr.a;
             xv[2 * k + 1][r] = pr.b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_sf_carries2: the same chunk states for TWO-state filters with the point / mirror-point
+// parity trick (round 5).  The causal and the anti-causal state of a chunk carry mirrored
+// weights -- dir 1: sum_t t^k rho^t x_t, dir 0: sum_t t^k rho^t x_{G-1-t} --, so with
+//   s_t = x_t + x_{G-1-t},  d_t = x_t - x_{G-1-t}   (t < G / 2; shared by every filter)
+// and host weights  a = (p_t + p_m) / 2, b = (p_t - p_m) / 2  (p_t = rho^t, m = G-1-t;
+// c, e: the same of t rho^t)
+//   dir 1 = sum a s + sum b d,   dir 0 = sum a s - sum b d:
+// 4 multiply-adds per point PAIR, state order and filter instead of 8, no weight
+// arithmetic on the device.  A lane holds the pairs (2 l, 2 l + 1) + 128 j of the first half
+// (j < 2) next to their mirrors, the pairs 510 - 2 l - 128 j (both 16-byte loads, one
+// ascending, one descending); the wave sums (SA, SB) pairs land in one writer lane.
+//   grid / block as k_sf_carries;  pwp: [NF][G / 2][4] = (a, b, c, e)
+//   LDS: NF (G / 2) 4 doubles  (+ 256 for the emulator's sums)
+// ---------------------------------------------------------------------------
+// a pair at chunk offset `off` (even) of a row, zeros past the end of the grid; `pr` was
+// requested from sf_pair_clamp(g0 + off, m)
+__device__ __forceinline__ int sf_pair_clamp(int gi, int m) { return gi <= m - 2 ? gi : m - 2; }
+__device__ __forceinline__ void sf_pair_pick(const SfPair& pr, int gi, int m, bool rowl, double& a,
+                                             double& b) {
+    // (a pair that would reach past the row was requested one point further left)
+    a = rowl && gi < m ? (gi > m - 2 ? pr.b : pr.a) : 0.0;
+    b = rowl && gi + 1 < m ? pr.b : 0.0;
+}
+template <int RB>
+__device__ __forceinline__ void sf_request_rows2(SfPair (&xa)[2][RB], SfPair (&xm)[2][RB],
+                                                 const double* __restrict__ X, int nrows, int m,
+                                                 int r0, int g0, int lane) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int row = r0 + r;
+        const double* xr = X + (size_t)(row < nrows ? row : nrows - 1) * m;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            xa[j][r] = *reinterpret_cast<const SfPair*>(xr + sf_pair_clamp(g0 + 2 * lane + 128 * j, m));
+            xm[j][r] = *reinterpret_cast<const SfPair*>(
+                xr + sf_pair_clamp(g0 + RL_SF_G - 2 - 2 * lane - 128 * j, m));
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_sf_carries2(const double* __restrict__ X, int nrows, int m, int NF, const double* __restrict__ pwp,
+              int rows_per_wg, double* __restrict__ E) {
+    constexpr int RB = 4, NS = 2, NV = RB * 2 * NS, G = RL_SF_G, HG = G / 2;
+    RL_SMEM(smem);
+    double* wl = reinterpret_cast<double*>(smem);                // [NF][HG][4]
+    double* red = wl + (size_t)NF * HG * 4;                      // emulator only
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, rbase = blockIdx.y * rows_per_wg, g0 = chunk * G;
+    for (int e = tid; e < NF * HG * 4; e += 256) wl[e] = pwp[e];
+    __syncthreads();
+    SfPair na[2][RB], nm[2][RB];
+    sf_request_rows2<RB>(na, nm, X, nrows, m, rbase + wave * RB, g0, lane);
+    for (int r0 = rbase + wave * RB; r0 < rbase + rows_per_wg; r0 += 4 * RB) {
+        // s and d of the lane's four points t = 2 l + b + 128 j (j, b < 2) of every row
+        double sv[4][RB], dv[4][RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool rowl = r0 + r < nrows;
+                double a0, a1, m0, m1;
+                sf_pair_pick(na[j][r], g0 + 2 * lane + 128 * j, m, rowl, a0, a1);
+                sf_pair_pick(nm[j][r], g0 + G - 2 - 2 * lane - 128 * j, m, rowl, m0, m1);
+                // point t = 2 l + 128 j mirrors G-1-t = (G - 2 - 2 l - 128 j) + 1: the pair's SECOND
+                sv[2 * j][r] = a0 + m1;
+                dv[2 * j][r] = a0 - m1;
+                sv[2 * j + 1][r] = a1 + m0;
+                dv[2 * j + 1][r] = a1 - m0;
+            }
+        if (r0 + 4 * RB < rbase + rows_per_wg)
+            sf_request_rows2<RB>(na, nm, X, nrows, m, r0 + 4 * RB, g0, lane);
+        for (int q = 0; q < NF; ++q) {
+            const double* w = wl + (size_t)q * HG * 4;
+            // acc[r][k][0 / 1] = (SA_k, SB_k) of row r: neighbours, so that a writer lane of the
+            // wave sums holds a pair
+            double acc[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int t = 2 * lane + (p & 1) + 128 * (p >> 1);
+                const double wa = w[4 * t], wb = w[4 * t + 1], wc = w[4 * t + 2], we = w[4 * t + 3];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    acc[r * 4 + 0] = fma(wa, sv[p][r], acc[r * 4 + 0]);
+                    acc[r * 4 + 1] = fma(wb, dv[p][r], acc[r * 4 + 1]);
+                    acc[r * 4 + 2] = fma(wc, sv[p][r], acc[r * 4 + 2]);
+                    acc[r * 4 + 3] = fma(we, dv[p][r], acc[r * 4 + 3]);
+                }
+            }
+            double out[NV / 8];
+            const int j0 = sf_wave_sums<NV>(acc, red, out);
+            if (sf_wave_sums_writer(lane)) {
+                // out = (SA_k, SB_k) of row r = j0 / 4, state order k = (j0 / 2) & 1
+                const int r = j0 >> 2, k = (j0 >> 1) & 1;
+                if (r0 + r < nrows) {
+                    double* dst = E + (((size_t)chunk * nrows + r0 + r) * NF + q) * 2 * NS;
+                    dst[k] = out[0] - out[1];            // dir 0: causal, at the chunk's last point
+                    dst[NS + k] = out[0] + out[1];       // dir 1: anti-causal, at its first point
+                }
+            }
         }
     }
 }
@@ -740,20 +847,18 @@ __device__ __forceinline__ void sf_stage(const double (&xr)[XR], const double (&
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
             const int pi = sf_pad(2 * tid) + half;
-            // (rows beyond D: unconditional reads of a clamped row, zero weight -- a
-            // branch around a read makes the compiler wait for every read in turn,
-            // measured 5 us per tile)
-            double xb[16];
+            // (D is a template argument: exactly D reads and multiply-adds.  With a runtime D
+            // the loops ran to 16 with clamped reads and zero weights -- a branch around a read
+            // made the compiler wait for every read in turn, 5 us per tile -- and until round 5
+            // they stayed that way: 16 instead of 10 at C5)
+            double xb[D];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) xb[b] = xs[(size_t)(b < D ? b : D - 1) * PAD + pi];
+            for (int b = 0; b < D; ++b) xb[b] = xs[(size_t)b * PAD + pi];
             for (int f = 0; f < nfac; ++f) {
                 const double* ar = facA + f * D;
                 double u = 0.0;
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const double wgt = ar[b < D ? b : D - 1];
-                    u = fma(b < D ? wgt : 0.0, xb[b], u);
-                }
+                for (int b = 0; b < D; ++b) u = fma(ar[b], xb[b], u);
                 us[(size_t)f * PAD + pi] = u;
             }
         }
@@ -896,28 +1001,25 @@ k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m
         const double* gAW = facAW;
         const int i0 = 2 * tid, pi = sf_pad(i0);
         double* ybase = Y + (size_t)v * D * m + g0 + i0;
-        double acc[NH][16];
+        double acc[NH][D];
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a) acc[half][a] = xs[(size_t)(a < D ? a : D - 1) * PAD + pi + half];
+            for (int a = 0; a < D; ++a) acc[half][a] = xs[(size_t)a * PAD + pi + half];
             for (int f = 0; f < nfac; ++f) {
                 const double* ar = gAW + f * D;
                 const double uw = us[(size_t)f * PAD + pi + half];
 #pragma unroll
-                for (int a = 0; a < 16; ++a)
-                    acc[half][a] = fma(ar[a < D ? a : D - 1], uw, acc[half][a]);
+                for (int a = 0; a < D; ++a) acc[half][a] = fma(ar[a], uw, acc[half][a]);
             }
         }
         if (g0 + i0 + 1 < m) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a)
-                if (a < D)
-                    *reinterpret_cast<SfPair*>(ybase + (size_t)a * m) = SfPair{acc[0][a], acc[1][a]};
+            for (int a = 0; a < D; ++a)
+                *reinterpret_cast<SfPair*>(ybase + (size_t)a * m) = SfPair{acc[0][a], acc[1][a]};
         } else if (g0 + i0 < m) {
 #pragma unroll
-            for (int a = 0; a < 16; ++a)
-                if (a < D) ybase[(size_t)a * m] = acc[0][a];
+            for (int a = 0; a < D; ++a) ybase[(size_t)a * m] = acc[0][a];
         }
     }
     RL_SF_STAMP(112);

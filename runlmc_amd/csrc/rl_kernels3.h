@@ -32,7 +32,12 @@
 #if defined(RL_EMU)
 #define RL_K3_ROWS_ATTR
 #else
-#define RL_K3_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(D <= 12 ? 4 : 2)))
+// (RL_K3_WPE_SMALL: experiment builds -- waves per SIMD of the instantiations with D <= 5,
+// whose 128-register versions spill 14-16 registers: tools/r05_k3_ab.sh)
+#if !defined(RL_K3_WPE_SMALL)
+#define RL_K3_WPE_SMALL 4
+#endif
+#define RL_K3_ROWS_ATTR __attribute__((amdgpu_waves_per_eu(D <= 12 ? (D <= 5 ? RL_K3_WPE_SMALL : 4) : 2)))
 #endif
 
 template <int RB>

@@ -165,6 +165,44 @@ __device__ __forceinline__ double rp_block_sum(double v, double* scr, int tid) {
     return r;
 }
 
+// MINRES's P inside the EXPANSION (round 5, RpPFuse).  P's element work per row and system --
+// finish iteration r - 1 (w_k, x_k, partial ||x_k||^2), start iteration r (y' = q' / beta_r -
+// (beta_r / beta_{r-1}) y_{r-2}, partial alfa_r) -- needs q' = K~ y_{r-1}, which the expansion
+// holds in a register: it reads y_{r-1} for the noise term anyway, so the fused kernel reads
+// r2, r1, w1, w2, x and writes w1, x, y' -- eight streams -- where expansion + P moved
+// 2 + 9 (q' written, then read back with six more operands).  P's scalar chain (sums of the
+// partial dot products, plane rotation) runs ONCE per system in a head kernel,
+// k_minres2_ph (rl_solver.h), which leaves the coefficients of the element work in pc:
+//   pc[v][0] go (0: frozen system, nothing of it is touched), [1] fin (round >= 2),
+//   [2] oinv = 1 / beta_{r-1}, [3] oldeps, [4] delta, [5] denom, [6] phi,
+//   [7] sinv = 1 / beta_r, [8] coef = beta_r / beta_{r-1}
+// The partial sums of alfa_r and ||x_k||^2 leave per workgroup (fixed order: lanes, then
+// the four waves): partA / partC [v][gridDim.x].  Same statements as k_minres2_p, same bits.
+#define RL_RP_PCW 10
+struct RpPFuse {
+    const double* pc;       // [nvec][RL_RP_PCW]; nullptr: plain expansion
+    double* r1;             // y_{r-2}: read, then receives y'
+    double* w1;             // w_{k-2}: read, receives w_k
+    const double* w2;       // w_{k-1}
+    double* x;
+    double* partA;          // [nvec][gridDim.x]
+    double* partC;
+};
+// sums of a and b over the 64 lanes of a wave, valid in lane 0 (fixed order)
+__device__ __forceinline__ void rp_wave_sum2(double& a, double& b) {
+#if !defined(RL_EMU)
+    // lanes >= 32 carry on with b, the others with a: one exchange serves both sums
+    const int lane = threadIdx.x & 63;
+    const bool hi = (lane & 32) != 0;
+    const double mine = hi ? b : a, send = hi ? a : b;
+    double v = mine + __shfl_xor(send, 32, 64);
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    a = v;                                  // lanes < 32: sum of a; lanes >= 32: sum of b
+    b = __shfl(v, 32, 64);
+#endif
+}
+
 template <int R, bool FLY, bool FB = false>
 __global__ void __launch_bounds__(256) RL_RP_PROJECT_ATTR
 k_rp_project(const double* Y, int n, int nvec, const double* __restrict__ F,
@@ -711,13 +749,14 @@ __device__ __forceinline__ int rp_output_of(const int* __restrict__ out_end, int
     return lo;
 }
 
-template <int R, bool FLY>
+template <int R, bool FLY, bool FP = false>
 __global__ void __launch_bounds__(256)
 k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n, int nvec, int D,
             const int* __restrict__ out_end, double* __restrict__ Q,
             const double* __restrict__ diag, const double* __restrict__ X2, int stagger,
             const int* __restrict__ base, const double* __restrict__ w4, int m,
-            const double* __restrict__ beta) {
+            const double* __restrict__ beta, RpPFuse pf = RpPFuse{nullptr, nullptr, nullptr, nullptr,
+                                                                  nullptr, nullptr, nullptr}) {
     const int tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
     const int ic = i < n ? i : n - 1;
@@ -738,6 +777,112 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
     const int dlast = RL_LR_UNIFORM(rp_output_of(out_end, D, wl));
     const int dmine = dfirst == dlast ? dfirst : rp_output_of(out_end, D, ic);
     int v = (int)(((unsigned)stagger * blockIdx.x) % (unsigned)nvec);
+    if constexpr (FP) {
+        // MINRES's P inside (RpPFuse above): q' stays in a register
+        RL_SMEM(smem);
+        double* ws = reinterpret_cast<double*>(smem);        // [nvec][4 waves][2]  (+ 256: emulator)
+#if !defined(RL_EMU)
+        const int lane = tid & 63, wave = tid >> 6;
+#endif
+        const bool live = i < n;
+        const bool uni = dfirst == dlast;
+        // The operands of a system (y_{r-1}, y_{r-2}, w_{k-2}, w_{k-1}, x: five loads per thread)
+        // are requested TWO systems ahead: with request and use in one iteration every
+        // iteration waited out the memory latency (2.40 ms per C5 round against 1.63 + 0.24
+        // for P and the plain expansion; a P thread has 24 loads in flight).  A frozen system
+        // moves nothing: its request goes to the addresses of the last live one (cache hits).
+        struct Ops {
+            double r2, r1, w1, w2, x;
+        };
+        auto vat = [&](int it) {                 // the it-th system this workgroup visits
+            const int vv = v + it;
+            return vv < nvec ? vv : vv - nvec;
+        };
+        int vlive = 0;                           // (some system's rows: any valid address)
+        auto request = [&](int it) {
+            int vv = it < nvec ? vat(it) : vlive;
+            if (pf.pc[(size_t)vv * RL_RP_PCW] == 0.0) vv = vlive;
+            else vlive = vv;
+            const size_t at = (size_t)vv * n + ic;
+            return Ops{X2[at], pf.r1[at], pf.w1[at], pf.w2[at], pf.x[at]};
+        };
+        Ops cur = request(0), nx1 = request(1);
+        for (int it = 0; it < nvec; ++it) {
+            const int vv = vat(it);
+            const Ops nx2 = request(it + 2);
+            const double* c = pf.pc + (size_t)vv * RL_RP_PCW;        // wave-uniform: scalar loads
+            double accA = 0.0, accC = 0.0;
+            if (c[0] != 0.0) {
+                const size_t at = (size_t)vv * n + ic;
+                double ev = 0.0, od = 0.0;
+                if (uni) {
+                    const double* z = Zhat + ((size_t)vv * D + dfirst) * R;
+#pragma unroll
+                    for (int j = 0; j + 1 < R; j += 2) {
+                        ev = fma(z[j], p[j], ev);
+                        od = fma(z[j + 1], p[j + 1], od);
+                    }
+                } else {
+                    const double* z = Zhat + ((size_t)vv * D + dmine) * R;
+#pragma unroll
+                    for (int j = 0; j + 1 < R; j += 2) {
+                        ev = fma(z[j], p[j], ev);
+                        od = fma(z[j + 1], p[j + 1], od);
+                    }
+                }
+                double q = ev + od;
+                if (diag != nullptr) q = fma(dg, cur.r2, q);
+                // the element work of k_minres2_p, statement by statement
+                if (c[1] != 0.0) {
+                    const double wn = (cur.r1 * c[2] - c[3] * cur.w1 - c[4] * cur.w2) * c[5];
+                    const double xi = cur.x + c[6] * wn;
+                    if (live) {
+                        pf.w1[at] = wn;
+                        pf.x[at] = xi;
+                        accC = fma(xi, xi, accC);
+                    }
+                }
+                const double yi = q * c[7] - c[8] * cur.r1;
+                if (live) {
+                    pf.r1[at] = yi;
+                    accA = fma(cur.r2 * c[7], yi, accA);
+                }
+            }
+            cur = nx1;
+            nx1 = nx2;
+#if defined(RL_EMU)
+            {
+                double* red = ws + (size_t)nvec * 8;
+                accA = rp_block_sum(accA, red, tid);
+                accC = rp_block_sum(accC, red, tid);
+                if (tid == 0) {
+                    ws[(size_t)it * 8] = accA;
+                    ws[(size_t)it * 8 + 1] = accC;
+                }
+            }
+#else
+            rp_wave_sum2(accA, accC);
+            if (lane == 0) {
+                ws[((size_t)it * 4 + wave) * 2] = accA;
+                ws[((size_t)it * 4 + wave) * 2 + 1] = accC;
+            }
+#endif
+        }
+        __syncthreads();
+        const int v0 = (int)(((unsigned)stagger * blockIdx.x) % (unsigned)nvec);
+        for (int it = tid; it < nvec; it += 256) {
+            const int vv = v0 + it < nvec ? v0 + it : v0 + it - nvec;
+#if defined(RL_EMU)
+            const double a = ws[(size_t)it * 8], cc = ws[(size_t)it * 8 + 1];
+#else
+            const double* w = ws + (size_t)it * 8;
+            const double a = (w[0] + w[2]) + (w[4] + w[6]), cc = (w[1] + w[3]) + (w[5] + w[7]);
+#endif
+            pf.partA[(size_t)vv * gridDim.x + blockIdx.x] = a;
+            pf.partC[(size_t)vv * gridDim.x + blockIdx.x] = cc;
+        }
+        return;
+    }
     // Two separate loops (not one loop with a select on the pointer: the compiler then loads
     // the coefficients per lane in both cases -- twelve dependent 16-byte vector loads per
     // vector, 800 us per C5 round instead of the scalar loads' 2xx)

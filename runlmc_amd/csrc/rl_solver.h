@@ -106,6 +106,20 @@ __device__ __forceinline__ void sum2_partials(const double* pa, const double* pb
     *sb = b;
 }
 
+// the same for ANY number of partials (strided per thread, then the block reduction:
+// a fixed order)
+__device__ __forceinline__ void sum2_partials_long(const double* pa, const double* pb, int na,
+                                                   int nb, double* red, double* sa, double* sb) {
+    double a = 0.0, b = 0.0;
+    if (pa != nullptr)
+        for (int k = threadIdx.x; k < na; k += blockDim.x) a += pa[k];
+    if (pb != nullptr)
+        for (int k = threadIdx.x; k < nb; k += blockDim.x) b += pb[k];
+    block_reduce_sum2(a, b, red);
+    *sa = a;
+    *sb = b;
+}
+
 // sqrt(a^2 + b^2) without the libm call (scaled: no spurious overflow)
 __device__ __forceinline__ double hypot2(double a, double b) {
     a = fabs(a);
@@ -534,6 +548,13 @@ struct Minres2Bufs {
     double* coef;             // [nrhs]
     double* nrmB;             // [nrhs][nrm_n]
     int nrm_n;
+    // P's vector work inside the round's EXPANSION (rl_rowpoly.h RpPFuse; fuse_p != 0, needs
+    // fuse_b): P is its scalar head k_minres2_ph, which leaves the coefficients of the element
+    // work in pc; the expansion's workgroups leave np partial sums per system in partA / partC
+    // (np = its grid, above the RL_SOLVER_THREADS a block reduction takes in one go).
+    int fuse_p;
+    double* pc;               // [nrhs][RL_RP_PCW]
+    int np;
 };
 
 #define RL_PT 5             // ints per entry of Minres2Bufs::poly_tab
@@ -1282,8 +1303,13 @@ k_minres2_bh(Minres2Bufs mb, int nblk, int par, double rtol, int maxiter) {
     int* iv = mb.I + rhs * I_NFIELDS;
     bool go = iv[I_ACTIVE] != 0;
     double xx = 0.0, alfa = 0.0;
-    sum2_partials(go ? mb.partC + (size_t)rhs * nblk : nullptr,
-                  go ? mb.partA[1 - p2] + (size_t)rhs * nblk : nullptr, nblk, red, &xx, &alfa);
+    if (nblk <= (int)blockDim.x)
+        sum2_partials(go ? mb.partC + (size_t)rhs * nblk : nullptr,
+                      go ? mb.partA[1 - p2] + (size_t)rhs * nblk : nullptr, nblk, red, &xx, &alfa);
+    else        // (P inside the expansion: one partial per expansion workgroup)
+        sum2_partials_long(go ? mb.partC + (size_t)rhs * nblk : nullptr,
+                           go ? mb.partA[1 - p2] + (size_t)rhs * nblk : nullptr, nblk, nblk, red,
+                           &xx, &alfa);
     const int round = *mb.giter;
     if (go && round >= 2) {
         const int istop = minres_stop_test(so, sqrt(xx), round - 1, rtol, maxiter);
@@ -1297,6 +1323,114 @@ k_minres2_bh(Minres2Bufs mb, int nblk, int par, double rtol, int maxiter) {
         if (istop != 0) go = false;
     }
     if (threadIdx.x == 0) mb.coef[rhs] = go ? alfa / so[S_BETA] : 0.0;
+}
+
+// P's scalar head (Minres2Bufs::fuse_p): everything of k_minres2_p that is per SYSTEM --
+// the sums of the partial dot products, the plane rotation of the iteration being finished,
+// the new scalar state, the Lanczos record -- once per system instead of once per
+// workgroup, and the coefficients of the element work for the expansion (rl_rowpoly.h
+// RpPFuse, which lists pc's fields).  Statement by statement k_minres2_p's.   grid (nrhs)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres2_ph(Minres2Bufs mb, int par) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.x;
+    const int p2 = par;
+    const double* si = mb.S[p2] + (size_t)rhs * S_NFIELDS;
+    double* so = mb.S[1 - p2] + (size_t)rhs * S_NFIELDS;
+    double* pc = mb.pc + (size_t)rhs * RL_RP_PCW;
+    if (!mb.I[rhs * I_NFIELDS + I_ACTIVE]) {
+        if (threadIdx.x < S_NFIELDS) so[threadIdx.x] = si[threadIdx.x];
+        if (threadIdx.x == 0) pc[0] = 0.0;
+        return;
+    }
+    const double eps = 2.220446049250313e-16;
+    const int round = *mb.giter;
+    const bool fin = round >= 2;
+    double part_a = 0.0, part_b = 0.0;
+    sum2_partials_long(mb.partA[p2] + (size_t)rhs * mb.np, mb.nrmB + (size_t)rhs * mb.nrm_n,
+                       fin ? mb.np : 0, fin ? mb.nrm_n : 0, red, &part_a, &part_b);
+    double alfa = 0.0, beta = si[S_BETA], oldb = si[S_BETA];
+    double tnorm2 = 0.0, delta = 0.0, gbar = 0.0, epsln = 0.0, dbar = 0.0, root = 0.0;
+    double gamma = 1.0, cs = 0.0, sn = 0.0, phi = 0.0, phibar = 0.0, denom = 0.0, oldeps = 0.0;
+    if (fin) {
+        alfa = part_a;
+        beta = sqrt(part_b > 0.0 ? part_b : 0.0);
+        tnorm2 = si[S_TNORM2] + alfa * alfa + oldb * oldb + beta * beta;
+        const double cs0 = si[S_CS], sn0 = si[S_SN], dbar0 = si[S_DBAR];
+        oldeps = si[S_EPSLN];
+        delta = cs0 * dbar0 + sn0 * alfa;
+        gbar = sn0 * dbar0 - cs0 * alfa;
+        epsln = sn0 * beta;
+        dbar = -cs0 * beta;
+        root = hypot2(gbar, dbar);
+        gamma = hypot2(gbar, beta);
+        gamma = gamma > eps ? gamma : eps;
+        cs = gbar / gamma;
+        sn = beta / gamma;
+        phi = cs * si[S_PHIBAR];
+        phibar = sn * si[S_PHIBAR];
+        denom = 1.0 / gamma;
+    }
+    const double oinv = oldb > 0.0 ? 1.0 / oldb : 0.0;
+    const double sinv = beta > 0.0 ? 1.0 / beta : 0.0;
+    const double coef = fin ? beta * oinv : 0.0;
+    if (threadIdx.x < RL_RP_PCW) {
+        double v = 0.0;
+        switch (threadIdx.x) {
+            case 0: v = 1.0; break;
+            case 1: v = fin ? 1.0 : 0.0; break;
+            case 2: v = oinv; break;
+            case 3: v = oldeps; break;
+            case 4: v = delta; break;
+            case 5: v = denom; break;
+            case 6: v = phi; break;
+            case 7: v = sinv; break;
+            case 8: v = coef; break;
+            default: break;
+        }
+        pc[threadIdx.x] = v;
+    }
+    if (threadIdx.x < S_NFIELDS) {
+        const int f = threadIdx.x;
+        double v = si[f];
+        if (fin) {
+            const double gmax = si[S_GMAX] > gamma ? si[S_GMAX] : gamma;
+            const double gmin = si[S_GMIN] < gamma ? si[S_GMIN] : gamma;
+            const double z = si[S_RHS1] / gamma;
+            switch (f) {
+                case S_OLDB: v = oldb; break;
+                case S_BETA: v = beta; break;
+                case S_TNORM2: v = tnorm2; break;
+                case S_DBAR: v = dbar; break;
+                case S_EPSLN: v = epsln; break;
+                case S_CS: v = cs; break;
+                case S_SN: v = sn; break;
+                case S_PHIBAR: v = phibar; break;
+                case S_PHI: v = phi; break;
+                case S_ALFA: v = alfa; break;
+                case S_OLDEPS: v = oldeps; break;
+                case S_DELTA: v = delta; break;
+                case S_DENOM: v = denom; break;
+                case S_ROOT: v = root; break;
+                case S_GBAR: v = gbar; break;
+                case S_GMAX: v = gmax; break;
+                case S_GMIN: v = gmin; break;
+                case S_RHS1: v = si[S_RHS2] - delta * z; break;
+                case S_RHS2: v = -epsln * z; break;
+                default: break;
+            }
+        }
+        so[f] = v;
+        if (f == 0 && fin) {
+            const int itn = round - 2;
+            if (mb.lanczos != nullptr && itn < mb.lanczos_cap) {
+                double* lz = mb.lanczos + ((size_t)rhs * mb.lanczos_cap + itn) * 2;
+                lz[0] = alfa;
+                lz[1] = beta;
+            }
+        }
+    }
 }
 
 // ---- CG ---------------------------------------------------------------------

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,7 @@ struct RlKnobs {
     int v1p_min = 0;             // RUNLMC_V1P_MIN
     bool no_lowrank = false;     // RUNLMC_NO_LOWRANK: no polynomial-subspace form
     bool no_filter = false;      // RUNLMC_NO_FILTER: no recursive-filter form
+    bool sf_carries1 = false;    // RUNLMC_SF_CARRIES1: the chunk states without the parity trick (k_sf_carries<2>)
     bool no_lr_bound = false;    // RUNLMC_NO_LR_BOUND: the polynomial verification without its operator-norm
                                  // bound (tests: what rounds 2-4 accepted)
     bool poly_round = false;     // RUNLMC_POLY_ROUND: polynomial rounds also on grids of 96..2047 points
@@ -108,6 +110,11 @@ struct RlKnobs {
     int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
     int rp_runlen = 0;           // RUNLMC_RP_RUNLEN: rows per run of k_rp_project (default: about n / 1024)
     bool no_rp_small = false;    // RUNLMC_NO_RP_SMALL: batches of <= 17 vectors through the general k_rp_project
+    bool rp_pfuse = false;       // RUNLMC_RP_PFUSE: MINRES's P inside the row-polynomial expansion (k_minres2_ph +
+                                 // k_rp_expand<.., true>; rl_rowpoly.h RpPFuse).  Built and parity-green in round 5,
+                                 // OFF by default: the expansion walks rows outer / systems inner, so a workgroup's
+                                 // eight streams are 2 KB bursts in 8 x nvec pages 8 MB apart -- C5 round 3.18-3.75 ms
+                                 // against 2.64-2.85 with P as its own kernel (profiles/r05/rp_pfuse_ab.txt)
     bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
@@ -167,6 +174,7 @@ static RlKnobs read_knobs() {
     k.no_lowrank = flag("RUNLMC_NO_LOWRANK");
     k.no_filter = flag("RUNLMC_NO_FILTER");
     k.no_lr_bound = flag("RUNLMC_NO_LR_BOUND");
+    k.sf_carries1 = flag("RUNLMC_SF_CARRIES1");
     k.poly_round = flag("RUNLMC_POLY_ROUND");
     k.no_poly_round = flag("RUNLMC_NO_POLY_ROUND");
     k.lr_min = num("RUNLMC_LR_MIN", -1);
@@ -178,6 +186,7 @@ static RlKnobs read_knobs() {
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
+    k.rp_pfuse = flag("RUNLMC_RP_PFUSE");
     k.rp_runlen = (int)num("RUNLMC_RP_RUNLEN", 0);
     // (k_spmv_w_poly exists for ranks 24, 32 and 36: a larger value would hand it coefficients
     // of a rank it has no instantiation for)
@@ -427,6 +436,7 @@ struct rl_gridop {
     std::vector<int> sf_slot;   // per top: its place among the filter tops, or -1
     std::vector<int> sf_top_ns; // per top: 2 or 3
     SfTop* sf_tops = nullptr;   // dev [max_tops]
+    double* sf_pwp = nullptr;   // dev [max_tops][2 G]: the chunk states' parity weights (k_sf_carries2)
     double* sf_blob = nullptr;  // dev: the filter part's block for k_sf_apply (rl_filter.h)
     double* sf_blob_top = nullptr;  // dev [max_tops][...]: the same for each top alone (B = I)
     double* sf_pw = nullptr;    // dev [max_tops][G + 1]
@@ -833,7 +843,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
                     g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_Cc, g->lr_Bc,
-                    g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
+                    g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pwp, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
                     g->sf_E, g->sf_Cin, g->sf_next};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1752,6 +1762,18 @@ static bool sf_detect(const double* t, int m, SfFit* fit) {
     return false;
 }
 
+// the chunk states' parity weights of one filter (rl_filter.h: k_sf_carries2): [t][a, b, c, e], t < G / 2,
+// from long-double powers, rounded once
+static void sf_parity_weights_chunk(const SfFit& f, double* out) {
+    for (int t = 0; t < RL_SF_G / 2; ++t) {
+        const int mi = RL_SF_G - 1 - t;
+        const long double pt = expl(-f.ah * t), pm = expl(-f.ah * mi);
+        out[4 * t + 0] = (double)((pt + pm) / 2);
+        out[4 * t + 1] = (double)((pt - pm) / 2);
+        out[4 * t + 2] = (double)((t * pt + mi * pm) / 2);
+        out[4 * t + 3] = (double)((t * pt - mi * pm) / 2);
+    }
+}
 static void sf_device_top(const SfFit& f, int m, SfTop* tp, SfBlk* bk, double* pw) {
     tp->rho = (double)expl(-f.ah);
     for (int k = 0; k < 3; ++k) tp->c[k] = (double)f.c[k];
@@ -1813,9 +1835,14 @@ static int sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const
     if (D < 1 || D > 16) return fail(RL_ELIMIT, "filter form: D outside 1..16");
     // rows per carries workgroup: the filter powers are staged once per workgroup
     const int rpw = nrows >= 16 * 64 ? 64 : 16;
-    RL_LAUNCH((k_sf_carries<NS>), dim3(nch, (nrows + rpw - 1) / rpw), dim3(256),
-              ((size_t)sp.NF * (RL_SF_G + 1) + 256) * sizeof(double), st, X, nrows, g->m, sp.NF,
-              sp.pw, rpw, g->sf_E);
+    if (NS == 2 && !g->kn.sf_carries1)
+        RL_LAUNCH(k_sf_carries2, dim3(nch, (nrows + rpw - 1) / rpw), dim3(256),
+                  ((size_t)sp.NF * (RL_SF_G / 2) * 4 + 256) * sizeof(double), st, X, nrows, g->m,
+                  sp.NF, sp.pwp, rpw, g->sf_E);
+    else
+        RL_LAUNCH((k_sf_carries<NS>), dim3(nch, (nrows + rpw - 1) / rpw), dim3(256),
+                  ((size_t)sp.NF * (RL_SF_G + 1) + 256) * sizeof(double), st, X, nrows, g->m, sp.NF,
+                  sp.pw, rpw, g->sf_E);
     const int ncd = 2 * (D * sp.NF + sp.nfac);
     RL_LAUNCH((k_sf_scan<NS>), dim3((ncd + 7) / 8, nvec), dim3(256), 256 * NS * sizeof(double),
               st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin, g->sf_next);
@@ -1852,7 +1879,7 @@ static int sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const
 // the operator's filter part (every filter top with its couplings)
 static int sf_apply_all(rl_gridop* g, const double* X, double* Y, int nvec, hipStream_t st) {
     SfParams sp{g->sf_n, g->sf_nfac, g->sf_tops, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW,
-                g->sf_facJ};
+                g->sf_facJ, g->sf_pwp};
     return g->sf_ns == 3 ? sf_launch<3>(g, sp, g->sf_blob, X, Y, nvec, st)
                          : sf_launch<2>(g, sp, g->sf_blob, X, Y, nvec, st);
 }
@@ -1860,7 +1887,7 @@ static int sf_apply_all(rl_gridop* g, const double* X, double* Y, int nvec, hipS
 static int sf_apply_top(rl_gridop* g, int q, const double* X, double* Y, int nvec, hipStream_t st) {
     const int j = g->sf_slot[q];
     SfParams sp{1, 0, g->sf_tops + j, g->sf_pw + (size_t)j * (RL_SF_G + 1), g->ones, nullptr,
-                nullptr, nullptr};
+                nullptr, nullptr, g->sf_pwp + (size_t)j * 2 * RL_SF_G};
     const double* blob = g->sf_blob_top + (size_t)j * sf_blob_doubles(1, 0, g->D);
     return g->sf_top_ns[q] == 3 ? sf_launch<3>(g, sp, blob, X, Y, nvec, st)
                                 : sf_launch<2>(g, sp, blob, X, Y, nvec, st);
@@ -1957,6 +1984,11 @@ k_lr_rowmax(const double* __restrict__ V, int m, double* __restrict__ out) {
 //                  -- every workgroup sums the RL_LR_NB partials in the same fixed order
 #define RL_LR_NPOW 8           // steps
 #define RL_LR_TOL_OP 2e-13     // accepted estimate of ||T - Phi C Phi^T||_2 / ||T||_2
+#if defined(RL_EMU)
+#define RL_LR_PWB 8            // (the emulator pays per thread it starts, not per element)
+#else
+#define RL_LR_PWB 512          // workgroups of its vector kernels (64: 20 us per kernel at C5, 10^6 entries)
+#endif
 __global__ void __launch_bounds__(256)
 k_lr_pw_diff(const double* a, const double* b, size_t n, double* out, double* __restrict__ part) {
     RL_SMEM(smem);
@@ -2040,7 +2072,7 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
         const size_t nvr = (RL_LR_RMAX + RL_LR_EXTRA + D - 1) / D;
         RL_HIP(hipMalloc((void**)&g->lr_scr, (3 + nvr) * vec * sizeof(double)));
         // power iteration: [v | w], [T v | T w], partial sums
-        RL_HIP(hipMalloc((void**)&g->lr_pw, (4 * vec + 2 * RL_LR_NB) * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&g->lr_pw, (4 * vec + 2 * RL_LR_PWB) * sizeof(double)));
         std::vector<double> xr(vec);
         unsigned long long st = 0x9E3779B97F4A7C15ull;          // fixed seed: same trials every time
         for (size_t i = 0; i < vec; ++i) {
@@ -2107,16 +2139,16 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
                     g->lr_bypass = false;
                     if (rc != RL_OK) return rc;
                     RL_TRY(lr_apply(g, vw, y2, 1, q, 1, g->lr_eye, st));
-                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_NB), dim3(256), 256 * sizeof(double), st,
+                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_PWB), dim3(256), 256 * sizeof(double), st,
                               (const double*)Tvw, (const double*)y2, vec, Tvw, parts);
-                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_NB), dim3(256), sizeof(double), st,
-                              (const double*)Tvw, vec, (const double*)parts, RL_LR_NB, vw, rec + k);
-                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_NB), dim3(256), 256 * sizeof(double), st,
+                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_PWB), dim3(256), sizeof(double), st,
+                              (const double*)Tvw, vec, (const double*)parts, RL_LR_PWB, vw, rec + k);
+                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_PWB), dim3(256), 256 * sizeof(double), st,
                               (const double*)(Tvw + vec), (const double*)nullptr, vec, Tvw + vec,
-                              parts + RL_LR_NB);
-                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_NB), dim3(256), sizeof(double), st,
-                              (const double*)(Tvw + vec), vec, (const double*)(parts + RL_LR_NB),
-                              RL_LR_NB, vw + vec, rec + RL_LR_NPOW + k);
+                              parts + RL_LR_PWB);
+                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_PWB), dim3(256), sizeof(double), st,
+                              (const double*)(Tvw + vec), vec, (const double*)(parts + RL_LR_PWB),
+                              RL_LR_PWB, vw + vec, rec + RL_LR_NPOW + k);
                 }
             }
         }
@@ -2250,6 +2282,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         RL_TRY(need((void**)&g->sf_blob, (size_t)sf_blob_doubles(g->max_tops, g->max_fac, D) * sizeof(double)));
         RL_TRY(need((void**)&g->sf_blob_top, (size_t)g->max_tops * sf_blob_doubles(1, 0, D) * sizeof(double)));
         RL_TRY(need((void**)&g->sf_pw, (size_t)g->max_tops * (RL_SF_G + 1) * sizeof(double)));
+        RL_TRY(need((void**)&g->sf_pwp, (size_t)g->max_tops * 2 * RL_SF_G * sizeof(double)));
         RL_TRY(need((void**)&g->sf_kappa, (size_t)g->max_tops * D * sizeof(double)));
         RL_TRY(need((void**)&g->sf_facA, (size_t)std::max(g->max_fac, 1) * D * sizeof(double)));
         RL_TRY(need((void**)&g->sf_facAW, (size_t)std::max(g->max_fac, 1) * D * sizeof(double)));
@@ -2257,12 +2290,14 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         std::vector<SfTop> tops(nfilt);
         std::vector<SfBlk> blks(nfilt);
         std::vector<double> pw((size_t)nfilt * (RL_SF_G + 1)), kp((size_t)nfilt * D), fa, faw;
+        std::vector<double> pwpv((size_t)nfilt * 2 * RL_SF_G);
         std::vector<int> fj;
         int ns = 2;
         for (int q = 0; q < Q; ++q) {
             const int j = g->sf_slot[q];
             if (j < 0) continue;
             sf_device_top(fits[q], m, &tops[j], &blks[j], pw.data() + (size_t)j * (RL_SF_G + 1));
+            sf_parity_weights_chunk(fits[q], pwpv.data() + (size_t)j * 2 * RL_SF_G);
             for (int a = 0; a < D; ++a) kp[(size_t)j * D + a] = kap[(size_t)q * D + a];
             ns = std::max(ns, g->sf_top_ns[q]);
         }
@@ -2279,6 +2314,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         g->sf_nfac = (int)fj.size();
         RL_HIP(hipMemcpy(g->sf_tops, tops.data(), tops.size() * sizeof(SfTop), hipMemcpyHostToDevice));
         RL_HIP(hipMemcpy(g->sf_pw, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice));
+        RL_HIP(hipMemcpy(g->sf_pwp, pwpv.data(), pwpv.size() * sizeof(double), hipMemcpyHostToDevice));
         RL_HIP(hipMemcpy(g->sf_kappa, kp.data(), kp.size() * sizeof(double), hipMemcpyHostToDevice));
         // the blocks k_sf_apply stages in LDS: the whole filter part, and every top alone
         {
@@ -2716,6 +2752,14 @@ struct rl_ski {
     double* rp_nrm = nullptr;       // fused B: [nrhs] coefficients + [nrhs][rp_nruns] partial norms
     size_t rp_nrm_cap = 0;
     RpFuse rp_fuse{nullptr, nullptr, nullptr};   // set by the solver around ONE operator product
+    // MINRES's P inside the expansion (rl_rowpoly.h RpPFuse): set by the solver around ONE
+    // operator product together with rp_mid, which launches P's scalar head between the
+    // coefficient map and the expansion; rp_pp: the head's coefficients [nrhs][RL_RP_PCW] and
+    // three arrays of [nrhs][ceil(n / 256)] partial sums
+    RpPFuse rp_pfuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::function<void(hipStream_t)> rp_mid;
+    double* rp_pp = nullptr;
+    size_t rp_pp_cap = 0;
     std::vector<int> eps_end;       // noise in runs: rows [eps_end[k-1], eps_end[k]) carry eps_val[k]
     std::vector<double> eps_val;    // (empty: more than RL_MAX_D runs)
     bool permuted = false;
@@ -2983,7 +3027,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
     void* ptrs[] = {s->W_indptr, s->W_indices, s->W_data, s->WT_indptr, s->WT_indices,
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
-                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part, s->rp_nrm,
+                    s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part, s->rp_nrm, s->rp_pp,
                     s->rp_base_c, s->rp_w4_c};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -3318,10 +3362,25 @@ projected:
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
               (const double*)g->lr_B, (const double*)g->lr_nu, g->lr_zhat,
               (const int*)s->rp_run_ptr);
+    if (s->rp_mid) s->rp_mid(st);
+    const RpPFuse pf = s->rp_pfuse;          // (by value: the solver clears the handle's copy)
+    if (pf.pc != nullptr) {
+        // MINRES's P inside the expansion: no operator output is written
+        size_t lds = (size_t)nvec * 8 * sizeof(double);
+#if defined(RL_EMU)
+        lds += 256 * sizeof(double);
+#endif
+        RL_LAUNCH((k_rp_expand<R, FLYE, true>), dim3((s->n + 255) / 256), dim3(256), lds, st,
+                  (const double*)g->lr_zhat, F, s->n, nvec, g->D,
+                  (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
+                  (const double*)g->lr_beta, pf);
+        return;
+    }
     RL_LAUNCH((k_rp_expand<R, FLYE>), dim3((s->n + 255) / 256), dim3(256), 0, st,
               (const double*)g->lr_zhat, F, s->n, nvec, g->D,
               (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
-              (const double*)g->lr_beta);
+              (const double*)g->lr_beta, RpPFuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                  nullptr});
 }
 // Do the rows of every output occupy the SAME index range in the caller's order as in the
 // sorted one?  (True for W built output by output, multi_interpolant's block-diagonal layout,
@@ -3384,7 +3443,7 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
         }
     }
     // (the solver asked for its vector update inside the projection: no other path does it)
-    if (s->rp_fuse.r2 != nullptr)
+    if (s->rp_fuse.r2 != nullptr || s->rp_pfuse.pc != nullptr)
         return fail(RL_EINVAL, "internal: MINRES update fused into a projection that does not run");
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     // a polynomial-form operator hands its mixed coefficients to the W kernel instead of
@@ -3757,9 +3816,25 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         // row-polynomial operator: the previous round's B finishes inside this projection
         // (y_{r-1} = y' - coef y_{r-2} formed and stored while the tile is staged; rl_rowpoly.h)
         if (mb.fuse_b && round >= 2) s->rp_fuse = RpFuse{mb.tri[par], mb.coef, mb.nrmB};
-        const int rc = ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter, mb.eps_runs == 0);
+        if (mb.fuse_p) {
+            // ... and this round's P inside the expansion (rl_rowpoly.h RpPFuse): its scalar
+            // head between the coefficient map and the expansion, no k_minres2_p
+            s->rp_pfuse = RpPFuse{mb.pc, mb.tri[par], mb.w[par], mb.w[1 - par], mb.x,
+                                  mb.partA[1 - par], mb.partC};
+            const Minres2Bufs mbc = mb;
+            s->rp_mid = [mbc, par, red](hipStream_t q) {
+                RL_LAUNCH(k_minres2_ph, dim3(mbc.fuse_p), dim3(RL_SOLVER_THREADS), red, q, mbc, par);
+            };
+        }
+        const int rc = ski_mvm_int(s, yin, mb.q, nrhs, st, mb.giter, mb.fuse_p || mb.eps_runs == 0);
         s->rp_fuse = RpFuse{nullptr, nullptr, nullptr};
+        s->rp_pfuse = RpPFuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        s->rp_mid = nullptr;
         if (rc != RL_OK) return rc;
+        if (mb.fuse_p) {
+            RL_LAUNCH(k_minres2_bh, dim3(nrhs), blk, red, st, mb, mb.np, par, rtol, maxiter);
+            return RL_OK;
+        }
     }
     RL_LAUNCH(k_minres2_p, grid, blk, red, st, mb, n, par);
     if (mb.fuse_b)
@@ -3991,6 +4066,9 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         mb.coef = nullptr;
         mb.nrmB = nullptr;
         mb.nrm_n = 0;
+        mb.fuse_p = 0;
+        mb.pc = nullptr;
+        mb.np = 0;
         if (mb.W_indptr == nullptr && mb.poly_part == nullptr && rp_ok(s, nrhs) && rp_ready(s, nrhs) &&
             !(s->kn.rp_fly & 2) && !s->kn.no_rp_fuse) {
             const size_t need = (size_t)nrhs * (s->rp_nruns + 1);
@@ -4006,6 +4084,26 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             mb.nrmB = s->rp_nrm + nrhs;
             mb.nrm_n = s->rp_nruns;
             trace_once("minres round: B inside the row-polynomial projection (k_minres2_bh)");
+            if (s->kn.rp_pfuse) {
+                // ... and P inside the expansion (k_minres2_ph + k_rp_expand<.., true>)
+                const int np = (n + 255) / 256;
+                const size_t needp = (size_t)nrhs * (RL_RP_PCW + 3 * (size_t)np);
+                if (s->rp_pp_cap < needp) {
+                    if (s->rp_pp) RL_HIP(hipFree(s->rp_pp));
+                    s->rp_pp = nullptr;
+                    s->rp_pp_cap = 0;
+                    RL_HIP(hipMalloc((void**)&s->rp_pp, needp * sizeof(double)));
+                    s->rp_pp_cap = needp;
+                }
+                RL_HIP(hipMemsetAsync(s->rp_pp, 0, needp * sizeof(double), st));
+                mb.fuse_p = nrhs;                 // (the head kernel's grid)
+                mb.pc = s->rp_pp;
+                mb.np = np;
+                mb.partA[0] = s->rp_pp + (size_t)nrhs * RL_RP_PCW;
+                mb.partA[1] = mb.partA[0] + (size_t)nrhs * np;
+                mb.partC = mb.partA[1] + (size_t)nrhs * np;
+                trace_once("minres round: P inside the row-polynomial expansion (k_minres2_ph)");
+            }
         }
         RL_LAUNCH(k_minres2_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], mb);
         if (mb.poly_part != nullptr)        // projection of W^T y_0 for the first round's P

@@ -1787,9 +1787,16 @@ def check_row_polynomial_form():
             # rounds with B as its own kernel: the whole batch (several vector blocks, a lone
             # last vector when k = 16 j + 1) and one rank's share of 17
             def solve(nofuse, kk, maxiter, tol=1e-6):
+                # nofuse: True -- B and P as kernels of their own; False -- B inside the projection,
+                # P as its own kernel (the default since round 4); 'p' -- B inside the projection
+                # AND P inside the expansion (round 5: k_minres2_ph, k_rp_expand<.., true>; parity
+                # held here, off by default: slower, rl_rowpoly.h RpPFuse)
                 os.environ.pop('RUNLMC_NO_RP', None)
                 os.environ.pop('RUNLMC_NO_RP_FUSE', None)
-                if nofuse:
+                os.environ.pop('RUNLMC_RP_PFUSE', None)
+                if nofuse == 'p':
+                    os.environ['RUNLMC_RP_PFUSE'] = '1'
+                elif nofuse:
                     os.environ['RUNLMC_NO_RP_FUSE'] = '1'
                 K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (W, WT)}, lens)
                 op = K.device_operator()
@@ -1797,10 +1804,15 @@ def check_row_polynomial_form():
                 Bm = torch.from_numpy(np.tile(V, (2, 1))[:kk]).to(op.device)
                 out = solve_batch(op, Bm, tol=tol, maxiter=maxiter, lanczos_cap=8)
                 os.environ.pop('RUNLMC_NO_RP_FUSE', None)
+                os.environ.pop('RUNLMC_RP_PFUSE', None)
                 return out[0].cpu().numpy(), np.asarray(out[1]), np.asarray(out[3]), out[4]
             for kk in (min(k, 49), 17):
                 Xf, itf, stf, lzf = solve(False, kk, 5)
                 Xn, itn, stn, lzn = solve(True, kk, 5)
+                Xp, itp, stp, lzp = solve('p', kk, 5)
+                assert np.abs(Xp - Xn).max() <= 1e-12 * np.abs(Xn).max(), (kk, np.abs(Xp - Xn).max())
+                assert np.array_equal(itp, itn) and np.array_equal(stp, stn)
+                assert np.abs(lzp - lzn).max() <= 1e-12 * np.abs(lzn).max()
                 assert np.abs(Xf - Xn).max() <= 1e-12 * np.abs(Xn).max(), (kk, np.abs(Xf - Xn).max())
                 assert np.array_equal(itf, itn) and np.array_equal(stf, stn)
                 # (the recorded Lanczos coefficients -- the log-determinant's input: beta comes
@@ -1812,6 +1824,9 @@ def check_row_polynomial_form():
                 # coefficient 0, their vectors rewritten unchanged) while the others go on
                 Xf, itf, stf, _ = solve(False, 19, 400, tol=1e-3)
                 Xn, itn, stn, _ = solve(True, 19, 400, tol=1e-3)
+                Xp, itp, stp, _ = solve('p', 19, 400, tol=1e-3)
+                assert np.array_equal(stp, stn) and np.abs(itp - itn).max() <= 6, (itp, itn)
+                assert np.abs(Xp - Xn).max() <= 1e-4 * np.abs(Xn).max()
                 assert np.array_equal(stf, stn) and (stf == 1).all(), (stf, stn)
                 assert len(set(itf.tolist())) > 1 and np.abs(itf - itn).max() <= 6, (itf, itn)
                 assert np.abs(Xf - Xn).max() <= 1e-4 * np.abs(Xn).max()

@@ -9,6 +9,7 @@ that may import oracle/).  Run on the GPU box:
     python tests/report_iteration_parity.py [c2|c1|c5]
 """
 import os
+os.environ.setdefault('OMP_NUM_THREADS', '1')   # reference bench.py:7 (a BLAS thread pool of cpu_count() threads under a cgroup quota of 16 cores made the round-4 record 8.5x slow)
 import sys
 import time
 

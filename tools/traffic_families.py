@@ -1,6 +1,6 @@
 """HBM-side bytes per grid product of one kernel family, from rocprofv3 PMC passes
 over tools/one_family.py (FETCH_SIZE and WRITE_SIZE in separate runs), into
-profiles/r04/traffic.json under the key bench.py looks up.
+profiles/r05/traffic.json under the key bench.py looks up.
 
     python tools/traffic_families.py <pmc dir> <config> <batch> <family> <calls> <label>
 
@@ -43,7 +43,7 @@ for name, c in tot.items():
                     'launches_counted': cnt[name].get('FETCH_SIZE', 0)}
     total += rd + wr
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                        'profiles', 'r04', 'traffic.json')
+                        'profiles', 'r05', 'traffic.json')
 try:
     table = json.load(open(out_path))
 except (OSError, ValueError):
