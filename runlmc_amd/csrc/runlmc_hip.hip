@@ -418,6 +418,7 @@ struct rl_gridop {
     size_t lr_zhat_cap = 0;
     double* lr_scr = nullptr;   // set-time scratch: 3 vectors of D*m + partial maxima
     double* lr_pw = nullptr;    // the power iteration's vectors (lr_verify (iv))
+    double* lr_sel = nullptr;   // ... and the selector couplings of its groups of tops
     std::vector<double> lr_vstat;   // host [max_tops][4]: the last verification's measurements per top
                                     // (trial ratio, tail ratio, ||E v||, ||T w||: rl_gridop_form_stats)
     double* lr_Cc = nullptr;    // dev [max_tops][r][r]: C of the polynomial tops only, contiguous
@@ -842,7 +843,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
-                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_Cc, g->lr_Bc,
+                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_sel, g->lr_Cc, g->lr_Bc,
                     g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pwp, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
                     g->sf_E, g->sf_Cin, g->sf_next};
     for (void* p : ptrs)
@@ -1978,7 +1979,7 @@ k_lr_rowmax(const double* __restrict__ V, int m, double* __restrict__ out) {
     if (tid == 0) out[blockIdx.x] = red[0];
 }
 // Power iteration of the verification's operator-norm bound (below): two tiny kernels per
-// vector and step, no host round trip.
+// vector block and step, no host round trip.
 //   k_lr_pw_diff   out = a - b (b may be NULL: out = a), part[block] = sum of out^2
 //   k_lr_pw_scale  v = d / ||d||_2 (d itself when the norm is 0 or not finite), *rec = ||d||_2
 //                  -- every workgroup sums the RL_LR_NB partials in the same fixed order
@@ -1989,14 +1990,17 @@ k_lr_rowmax(const double* __restrict__ V, int m, double* __restrict__ out) {
 #else
 #define RL_LR_PWB 512          // workgroups of its vector kernels (64: 20 us per kernel at C5, 10^6 entries)
 #endif
+//   (grid (RL_LR_PWB, D): row a of the D rows of length m is its own vector -- every row
+//   iterates on the top row the selectors of lr_verify gave it)
 __global__ void __launch_bounds__(256)
-k_lr_pw_diff(const double* a, const double* b, size_t n, double* out, double* __restrict__ part) {
+k_lr_pw_diff(const double* a, const double* b, int m, double* out, double* __restrict__ part) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);       // [256]
+    const size_t off = (size_t)blockIdx.y * m;
     double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double d = b ? a[i] - b[i] : a[i];
-        out[i] = d;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        const double d = b ? a[off + i] - b[off + i] : a[off + i];
+        out[off + i] = d;
         s = fma(d, d, s);
     }
     const int tid = threadIdx.x;
@@ -2006,24 +2010,28 @@ k_lr_pw_diff(const double* a, const double* b, size_t n, double* out, double* __
         if (tid < w) red[tid] += red[tid + w];
         __syncthreads();
     }
-    if (tid == 0) part[blockIdx.x] = red[0];
+    if (tid == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
 }
+//   rec: stat + top_of_row[a] * stride + off  (rows without a top: nothing recorded)
 __global__ void __launch_bounds__(256)
-k_lr_pw_scale(const double* __restrict__ d, size_t n, const double* __restrict__ part, int nparts,
-              double* __restrict__ v, double* __restrict__ rec) {
+k_lr_pw_scale(const double* __restrict__ d, int m, const double* __restrict__ part,
+              double* __restrict__ v, double* __restrict__ stat, const int* __restrict__ top_of_row,
+              int stride, int off) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);       // [1]
+    const int row = blockIdx.y;
     if (threadIdx.x == 0) {
         double s = 0.0;
-        for (int b = 0; b < nparts; ++b) s += part[b];
+        for (int b = 0; b < (int)gridDim.x; ++b) s += part[(size_t)row * gridDim.x + b];
         red[0] = sqrt(s);
     }
     __syncthreads();
     const double nrm = red[0];
     const double inv = (nrm > 0.0 && nrm <= 1e300) ? 1.0 / nrm : 1.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        v[i] = d[i] * inv;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *rec = nrm;
+    const size_t o = (size_t)row * m;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) v[o + i] = d[o + i] * inv;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && top_of_row[row] >= 0)
+        stat[(size_t)top_of_row[row] * stride + off] = nrm;
 }
 // per-top verdict record on the device: RL_LR_NB x 3 comparison partials, the row maxima
 // of T Phi_j, j < RL_LR_RMAX + 16, then the power iteration's norms ||E v_k||, ||T w_k||
@@ -2060,6 +2068,9 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
         // verdict records in front of C, so that one copy brings both back
         double* cs = nullptr;
         RL_HIP(hipMalloc((void**)&cs, (size_t)g->max_tops * (RL_LR_STATW + RL_LR_RMAX * RL_LR_RMAX) * sizeof(double)));
+        // (zeros: the grouped power iteration multiplies the C of tops that are no candidates by a
+        // zero coupling -- they have to be finite)
+        RL_HIP(hipMemset(cs, 0, (size_t)g->max_tops * (RL_LR_STATW + RL_LR_RMAX * RL_LR_RMAX) * sizeof(double)));
         g->lr_stat = cs;
         g->lr_C = cs + (size_t)g->max_tops * RL_LR_STATW;
         RL_HIP(hipMalloc((void**)&g->lr_Cc, (size_t)g->max_tops * RL_LR_RMAX * RL_LR_RMAX * sizeof(double)));
@@ -2072,7 +2083,11 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
         const size_t nvr = (RL_LR_RMAX + RL_LR_EXTRA + D - 1) / D;
         RL_HIP(hipMalloc((void**)&g->lr_scr, (3 + nvr) * vec * sizeof(double)));
         // power iteration: [v | w], [T v | T w], partial sums
-        RL_HIP(hipMalloc((void**)&g->lr_pw, (4 * vec + 2 * RL_LR_PWB) * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&g->lr_pw, (4 * vec + 2 * (size_t)RL_LR_PWB * D) * sizeof(double)));
+        // selector couplings of the grouped power iteration, per group of D candidate tops:
+        // kappa [Q][D] | B [Q][D][D] | top of each output row [D] (ints, padded to doubles)
+        RL_HIP(hipMalloc((void**)&g->lr_sel, (size_t)g->max_tops *
+                         ((size_t)g->max_tops * D + (size_t)g->max_tops * D * D + D) * sizeof(double)));
         std::vector<double> xr(vec);
         unsigned long long st = 0x9E3779B97F4A7C15ull;          // fixed seed: same trials every time
         for (size_t i = 0; i < vec; ++i) {
@@ -2088,6 +2103,28 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
     hipStream_t st = nullptr;
     std::vector<double> back;
     std::vector<char> best;
+    // candidate tops in groups of D, each group's selectors (see (iv) below)
+    std::vector<int> cand;
+    for (int q = 0; q < Q; ++q)
+        if (want[q]) cand.push_back(q);
+    const size_t sel_stride = (size_t)Q * D + (size_t)Q * D * D + D;
+    {
+        const size_t ngroups = (cand.size() + D - 1) / D;
+        std::vector<double> sel(std::max<size_t>(1, ngroups) * sel_stride, 0.0);
+        for (size_t grp = 0; grp < ngroups; ++grp) {
+            double* ks = sel.data() + grp * sel_stride;
+            double* bs = ks + (size_t)Q * D;
+            int* rows = reinterpret_cast<int*>(bs + (size_t)Q * D * D);
+            for (int a = 0; a < D; ++a) rows[a] = -1;
+            for (int a = 0; a < D && grp * D + a < cand.size(); ++a) {
+                const int q = cand[grp * D + a];
+                ks[(size_t)q * D + a] = 1.0;
+                bs[((size_t)q * D + a) * D + a] = 1.0;
+                rows[a] = q;
+            }
+        }
+        RL_HIP(hipMemcpy(g->lr_sel, sel.data(), sel.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     for (int r : {24, 32, 36, 40, 48}) {
         g->lr_r = r;
         const int nvr = (r + RL_LR_EXTRA + D - 1) / D, nrows = nvr * D;
@@ -2124,32 +2161,42 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
             RL_TRY(lr_apply(g, xr, y2, 1, q, 1, g->lr_eye, st));
             RL_LAUNCH(k_lr_compare, dim3(RL_LR_NB), dim3(256), 3 * 256 * sizeof(double), st,
                       (const double*)y1, (const double*)y2, vec, stat);
-            // (iv) power iteration on E = T - Phi C Phi^T (vector v) and on T (vector w), both
-            // from the trial vector; the pair [v | w] is ONE two-vector transform product
-            {
-                double* vw = g->lr_pw;
-                double* Tvw = vw + 2 * vec;
-                double* parts = Tvw + 2 * vec;
-                double* rec = stat + RL_LR_NB * 3 + RL_LR_RMAX + 16;
-                RL_HIP(hipMemcpyAsync(vw, xr, vec * sizeof(double), hipMemcpyDeviceToDevice, st));
-                RL_HIP(hipMemcpyAsync(vw + vec, xr, vec * sizeof(double), hipMemcpyDeviceToDevice, st));
-                for (int k = 0; k < RL_LR_NPOW; ++k) {
-                    g->lr_bypass = true;
-                    rc = mvm_with_mix(g, mp, vw, Tvw, 2, st);
-                    g->lr_bypass = false;
-                    if (rc != RL_OK) return rc;
-                    RL_TRY(lr_apply(g, vw, y2, 1, q, 1, g->lr_eye, st));
-                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_PWB), dim3(256), 256 * sizeof(double), st,
-                              (const double*)Tvw, (const double*)y2, vec, Tvw, parts);
-                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_PWB), dim3(256), sizeof(double), st,
-                              (const double*)Tvw, vec, (const double*)parts, RL_LR_PWB, vw, rec + k);
-                    RL_LAUNCH(k_lr_pw_diff, dim3(RL_LR_PWB), dim3(256), 256 * sizeof(double), st,
-                              (const double*)(Tvw + vec), (const double*)nullptr, vec, Tvw + vec,
-                              parts + RL_LR_PWB);
-                    RL_LAUNCH(k_lr_pw_scale, dim3(RL_LR_PWB), dim3(256), sizeof(double), st,
-                              (const double*)(Tvw + vec), vec, (const double*)(parts + RL_LR_PWB),
-                              RL_LR_PWB, vw + vec, rec + RL_LR_NPOW + k);
-                }
+        }
+        // (iv) power iteration on E = T - Phi C Phi^T (vector v) and on T (vector w), both from
+        // the trial vector.  ALL candidate tops at once: selector couplings give output row a
+        // the top row of slot a (kappa_q = e_a for the transform kernels, B_q = e_a e_a^T for
+        // the polynomial form), so one two-vector transform product [v | w] and one
+        // polynomial product advance every top's iteration, D tops per group -- per step ten
+        // launches whatever Q (one group per step and top, as first built: 2.9 ms per update
+        // at C2 against 0.42 for the sampled tests alone).
+        for (size_t grp = 0; grp * D < cand.size(); ++grp) {
+            double* vw = g->lr_pw;
+            double* Tvw = vw + 2 * vec;
+            double* parts = Tvw + 2 * vec;
+            const double* ksel = g->lr_sel + grp * sel_stride;
+            const double* bsel = ksel + (size_t)Q * D;
+            const int* rows = reinterpret_cast<const int*>(bsel + (size_t)Q * D * D);
+            MixParams mps{Q, 0, g->spec, nullptr, nullptr, nullptr, ksel, nullptr, nullptr};
+            RL_HIP(hipMemcpyAsync(vw, xr, vec * sizeof(double), hipMemcpyDeviceToDevice, st));
+            RL_HIP(hipMemcpyAsync(vw + vec, xr, vec * sizeof(double), hipMemcpyDeviceToDevice, st));
+            const int recE = RL_LR_NB * 3 + RL_LR_RMAX + 16;
+            for (int k = 0; k < RL_LR_NPOW; ++k) {
+                g->lr_bypass = true;
+                int rc = mvm_with_mix(g, mps, vw, Tvw, 2, st);
+                g->lr_bypass = false;
+                if (rc != RL_OK) return rc;
+                RL_TRY(lr_apply(g, vw, y2, 1, 0, Q, bsel, st));
+                const dim3 pg(RL_LR_PWB, D);
+                RL_LAUNCH(k_lr_pw_diff, pg, dim3(256), 256 * sizeof(double), st, (const double*)Tvw,
+                          (const double*)y2, m, Tvw, parts);
+                RL_LAUNCH(k_lr_pw_scale, pg, dim3(256), sizeof(double), st, (const double*)Tvw, m,
+                          (const double*)parts, vw, g->lr_stat, rows, RL_LR_STATW, recE + k);
+                RL_LAUNCH(k_lr_pw_diff, pg, dim3(256), 256 * sizeof(double), st,
+                          (const double*)(Tvw + vec), (const double*)nullptr, m, Tvw + vec,
+                          parts + (size_t)RL_LR_PWB * D);
+                RL_LAUNCH(k_lr_pw_scale, pg, dim3(256), sizeof(double), st,
+                          (const double*)(Tvw + vec), m, (const double*)(parts + (size_t)RL_LR_PWB * D),
+                          vw + vec, g->lr_stat, rows, RL_LR_STATW, recE + RL_LR_NPOW + k);
             }
         }
         RL_HIP(hipGetLastError());
