@@ -445,6 +445,91 @@ __device__ __forceinline__ void sf_chunk_state(const double* __restrict__ E, con
     }
 }
 
+// k_sf_scan1<NS>: the same, the chunk states of a thread's segment read ONCE and kept in
+// registers for both walks (round 5; grids of at most RL_SF_SEGMAX * RL_SF_NSEG chunks = 131 072
+// points, C5: 196 chunks, 7 per segment).  A mixed channel's chunk state is a sum over D rows of
+// E: read twice, these were half of k_sf_scan's traffic (472 MB per C5 Matern product).
+#define RL_SF_SEGMAX 8
+template <int NS>
+__global__ void __launch_bounds__(256)
+k_sf_scan1(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams sp,
+           double* __restrict__ Cin, int* __restrict__ next_tile) {
+    RL_SMEM(smem);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *next_tile = 0;
+    constexpr int NCD = 8, NSEG = RL_SF_NSEG, SM = RL_SF_SEGMAX;
+    double* agg = reinterpret_cast<double*>(smem);       // [NSEG][NCD][NS]
+    const int NF = sp.NF, nchan = D * NF + sp.nfac, ncd = 2 * nchan;
+    const int tid = threadIdx.x, cdl = tid & (NCD - 1), seg = tid / NCD, v = blockIdx.y;
+    const int cdr = blockIdx.x * NCD + cdl;
+    const bool live = cdr < ncd;
+    const int cd = live ? cdr : ncd - 1;
+    const int dir = cd & 1, chan = cd >> 1;
+    const bool diag = chan < D * NF;
+    const int f = diag ? 0 : chan - D * NF;
+    const int j = diag ? chan % NF : sp.facJ[f];
+    const int a = diag ? chan / NF : 0;
+    const double rG = sp.tops[j].rG, n = (double)RL_SF_G;
+    const int nrows = nvec * D, row0 = v * D;
+    const int seglen = (nchunks + NSEG - 1) / NSEG;          // <= SM (host)
+    const int p0 = seg * seglen < nchunks ? seg * seglen : nchunks;
+    const int p1 = p0 + seglen < nchunks ? p0 + seglen : nchunks;
+    // the segment's chunk states, requested together (clamped chunks: zero weight)
+    double es[SM][NS];
+#pragma unroll
+    for (int k = 0; k < SM; ++k) {
+        const int p = p0 + k < p1 ? p0 + k : (p1 > 0 ? p1 - 1 : 0);
+        const int c = dir == 0 ? p : nchunks - 1 - p;
+        sf_chunk_state<NS>(E, sp, c < nchunks ? c : nchunks - 1, nrows, row0, D, diag, a, f, j, dir, es[k]);
+    }
+    double st[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < SM; ++k) {
+        if (p0 + k < p1) {
+            double e[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) e[q] = es[k][q];
+            sf_carry<NS>(e, st, rG, n);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) st[q] = e[q];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) agg[(seg * NCD + cdl) * NS + k] = st[k];
+    __syncthreads();
+    const double rL = sp.tops[j].rL;
+    const double nL = n * seglen;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st[k] = 0.0;
+    for (int s = 0; s < seg; ++s) {
+        double e[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) e[k] = agg[(s * NCD + cdl) * NS + k];
+        sf_carry<NS>(e, st, rL, nL);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) st[k] = e[k];
+    }
+#pragma unroll
+    for (int k = 0; k < SM; ++k) {
+        if (p0 + k < p1) {
+            const int p = p0 + k;
+            const int c = dir == 0 ? p : nchunks - 1 - p;
+            if (live) {
+                double* dst = Cin + ((((size_t)c * nvec + v) * nchan + chan) * 2 + dir) * NS;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) dst[q] = st[q];
+            }
+            double e[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) e[q] = es[k][q];
+            sf_carry<NS>(e, st, rG, n);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) st[q] = e[q];
+        }
+    }
+}
+
 template <int NS>
 __global__ void __launch_bounds__(256)
 k_sf_scan(const double* __restrict__ E, int nchunks, int nvec, int D, SfParams sp,

@@ -97,6 +97,7 @@ struct RlKnobs {
     int v1p_min = 0;             // RUNLMC_V1P_MIN
     bool no_lowrank = false;     // RUNLMC_NO_LOWRANK: no polynomial-subspace form
     bool no_filter = false;      // RUNLMC_NO_FILTER: no recursive-filter form
+    bool sf_scan2 = false;       // RUNLMC_SF_SCAN2: the chunk chain reading the chunk states twice (k_sf_scan) on short grids too
     bool sf_carries1 = false;    // RUNLMC_SF_CARRIES1: the chunk states without the parity trick (k_sf_carries<2>)
     bool no_lr_bound = false;    // RUNLMC_NO_LR_BOUND: the polynomial verification without its operator-norm
                                  // bound (tests: what rounds 2-4 accepted)
@@ -175,6 +176,7 @@ static RlKnobs read_knobs() {
     k.no_filter = flag("RUNLMC_NO_FILTER");
     k.no_lr_bound = flag("RUNLMC_NO_LR_BOUND");
     k.sf_carries1 = flag("RUNLMC_SF_CARRIES1");
+    k.sf_scan2 = flag("RUNLMC_SF_SCAN2");
     k.poly_round = flag("RUNLMC_POLY_ROUND");
     k.no_poly_round = flag("RUNLMC_NO_POLY_ROUND");
     k.lr_min = num("RUNLMC_LR_MIN", -1);
@@ -1845,8 +1847,12 @@ static int sf_launch(rl_gridop* g, const SfParams& sp, const double* blob, const
                   ((size_t)sp.NF * (RL_SF_G + 1) + 256) * sizeof(double), st, X, nrows, g->m, sp.NF,
                   sp.pw, rpw, g->sf_E);
     const int ncd = 2 * (D * sp.NF + sp.nfac);
-    RL_LAUNCH((k_sf_scan<NS>), dim3((ncd + 7) / 8, nvec), dim3(256), 256 * NS * sizeof(double),
-              st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin, g->sf_next);
+    if ((nch + RL_SF_NSEG - 1) / RL_SF_NSEG <= RL_SF_SEGMAX && !g->kn.sf_scan2)
+        RL_LAUNCH((k_sf_scan1<NS>), dim3((ncd + 7) / 8, nvec), dim3(256), 256 * NS * sizeof(double),
+                  st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin, g->sf_next);
+    else
+        RL_LAUNCH((k_sf_scan<NS>), dim3((ncd + 7) / 8, nvec), dim3(256), 256 * NS * sizeof(double),
+                  st, (const double*)g->sf_E, nch, nvec, D, sp, g->sf_Cin, g->sf_next);
     // persistent workgroups of four waves, two per CU (256 registers a lane: a segment's
     // 32 points and the states of five filters; the tile's LDS allows two at C5), each
     // walking every (2 x CUs)-th tile.  (A workgroup of five waves puts two on the first
@@ -2018,15 +2024,19 @@ k_lr_pw_scale(const double* __restrict__ d, int m, const double* __restrict__ pa
               double* __restrict__ v, double* __restrict__ stat, const int* __restrict__ top_of_row,
               int stride, int off) {
     RL_SMEM(smem);
-    double* red = reinterpret_cast<double*>(smem);       // [1]
-    const int row = blockIdx.y;
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < (int)gridDim.x; ++b) s += part[(size_t)row * gridDim.x + b];
-        red[0] = sqrt(s);
-    }
+    double* red = reinterpret_cast<double*>(smem);       // [256]
+    const int row = blockIdx.y, tid = threadIdx.x;
+    // (every workgroup sums the row's partials itself, in the same fixed order: strided per
+    // thread, then a tree -- one thread adding 512 of them in turn was 90 us of this kernel)
+    double sp = 0.0;
+    for (int b = tid; b < (int)gridDim.x; b += 256) sp += part[(size_t)row * gridDim.x + b];
+    red[tid] = sp;
     __syncthreads();
-    const double nrm = red[0];
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    const double nrm = sqrt(red[0]);
     const double inv = (nrm > 0.0 && nrm <= 1e300) ? 1.0 / nrm : 1.0;
     const size_t o = (size_t)row * m;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) v[o + i] = d[o + i] * inv;
@@ -2189,12 +2199,12 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
                 const dim3 pg(RL_LR_PWB, D);
                 RL_LAUNCH(k_lr_pw_diff, pg, dim3(256), 256 * sizeof(double), st, (const double*)Tvw,
                           (const double*)y2, m, Tvw, parts);
-                RL_LAUNCH(k_lr_pw_scale, pg, dim3(256), sizeof(double), st, (const double*)Tvw, m,
+                RL_LAUNCH(k_lr_pw_scale, pg, dim3(256), 256 * sizeof(double), st, (const double*)Tvw, m,
                           (const double*)parts, vw, g->lr_stat, rows, RL_LR_STATW, recE + k);
                 RL_LAUNCH(k_lr_pw_diff, pg, dim3(256), 256 * sizeof(double), st,
                           (const double*)(Tvw + vec), (const double*)nullptr, m, Tvw + vec,
                           parts + (size_t)RL_LR_PWB * D);
-                RL_LAUNCH(k_lr_pw_scale, pg, dim3(256), sizeof(double), st,
+                RL_LAUNCH(k_lr_pw_scale, pg, dim3(256), 256 * sizeof(double), st,
                           (const double*)(Tvw + vec), m, (const double*)(parts + (size_t)RL_LR_PWB * D),
                           vw + vec, g->lr_stat, rows, RL_LR_STATW, recE + RL_LR_NPOW + k);
             }

@@ -1824,12 +1824,16 @@ def check_row_polynomial_form():
                 # coefficient 0, their vectors rewritten unchanged) while the others go on
                 Xf, itf, stf, _ = solve(False, 19, 400, tol=1e-3)
                 Xn, itn, stn, _ = solve(True, 19, 400, tol=1e-3)
-                Xp, itp, stp, _ = solve('p', 19, 400, tol=1e-3)
-                assert np.array_equal(stp, stn) and np.abs(itp - itn).max() <= 6, (itp, itn)
-                assert np.abs(Xp - Xn).max() <= 1e-4 * np.abs(Xn).max()
                 assert np.array_equal(stf, stn) and (stf == 1).all(), (stf, stn)
                 assert len(set(itf.tolist())) > 1 and np.abs(itf - itn).max() <= 6, (itf, itn)
                 assert np.abs(Xf - Xn).max() <= 1e-4 * np.abs(Xn).max()
+                from runlmc_amd import _lib as _l
+                if _l.get_library().is_hip:
+                    # (GPU only -- 400 rounds of 19 systems cost the emulator a minute: frozen
+                    # systems under the opt-in P fusion, whose expansion must not touch them)
+                    Xp, itp, stp, _ = solve('p', 19, 400, tol=1e-3)
+                    assert np.array_equal(stp, stn) and np.abs(itp - itn).max() <= 6, (itp, itn)
+                    assert np.abs(Xp - Xn).max() <= 1e-4 * np.abs(Xn).max()
             make = {'rbf': RBFSpec, 'periodic': StdPeriodicSpec}
             spec = KernelSpec(D, [make[d_[0]](*d_[1:]) for d_ in p.kern_desc], list(p.coreg_vecs),
                               list(p.coreg_diags), p.noise)
