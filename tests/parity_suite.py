@@ -943,6 +943,23 @@ def check_polynomial_bound():
         assert f1 == [0] and r1 == 0, out[False]          # the bound rejects the row
         assert sig_e1 > 2e-13 * sig_t1
         assert err1 < 1e-12, err1
+        # more top rows than outputs (Q = 5, D = 2: the grouped power iteration walks three
+        # groups of selector couplings): every honest row accepted, the product the oracle's
+        rng = np.random.RandomState(5)
+        tops5 = np.array([np.exp(-0.5 * (a_ * t) ** 2) for a_ in (1.0, 1.4, 1.8, 2.2, 2.6)])
+        A5 = [rng.randn(1, 2) for _ in range(5)]
+        k5 = [np.abs(rng.randn(2)) + 0.1 for _ in range(5)]
+        g5 = GridOp(2, m, 5)
+        g5.set_lmc(tops5, A5, k5)
+        g5.set_form_gate(0)
+        assert g5.top_forms() == ([1] * 5, True)
+        for q in range(5):
+            sig_e, sig_t = g5.form_stats(q)[2:]
+            assert 0 < sig_e < 1e-13 * sig_t, (q, sig_e, sig_t)
+        X5 = rng.randn(3, 2 * m)
+        ref5 = np.array([ops.grid_sum_matvec(ops.coreg_mats(A5, k5),
+                                             [ops.BTTBOracle(tp) for tp in tops5], v) for v in X5])
+        _close(g5.matmat_host(X5), ref5, 1e-11)
         # an honest row is far inside the bound (RBF: the difference is the transform
         # kernels' own roundoff)
         g = GridOp(1, m, 1)
@@ -1053,6 +1070,18 @@ def check_filter_form():
             flt = _poly_product(g, X)
             _close(flt, ref)
             _close(flt, fft, 1e-12)
+            if (D, Q) in ((2, 2), (3, 5)):
+                # the chunk chain that reads its chunk states twice (k_sf_scan: the kernel of
+                # grids above 131 072 points, where a segment's states do not fit the registers
+                # of k_sf_scan1) and the chunk states without the parity trick (k_sf_carries<2>)
+                for knob in ('RUNLMC_SF_SCAN2', 'RUNLMC_SF_CARRIES1'):
+                    os.environ[knob] = '1'
+                    try:
+                        g2 = GridOp(D, m, Q)
+                        g2.set_lmc(mat, A, kap)
+                        _close(_poly_product(g2, X), flt, 1e-13)
+                    finally:
+                        os.environ.pop(knob, None)
             g.set_dense(mat, np.array(Bs))
             _close(_poly_product(g, X), ref)
             # single tops: a Matern row, then the handle the gradient uses (k and dk/dgamma)
