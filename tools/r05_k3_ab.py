@@ -1,7 +1,10 @@
 """GPU box: the row kernel of the transform path, k3_rows_mix<D <= 5, ..>, at 128 registers (four waves
 per SIMD, 14-16 registers spilled) against a build at 168 (three waves, no spill: -DRL_K3_WPE_SMALL=3,
 runlmc_amd/csrc/librunlmc_hip_k3w3.so), same box, alternating: C2 (D=4, Q=3, m=5000) products on the
-transform kernels at 17 / 256 / 1024 vectors.   python tools/r05_k3_ab.py"""
+transform kernels at 17 / 256 / 1024 vectors.  The second library is an experiment build, not kept in the tree:
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRL_K3_WPE_SMALL=3 \
+          -o runlmc_amd/csrc/librunlmc_hip_k3w3.so runlmc_amd/csrc/runlmc_hip.hip
+    python tools/r05_k3_ab.py          (result: profiles/r05/k3_registers_ab.txt -- no difference)"""
 import os
 import sys
 import time
