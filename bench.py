@@ -538,7 +538,7 @@ def product_form(g, batch, D, m):
                                'kernels), D=%d' % (rank_poly, D))
     if all(f == 2 for f in forms):
         return 'filter', names, ('grid MVM, recursive-filter form of exponential-polynomial top '
-                                 'rows (k_sf_carries -> k_sf_scan -> k_sf_apply: one lane per (row, '
+                                 'rows (k_sf_carries2 -> k_sf_scan1 -> k_sf_apply: one lane per (row, '
                                  '32-point segment) runs the recurrences, segments chained over DPP '
                                  'rows, persistent workgroups), D=%d' % D)
     return 'filter+poly', names, ('grid MVM, filter part (k_sf_*) + polynomial part (k_lr_*, '

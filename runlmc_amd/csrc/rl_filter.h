@@ -18,12 +18,15 @@
 // So  K x = sum_q B_q (x) T_q x  for such tops is a block-parallel scan that
 // reads x and writes y -- no zero-padded complex intermediates, no transform:
 //
-//   k_sf_carries   per chunk of RL_SF_G grid points and row: the state the chunk
-//                  alone leaves at its last point (F) and at its first point (H)
-//                  -- 2 NS weighted sums per filter, lanes along the grid;
-//   k_sf_scan      per (vector, channel, direction): the chunks' states chained
-//                  ( state' = rho^G (F0, F1 + G F0, F2 + 2 G F1 + G^2 F0) + chunk ),
-//                  which gives every chunk the state it starts from;
+//   k_sf_carries2  per chunk of RL_SF_G grid points and row: the state the chunk
+//   (k_sf_carries  alone leaves at its last point (F) and at its first point (H)
+//    for three     -- 2 NS weighted sums per filter, lanes along the grid; two-state
+//    states)       filters: sums and differences of a point and its mirror halve the
+//                  multiply-adds (round 5);
+//   k_sf_scan1     per (vector, channel, direction): the chunks' states chained
+//   (k_sf_scan     ( state' = rho^G (F0, F1 + G F0, F2 + 2 G F1 + G^2 F0) + chunk ),
+//    above 131 072 which gives every chunk the state it starts from; a segment's chunk
+//    points)       states read once and kept in registers for both walks (round 5);
 //   k_sf_apply     per (vector, chunk): the D rows of the chunk in LDS, rank-one
 //                  factors mixed there (u_f = A_f . x); a row is cut into 16 segments
 //                  of 32 points and ONE LANE runs the recurrences of a (row, segment)
