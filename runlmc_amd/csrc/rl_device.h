@@ -26,6 +26,44 @@
 
 #include <stdint.h>
 
+// A pointer to data that NO thread of the running kernel writes, read at a wave-uniform
+// address: the constant address space makes the compiler fetch it through the scalar
+// unit (s_load into SGPRs).  Needed where a kernel also stores through pointers the
+// compiler cannot tell apart from this one (struct members): there it falls back to one
+// vector load per lane and drains the vector-memory counter around it.
+#if defined(RL_EMU)
+typedef const double* rl_kconst;
+#define RL_KCONST(p) (p)
+#else
+typedef const double __attribute__((address_space(4)))* rl_kconst;
+#define RL_KCONST(p) ((rl_kconst)(unsigned long long)(p))
+#endif
+
+
+// One element of a row block addressed as  wave-uniform base + per-lane byte offset  (both
+// < 2^31): a buffer access -- the base lives in scalar registers, ONE offset register serves
+// every access of a loop over bases, and an offset at or past `nbytes` reads 0 / stores
+// nothing (the hardware's range check: no clamped index, no masked store).
+#if defined(RL_EMU)
+__device__ __forceinline__ double rl_row_load(const double* base, unsigned nbytes, unsigned off) {
+    return off < nbytes ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off) : 0.0;
+}
+__device__ __forceinline__ void rl_row_store(double* base, unsigned nbytes, unsigned off, double v) {
+    if (off < nbytes) *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v;
+}
+#else
+typedef unsigned int rl_u32x2 __attribute__((ext_vector_type(2)));
+#define RL_BUFFER_WORD3 0x00020000       // raw buffer, 32-bit data format (gfx90a .. gfx950)
+__device__ __forceinline__ double rl_row_load(const double* base, unsigned nbytes, unsigned off) {
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, (int)nbytes, RL_BUFFER_WORD3);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void rl_row_store(double* base, unsigned nbytes, unsigned off, double v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)nbytes, RL_BUFFER_WORD3);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rl_u32x2, v), r, (int)off, 0, 0);
+}
+#endif
 
 // RL_TIMING (experiment builds only: python -m runlmc_amd.build --timing):
 // kernels stamp s_memtime at their phase boundaries into a global buffer that

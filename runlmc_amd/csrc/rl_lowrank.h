@@ -120,23 +120,40 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
     static_assert(RL_LR_T % G == 0, "ring length divides the chunk");
     const int slots = lr_slots(m);
     double xr[G][RB], xm[G][RB];
+    // (buffer accesses, rl_device.h: row base in scalar registers + a byte offset.  As plain
+    // loads from the const __restrict__ X the compiler folded "value carried from the previous
+    // iteration's load" into "load at the point of use" -- sixteen loads at the top of every
+    // iteration, each waited for on the spot: the ring existed in the source only.)
+    const unsigned rowbytes = (unsigned)m * 8u;
     auto request = [&](int slot, int step) {
         const int n = n_begin + lane + 64 * step;
         const int nc = n < slots ? n : slots - 1;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            xr[slot][r] = xrow[r][nc];
-            xm[slot][r] = xrow[r][m - 1 - nc];
+            xr[slot][r] = rl_row_load(xrow[r], rowbytes, (unsigned)nc * 8u);
+            xm[slot][r] = rl_row_load(xrow[r], rowbytes, (unsigned)(m - 1 - nc) * 8u);
         }
     };
+    // The first requests are issued by the loop itself, in an iteration of their own that
+    // consumes zeros (t = -G: one iteration of arithmetic more per chunk).  Issued before the
+    // loop they were pending on the way in, row by row instead of slot by slot, and the wait
+    // counts of the loop -- derived from the worse of the two ways into it -- let every
+    // iteration wait for all but two of its sixteen loads.
 #pragma unroll
-    for (int k = 0; k < G; ++k) request(k, k);
+    for (int k = 0; k < G; ++k)
+#pragma unroll
+        for (int r = 0; r < RB; ++r) xr[k][r] = xm[k][r] = 0.0;
 #pragma unroll 1
-    for (int t = 0; t < steps; t += G) {
+    for (int t = -G; t < steps; t += G) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
+#if !defined(RL_EMU)
+            // (the lane-steps stay in source order: scheduled freely, every step's values were
+            // consumed -- and waited for -- at the top of the iteration)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const int n = n_begin + lane + 64 * (t + k);
-            const int nc = n < slots ? n : slots - 1;
+            const int nc = n < slots ? (n > 0 ? n : 0) : slots - 1;     // (n < 0: the iteration of zeros)
             const double s = lr_point(nc, m);
             const double live = n < slots ? 1.0 : 0.0;
             const double pair = m - 1 - nc != nc ? live : 0.0;     // (the centre has no mirror)
@@ -272,10 +289,15 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
 // ranks on the fp64 matrix cores -- Zhat fragments in registers, the chunk's basis in
 // LDS, 16 rows x 16 slots per tile, 128-byte stores: 555 vs 330-370 us at rank 48.)
 // ---------------------------------------------------------------------------
-template <int R>
+// (ACC is a template parameter, not a run-time flag: with the read of Y behind a run-time
+// condition the compiler waited for EVERY outstanding access before each of the two stores
+// of a row -- one store in flight per wave, which is what bounded the kernel.  The plain
+// kernel has no load at all, the accumulating one loads unconditionally from the clamped
+// positions.)
+template <int R, bool ACC>
 __global__ void __launch_bounds__(256)
 k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __restrict__ beta,
-            int rows_per_block, double* __restrict__ Y, int accumulate) {
+            int rows_per_block, double* __restrict__ Y) {
     const int slots = lr_slots(m);
     // workgroups are numbered with the ROW block fastest: consecutive workgroups
     // write the same columns of different rows (measured at C5: 204-215 us against
@@ -312,7 +334,11 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
         // (accumulate: the operator's filter part has written Y already, rl_filter.h)
         double* y0 = Y + (size_t)row * m + nc;
         double* y1 = Y + (size_t)row * m + mir;
-        const double o0 = accumulate && live ? *y0 : 0.0, o1 = accumulate && pair ? *y1 : 0.0;
+        double o0 = 0.0, o1 = 0.0;
+        if constexpr (ACC) {
+            o0 = *y0;
+            o1 = *y1;
+        }
         if (live) *y0 = (ev + od) + o0;
         if (pair) *y1 = (ev - od) + o1;
     }

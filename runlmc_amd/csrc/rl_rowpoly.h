@@ -749,7 +749,7 @@ __device__ __forceinline__ int rp_output_of(const int* __restrict__ out_end, int
     return lo;
 }
 
-template <int R, bool FLY, bool FP = false>
+template <int R, bool FLY, bool FP = false, bool NOISY = true>
 __global__ void __launch_bounds__(256)
 k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n, int nvec, int D,
             const int* __restrict__ out_end, double* __restrict__ Q,
@@ -776,7 +776,11 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
     const int dfirst = RL_LR_UNIFORM(rp_output_of(out_end, D, wf < n ? wf : n - 1));
     const int dlast = RL_LR_UNIFORM(rp_output_of(out_end, D, wl));
     const int dmine = dfirst == dlast ? dfirst : rp_output_of(out_end, D, ic);
-    int v = (int)(((unsigned)stagger * blockIdx.x) % (unsigned)nvec);
+    // (Measured and dropped, round 5: a second grid dimension over groups of 4 .. 64 vectors, so
+    // that the chip works inside a few vectors' pages at a time -- 2.87-3.20 ms per C5 round
+    // against 2.83 plain, 3.64-4.18 against 3.76 with P inside: placement was not the limit.)
+    const int cnt = nvec;
+    const int voff = (int)(((unsigned)stagger * blockIdx.x) % (unsigned)cnt);
     if constexpr (FP) {
         // MINRES's P inside (RpPFuse above): q' stays in a register
         RL_SMEM(smem);
@@ -787,36 +791,53 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
         const bool live = i < n;
         const bool uni = dfirst == dlast;
         // The operands of a system (y_{r-1}, y_{r-2}, w_{k-2}, w_{k-1}, x: five loads per thread)
-        // are requested TWO systems ahead: with request and use in one iteration every
-        // iteration waited out the memory latency (2.40 ms per C5 round against 1.63 + 0.24
-        // for P and the plain expansion; a P thread has 24 loads in flight).  A frozen system
-        // moves nothing: its request goes to the addresses of the last live one (cache hits).
+        // are requested TWO systems ahead.  A frozen system moves nothing: its request goes to
+        // the addresses of the last live one (cache hits).
+        // (What the first versions of this loop lost, 2.40-2.96 ms per C5 round against 1.63 +
+        // 0.24 for P and the plain expansion, was code generation, not the order of the walk:
+        // this kernel stores through pointers the compiler cannot tell from pc and Zhat, so it
+        // fetched the wave-uniform coefficients with a vector load per lane and waited for
+        // EVERY outstanding access around them; rotating the register sets by copies made it
+        // wait for the newest request each system; per-lane 64-bit addresses reused the
+        // requests' registers -- another full wait.  With the coefficients in the constant
+        // address space (scalar loads), a ring of three register sets in a loop unrolled by
+        // three and buffer accesses (scalar base + one offset register) no wait of the loop
+        // drains the queue: 1.52 ms, the round 2.30 against 2.62.)
         struct Ops {
             double r2, r1, w1, w2, x;
         };
         auto vat = [&](int it) {                 // the it-th system this workgroup visits
-            const int vv = v + it;
-            return vv < nvec ? vv : vv - nvec;
+            const int vv = voff + it;
+            return vv < cnt ? vv : vv - cnt;
         };
+        // (a system's base address is wave-uniform and the row's byte offset fits 32 bits -- the
+        // host takes this path for n < 2^28 only: buffer accesses, rl_device.h -- scalar base,
+        // one offset register for the whole loop, rows past n read 0 and store nothing)
+        const unsigned off8 = (unsigned)i * 8u, nb8 = (unsigned)n * 8u;
         int vlive = 0;                           // (some system's rows: any valid address)
         auto request = [&](int it) {
-            int vv = it < nvec ? vat(it) : vlive;
-            if (pf.pc[(size_t)vv * RL_RP_PCW] == 0.0) vv = vlive;
+            int vv = it < cnt ? vat(it) : vlive;
+            if (RL_KCONST(pf.pc)[(size_t)vv * RL_RP_PCW] == 0.0) vv = vlive;
             else vlive = vv;
-            const size_t at = (size_t)vv * n + ic;
-            return Ops{X2[at], pf.r1[at], pf.w1[at], pf.w2[at], pf.x[at]};
+            const size_t at = (size_t)vv * n;
+            return Ops{rl_row_load(X2 + at, nb8, off8), rl_row_load(pf.r1 + at, nb8, off8),
+                       rl_row_load(pf.w1 + at, nb8, off8), rl_row_load(pf.w2 + at, nb8, off8),
+                       rl_row_load(pf.x + at, nb8, off8)};
         };
-        Ops cur = request(0), nx1 = request(1);
-        for (int it = 0; it < nvec; ++it) {
+        // (a ring of three register sets, the loop unrolled by three: rotating two sets by
+        // copies made the compiler wait for the loads just issued before every copy)
+        Ops ring[3];
+        ring[0] = request(0);
+        ring[1] = request(1);
+        auto step = [&](int it, const Ops& cur) {
             const int vv = vat(it);
-            const Ops nx2 = request(it + 2);
-            const double* c = pf.pc + (size_t)vv * RL_RP_PCW;        // wave-uniform: scalar loads
+            rl_kconst c = RL_KCONST(pf.pc) + (size_t)vv * RL_RP_PCW;        // wave-uniform: scalar loads
             double accA = 0.0, accC = 0.0;
             if (c[0] != 0.0) {
-                const size_t at = (size_t)vv * n + ic;
+                const size_t at = (size_t)vv * n;
                 double ev = 0.0, od = 0.0;
                 if (uni) {
-                    const double* z = Zhat + ((size_t)vv * D + dfirst) * R;
+                    rl_kconst z = RL_KCONST(Zhat) + ((size_t)vv * D + dfirst) * R;
 #pragma unroll
                     for (int j = 0; j + 1 < R; j += 2) {
                         ev = fma(z[j], p[j], ev);
@@ -836,20 +857,14 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
                 if (c[1] != 0.0) {
                     const double wn = (cur.r1 * c[2] - c[3] * cur.w1 - c[4] * cur.w2) * c[5];
                     const double xi = cur.x + c[6] * wn;
-                    if (live) {
-                        pf.w1[at] = wn;
-                        pf.x[at] = xi;
-                        accC = fma(xi, xi, accC);
-                    }
+                    rl_row_store(pf.w1 + at, nb8, off8, wn);
+                    rl_row_store(pf.x + at, nb8, off8, xi);
+                    accC = live ? xi * xi : 0.0;
                 }
                 const double yi = q * c[7] - c[8] * cur.r1;
-                if (live) {
-                    pf.r1[at] = yi;
-                    accA = fma(cur.r2 * c[7], yi, accA);
-                }
+                rl_row_store(pf.r1 + at, nb8, off8, yi);
+                accA = live ? (cur.r2 * c[7]) * yi : 0.0;
             }
-            cur = nx1;
-            nx1 = nx2;
 #if defined(RL_EMU)
             {
                 double* red = ws + (size_t)nvec * 8;
@@ -867,11 +882,19 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
                 ws[((size_t)it * 4 + wave) * 2 + 1] = accC;
             }
 #endif
+        };
+        for (int it0 = 0; it0 < cnt; it0 += 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (it0 + k < cnt) {
+                    ring[(k + 2) % 3] = request(it0 + k + 2);
+                    step(it0 + k, ring[k]);
+                }
+            }
         }
         __syncthreads();
-        const int v0 = (int)(((unsigned)stagger * blockIdx.x) % (unsigned)nvec);
-        for (int it = tid; it < nvec; it += 256) {
-            const int vv = v0 + it < nvec ? v0 + it : v0 + it - nvec;
+        for (int it = tid; it < cnt; it += 256) {
+            const int vv = vat(it);
 #if defined(RL_EMU)
             const double a = ws[(size_t)it * 8], cc = ws[(size_t)it * 8 + 1];
 #else
@@ -883,36 +906,48 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
         }
         return;
     }
-    // Two separate loops (not one loop with a select on the pointer: the compiler then loads
-    // the coefficients per lane in both cases -- twelve dependent 16-byte vector loads per
-    // vector, 800 us per C5 round instead of the scalar loads' 2xx)
-    if (dfirst == dlast) {
-        for (int it = 0; it < nvec; ++it) {
-            const double* z = Zhat + ((size_t)v * D + dfirst) * R;      // wave-uniform: scalar loads
-            double ev = 0.0, od = 0.0;
-#pragma unroll
-            for (int j = 0; j + 1 < R; j += 2) {
-                ev = fma(z[j], p[j], ev);
-                od = fma(z[j + 1], p[j + 1], od);
-            }
-            double acc = ev + od;
-            if (diag != nullptr) acc = fma(dg, X2[(size_t)v * n + ic], acc);
-            if (i < n) Q[(size_t)v * n + i] = acc;
-            v = v + 1 < nvec ? v + 1 : 0;
+    // Plain expansion.  The noise term's operand X2 is requested two vectors ahead through a
+    // ring of three registers (loop unrolled by three, as above) and every access is a buffer
+    // access: before, a vector's load was waited for with everything else outstanding -- the
+    // previous vector's store included, one store in flight per wave.
+    // Two instantiations of the walk (not one loop with a select on the pointer: the compiler
+    // then loads the coefficients per lane in both cases -- twelve dependent 16-byte vector
+    // loads per vector, 800 us per C5 round instead of the scalar loads' 2xx).
+    const unsigned off8 = (unsigned)i * 8u, nb8 = (unsigned)n * 8u;
+    constexpr bool noisy = NOISY;     // (diag != nullptr, known at compile time: a load behind a
+                                      // run-time condition costs the exact wait counts)
+    auto vat = [&](int it) {                     // the it-th vector this workgroup visits
+        const int vv = voff + (it < cnt ? it : cnt - 1);
+        return vv < cnt ? vv : vv - cnt;
+    };
+    auto walk = [&](auto zrow) {
+        double xr[3] = {0.0, 0.0, 0.0};
+        if constexpr (noisy) {
+            xr[0] = rl_row_load(X2 + (size_t)vat(0) * n, nb8, off8);
+            xr[1] = rl_row_load(X2 + (size_t)vat(1) * n, nb8, off8);
         }
-    } else {
-        for (int it = 0; it < nvec; ++it) {
-            const double* z = Zhat + ((size_t)v * D + dmine) * R;
-            double ev = 0.0, od = 0.0;
+        for (int it0 = 0; it0 < cnt; it0 += 3) {
 #pragma unroll
-            for (int j = 0; j + 1 < R; j += 2) {
-                ev = fma(z[j], p[j], ev);
-                od = fma(z[j + 1], p[j + 1], od);
+            for (int k = 0; k < 3; ++k) {
+                if (it0 + k < cnt) {
+                    const int vv = vat(it0 + k);
+                    if constexpr (noisy) xr[(k + 2) % 3] = rl_row_load(X2 + (size_t)vat(it0 + k + 2) * n, nb8, off8);
+                    const auto z = zrow(vv);
+                    double ev = 0.0, od = 0.0;
+#pragma unroll
+                    for (int j = 0; j + 1 < R; j += 2) {
+                        ev = fma(z[j], p[j], ev);
+                        od = fma(z[j + 1], p[j + 1], od);
+                    }
+                    double acc = ev + od;
+                    if constexpr (noisy) acc = fma(dg, xr[k], acc);
+                    rl_row_store(Q + (size_t)vv * n, nb8, off8, acc);
+                }
             }
-            double acc = ev + od;
-            if (diag != nullptr) acc = fma(dg, X2[(size_t)v * n + ic], acc);
-            if (i < n) Q[(size_t)v * n + i] = acc;
-            v = v + 1 < nvec ? v + 1 : 0;
         }
-    }
+    };
+    if (dfirst == dlast)        // wave-uniform coefficient rows: scalar loads
+        walk([&](int vv) { return RL_KCONST(Zhat) + ((size_t)vv * D + dfirst) * R; });
+    else
+        walk([&](int vv) { return Zhat + ((size_t)vv * D + dmine) * R; });
 }

@@ -111,11 +111,9 @@ struct RlKnobs {
     int rp_stagger = 7;          // RUNLMC_RP_STAGGER: k_rp_expand's workgroup b starts at vector (stagger b) mod nvec
     int rp_runlen = 0;           // RUNLMC_RP_RUNLEN: rows per run of k_rp_project (default: about n / 1024)
     bool no_rp_small = false;    // RUNLMC_NO_RP_SMALL: batches of <= 17 vectors through the general k_rp_project
-    bool rp_pfuse = false;       // RUNLMC_RP_PFUSE: MINRES's P inside the row-polynomial expansion (k_minres2_ph +
-                                 // k_rp_expand<.., true>; rl_rowpoly.h RpPFuse).  Built and parity-green in round 5,
-                                 // OFF by default: the expansion walks rows outer / systems inner, so a workgroup's
-                                 // eight streams are 2 KB bursts in 8 x nvec pages 8 MB apart -- C5 round 3.18-3.75 ms
-                                 // against 2.64-2.85 with P as its own kernel (profiles/r05/rp_pfuse_ab.txt)
+    bool rp_pfuse = true;        // RUNLMC_NO_RP_PFUSE turns off MINRES's P inside the row-polynomial expansion
+                                 // (k_minres2_ph + k_rp_expand<.., true>; rl_rowpoly.h RpPFuse): C5 round 2.30 ms
+                                 // against 2.62 with P as its own kernel (profiles/r05/rp_pfuse_ab.txt, run 3)
     bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
@@ -188,7 +186,7 @@ static RlKnobs read_knobs() {
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
-    k.rp_pfuse = flag("RUNLMC_RP_PFUSE");
+    k.rp_pfuse = !flag("RUNLMC_NO_RP_PFUSE");
     k.rp_runlen = (int)num("RUNLMC_RP_RUNLEN", 0);
     // (k_spmv_w_poly exists for ranks 24, 32 and 36: a larger value would hand it coefficients
     // of a rank it has no instantiation for)
@@ -1619,9 +1617,12 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
         const int nby = std::max(1, std::min(nrows, per_cu * RL_LR_CUS / nbx));
         rpb = (nrows + nby - 1) / nby;
     }
-    RL_LAUNCH((k_lr_expand<R>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
-              st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y,
-              accumulate);
+    if (accumulate)
+        RL_LAUNCH((k_lr_expand<R, true>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
+                  st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
+    else
+        RL_LAUNCH((k_lr_expand<R, false>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
+                  st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
 }
 
 // Y = Phi [sum_q B_q (x) C_q] Phi^T X for tops [q0, q0 + Q) with coupling Bq
@@ -3301,6 +3302,7 @@ static bool rp_ok(const rl_ski* s, int nvec) {
     const rl_gridop* g = s->g;
     return s->extra.empty() && s->W4_base != nullptr && !s->h_base.empty() && !g->wide &&
            g->lr_try && !g->lr_dirty && g->lr_ok && s->ngrid == g->D * g->m &&
+           s->n < (1 << 28) &&          // (k_rp_expand's row accesses carry 32-bit byte offsets)
            // (the batch gate of the structured forms also gates this one: rl_gridop_set_form_gate
            // with a huge value puts the whole operator back on the transform kernels)
            (size_t)nvec * g->D * g->m >= g->lr_min &&
@@ -3433,11 +3435,17 @@ projected:
                   (const double*)g->lr_beta, pf);
         return;
     }
-    RL_LAUNCH((k_rp_expand<R, FLYE>), dim3((s->n + 255) / 256), dim3(256), 0, st,
-              (const double*)g->lr_zhat, F, s->n, nvec, g->D,
-              (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
-              (const double*)g->lr_beta, RpPFuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                  nullptr});
+    const RpPFuse nopf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (diag != nullptr)
+        RL_LAUNCH((k_rp_expand<R, FLYE, false, true>), dim3((s->n + 255) / 256), dim3(256), 0, st,
+                  (const double*)g->lr_zhat, F, s->n, nvec, g->D,
+                  (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
+                  (const double*)g->lr_beta, nopf);
+    else
+        RL_LAUNCH((k_rp_expand<R, FLYE, false, false>), dim3((s->n + 255) / 256), dim3(256), 0, st,
+                  (const double*)g->lr_zhat, F, s->n, nvec, g->D,
+                  (const int*)s->rp_out_end, Yp, diag, Xp, s->kn.rp_stagger, base, w4, g->m,
+                  (const double*)g->lr_beta, nopf);
 }
 // Do the rows of every output occupy the SAME index range in the caller's order as in the
 // sorted one?  (True for W built output by output, multi_interpolant's block-diagonal layout,

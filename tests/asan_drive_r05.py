@@ -2,7 +2,7 @@
     python -m runlmc_amd.build --emu --asan
     LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 python tests/asan_drive_r05.py) over the kernels round 5 added or changed (emulator build):
 k_sf_carries2, k_sf_scan1, k_sf_apply (exact-D loops), k_lr_pw_diff / k_lr_pw_scale with the
-selector-coupled power iteration, k_minres2_ph + k_rp_expand<.., true> (RUNLMC_RP_PFUSE=1)."""
+selector-coupled power iteration, k_minres2_ph + k_rp_expand<.., true> (the default solver round)."""
 import os, sys
 os.environ['RUNLMC_DEBUG'] = '1'
 os.environ['RUNLMC_STAGED_WT'] = '1'; os.environ['RUNLMC_NO_FUSE_W'] = '1'; os.environ['RUNLMC_NO_FUSE_WT'] = '1'
@@ -37,7 +37,6 @@ g2.set_lmc(tops2, [rng.randn(1, D2) for _ in range(5)], [np.abs(rng.randn(D2)) +
 g2.set_form_gate(0)
 print('poly forms', g2.top_forms(), g2.form(), [g2.form_stats(q)[2:] for q in range(5)])
 # 3. MINRES with P inside the expansion
-os.environ['RUNLMC_RP_PFUSE'] = '1'
 p = synth.make_problem(3, 2, 1, 700, eps=1.0, kern='rbf')
 fk = synth.functional_kernel(p); ad = (0,)
 K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)

@@ -1760,7 +1760,7 @@ def check_row_polynomial_form():
     from oracle.kernels import KernelSpec, RBFSpec, StdPeriodicSpec
     rng = np.random.RandomState(29)
     knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_RP', 'RUNLMC_NO_FUSE_W', 'RUNLMC_NO_FUSE_WT',
-             'RUNLMC_NO_RP_FUSE')
+             'RUNLMC_NO_RP_FUSE', 'RUNLMC_NO_RP_PFUSE')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     try:
         os.environ['RUNLMC_STAGED_WT'] = '1'
@@ -1817,23 +1817,23 @@ def check_row_polynomial_form():
             # last vector when k = 16 j + 1) and one rank's share of 17
             def solve(nofuse, kk, maxiter, tol=1e-6):
                 # nofuse: True -- B and P as kernels of their own; False -- B inside the projection,
-                # P as its own kernel (the default since round 4); 'p' -- B inside the projection
-                # AND P inside the expansion (round 5: k_minres2_ph, k_rp_expand<.., true>; parity
-                # held here, off by default: slower, rl_rowpoly.h RpPFuse)
+                # P as its own kernel (round 4); 'p' -- B inside the projection AND P inside the
+                # expansion (round 5: k_minres2_ph, k_rp_expand<.., true>, rl_rowpoly.h RpPFuse:
+                # the default)
                 os.environ.pop('RUNLMC_NO_RP', None)
                 os.environ.pop('RUNLMC_NO_RP_FUSE', None)
-                os.environ.pop('RUNLMC_RP_PFUSE', None)
-                if nofuse == 'p':
-                    os.environ['RUNLMC_RP_PFUSE'] = '1'
-                elif nofuse:
+                os.environ.pop('RUNLMC_NO_RP_PFUSE', None)
+                if nofuse is True:
                     os.environ['RUNLMC_NO_RP_FUSE'] = '1'
+                elif nofuse is False:
+                    os.environ['RUNLMC_NO_RP_PFUSE'] = '1'
                 K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (W, WT)}, lens)
                 op = K.device_operator()
                 op.grid.set_form_gate(0)
                 Bm = torch.from_numpy(np.tile(V, (2, 1))[:kk]).to(op.device)
                 out = solve_batch(op, Bm, tol=tol, maxiter=maxiter, lanczos_cap=8)
                 os.environ.pop('RUNLMC_NO_RP_FUSE', None)
-                os.environ.pop('RUNLMC_RP_PFUSE', None)
+                os.environ.pop('RUNLMC_NO_RP_PFUSE', None)
                 return out[0].cpu().numpy(), np.asarray(out[1]), np.asarray(out[3]), out[4]
             for kk in (min(k, 49), 17):
                 Xf, itf, stf, lzf = solve(False, kk, 5)
@@ -1859,7 +1859,7 @@ def check_row_polynomial_form():
                 from runlmc_amd import _lib as _l
                 if _l.get_library().is_hip:
                     # (GPU only -- 400 rounds of 19 systems cost the emulator a minute: frozen
-                    # systems under the opt-in P fusion, whose expansion must not touch them)
+                    # systems under the P fusion, whose expansion must not touch them)
                     Xp, itp, stp, _ = solve('p', 19, 400, tol=1e-3)
                     assert np.array_equal(stp, stn) and np.abs(itp - itn).max() <= 6, (itp, itn)
                     assert np.abs(Xp - Xn).max() <= 1e-4 * np.abs(Xn).max()
