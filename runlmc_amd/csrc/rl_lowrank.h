@@ -124,14 +124,20 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
     // loads from the const __restrict__ X the compiler folded "value carried from the previous
     // iteration's load" into "load at the point of use" -- sixteen loads at the top of every
     // iteration, each waited for on the spot: the ring existed in the source only.)
+    constexpr bool RING = R <= 24;
     const unsigned rowbytes = (unsigned)m * 8u;
     auto request = [&](int slot, int step) {
         const int n = n_begin + lane + 64 * step;
         const int nc = n < slots ? n : slots - 1;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            xr[slot][r] = rl_row_load(xrow[r], rowbytes, (unsigned)nc * 8u);
-            xm[slot][r] = rl_row_load(xrow[r], rowbytes, (unsigned)(m - 1 - nc) * 8u);
+            if constexpr (RING) {
+                xr[slot][r] = rl_row_load(xrow[r], rowbytes, (unsigned)nc * 8u);
+                xm[slot][r] = rl_row_load(xrow[r], rowbytes, (unsigned)(m - 1 - nc) * 8u);
+            } else {
+                xr[slot][r] = xrow[r][nc];
+                xm[slot][r] = xrow[r][m - 1 - nc];
+            }
         }
     };
     // The first requests are issued by the loop itself, in an iteration of their own that
@@ -139,18 +145,27 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
     // loop they were pending on the way in, row by row instead of slot by slot, and the wait
     // counts of the loop -- derived from the worse of the two ways into it -- let every
     // iteration wait for all but two of its sixteen loads.
+    // (Ranks above 24 -- two rows per wave, a ring of four lane-steps -- keep the plain loads
+    // and the requests ahead of the loop: there the iteration of zeros is an eighth of a
+    // 32-step chunk's arithmetic and the pinned order exposes the recurrence's latency --
+    // C5 periodic, rank 36: 0.61 against 0.56 ms per product.)
 #pragma unroll
-    for (int k = 0; k < G; ++k)
+    for (int k = 0; k < G; ++k) {
+        if constexpr (RING) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) xr[k][r] = xm[k][r] = 0.0;
+            for (int r = 0; r < RB; ++r) xr[k][r] = xm[k][r] = 0.0;
+        } else {
+            request(k, k);
+        }
+    }
 #pragma unroll 1
-    for (int t = -G; t < steps; t += G) {
+    for (int t = RING ? -G : 0; t < steps; t += G) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
 #if !defined(RL_EMU)
             // (the lane-steps stay in source order: scheduled freely, every step's values were
             // consumed -- and waited for -- at the top of the iteration)
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RING) __builtin_amdgcn_sched_barrier(0);
 #endif
             const int n = n_begin + lane + 64 * (t + k);
             const int nc = n < slots ? (n > 0 ? n : 0) : slots - 1;     // (n < 0: the iteration of zeros)
@@ -325,11 +340,21 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
     }
     for (int row = row0; row < row1; ++row) {
         const double* z = Zhat + (size_t)row * R;
+        // (the row's coefficients are fetched in ONE batch of scalar loads, pinned ahead of the
+        // multiply-adds: left to itself the scheduler fetched 16 at a time, each batch waited
+        // for before the next was issued -- five scalar-memory round trips per row at rank 36,
+        // 300 us per C5 expansion instead of 240)
+        double zz[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) zz[j] = z[j];
+#if !defined(RL_EMU)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         double ev = 0.0, od = 0.0;
 #pragma unroll
         for (int j = 0; j + 1 < R; j += 2) {
-            ev = fma(z[j], p[j], ev);
-            od = fma(z[j + 1], p[j + 1], od);
+            ev = fma(zz[j], p[j], ev);
+            od = fma(zz[j + 1], p[j + 1], od);
         }
         // (accumulate: the operator's filter part has written Y already, rl_filter.h)
         double* y0 = Y + (size_t)row * m + nc;

@@ -831,17 +831,31 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
         ring[1] = request(1);
         auto step = [&](int it, const Ops& cur) {
             const int vv = vat(it);
-            rl_kconst c = RL_KCONST(pf.pc) + (size_t)vv * RL_RP_PCW;        // wave-uniform: scalar loads
+            rl_kconst cp = RL_KCONST(pf.pc) + (size_t)vv * RL_RP_PCW;       // wave-uniform: scalar loads
+            // (the system's nine coefficients in one batch, not four dependent round trips)
+            double c[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) c[j] = cp[j];
+#if !defined(RL_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             double accA = 0.0, accC = 0.0;
             if (c[0] != 0.0) {
                 const size_t at = (size_t)vv * n;
                 double ev = 0.0, od = 0.0;
                 if (uni) {
+                    // (ONE batch of scalar loads, pinned ahead of the multiply-adds: k_lr_expand)
                     rl_kconst z = RL_KCONST(Zhat) + ((size_t)vv * D + dfirst) * R;
+                    double zz[R];
+#pragma unroll
+                    for (int j = 0; j < R; ++j) zz[j] = z[j];
+#if !defined(RL_EMU)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                     for (int j = 0; j + 1 < R; j += 2) {
-                        ev = fma(z[j], p[j], ev);
-                        od = fma(z[j + 1], p[j + 1], od);
+                        ev = fma(zz[j], p[j], ev);
+                        od = fma(zz[j + 1], p[j + 1], od);
                     }
                 } else {
                     const double* z = Zhat + ((size_t)vv * D + dmine) * R;
@@ -933,11 +947,17 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
                     const int vv = vat(it0 + k);
                     if constexpr (noisy) xr[(k + 2) % 3] = rl_row_load(X2 + (size_t)vat(it0 + k + 2) * n, nb8, off8);
                     const auto z = zrow(vv);
+                    double zz[R];
+#pragma unroll
+                    for (int j = 0; j < R; ++j) zz[j] = z[j];
+#if !defined(RL_EMU)
+                    __builtin_amdgcn_sched_barrier(0);       // (one batch of loads: k_lr_expand)
+#endif
                     double ev = 0.0, od = 0.0;
 #pragma unroll
                     for (int j = 0; j + 1 < R; j += 2) {
-                        ev = fma(z[j], p[j], ev);
-                        od = fma(z[j + 1], p[j + 1], od);
+                        ev = fma(zz[j], p[j], ev);
+                        od = fma(zz[j + 1], p[j + 1], od);
                     }
                     double acc = ev + od;
                     if constexpr (noisy) acc = fma(dg, xr[k], acc);
