@@ -971,3 +971,153 @@ k_rp_expand(const double* __restrict__ Zhat, const double* __restrict__ F, int n
     else
         walk([&](int vv) { return Zhat + ((size_t)vv * D + dmine) * R; });
 }
+
+// ---------------------------------------------------------------------------
+// k_spmv_w_staged_p<VB, XPT>: MINRES's P inside the interpolation product W g (+ eps (.) y) of
+// a round whose operator is NOT in the row-polynomial form (filter and transform forms:
+// W^T, grid product, W).  k_spmv_w_staged (rl_kernels.h) with the element work of k_minres2_p on
+// the q' = (W g)[row] + eps y_{r-1}[row] a thread holds in a register for each of a group's VB
+// systems -- the kernel reads g (staged through LDS as before), y_{r-1}, y_{r-2}, w_{k-2},
+// w_{k-1}, x and writes w_k, x, y': nine streams where W and P moved 2 + 9.  The scalar chain
+// is k_minres2_ph's (pc: RpPFuse above), the partial sums of alfa and ||x||^2 leave per
+// (system, row block): partA / partC [v][row blocks].  A frozen system's descriptors are
+// EMPTY (zero bytes): its loads return 0 without a fetch and nothing of it is stored.
+//   grid / block / LDS as k_spmv_w_staged + vgroups VB 8 doubles (+ 256: emulator)
+// ---------------------------------------------------------------------------
+template <int VB, int XPT>
+__global__ void __launch_bounds__(RL_THREADS)
+k_spmv_w_staged_p(const int* __restrict__ base, const double* __restrict__ w4, int nrows, int ncols,
+                  int nvec, const double* __restrict__ G, const double* __restrict__ diag,
+                  const double* X2, int xcap, int vgroups, RpPFuse pf) {
+    RL_SMEM(smem);
+    double* xs = reinterpret_cast<double*>(smem);          // [VB][xcap]
+    double* ws = xs + (size_t)VB * xcap;                   // [vgroups VB][4 waves][2]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+#if !defined(RL_EMU)
+    const int lane = tid & 63, wave = tid >> 6;
+#endif
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int bx = lin / gridDim.y, by = lin - bx * gridDim.y;
+    const int r0 = bx * nthr;
+    const int rl = (r0 + nthr < nrows ? r0 + nthr : nrows) - 1;
+    const int groups = (nvec + VB - 1) / VB;
+    const int g0 = by * vgroups;
+    const int ng = groups - g0 < vgroups ? groups - g0 : vgroups;
+    const int c0 = base[r0], c1 = base[rl] + 4;
+    const int len = c1 - c0;
+    const int row = r0 + tid;
+    const int rowc = row <= rl ? row : rl;
+    const bool live = row <= rl;
+    const int b = base[rowc];
+    double w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = w4[(size_t)4 * rowc + e];
+    const double dg = diag != nullptr ? diag[rowc] : 0.0;
+    // (rows past the workgroup's last one lie past the vectors' end or in the next workgroup:
+    // their accesses get an offset past every descriptor)
+    const unsigned nb8 = (unsigned)nrows * 8u, off8 = live ? (unsigned)row * 8u : nb8;
+    double xr[VB][XPT];
+    auto request = [&](int grp) {
+        const int v0 = (g0 + grp) * VB;
+        const int nv = nvec - v0 < VB ? nvec - v0 : VB;
+#pragma unroll
+        for (int j = 0; j < VB; ++j) {
+            const double* g = G + (size_t)(v0 + (j < nv ? j : 0)) * ncols;
+#pragma unroll
+            for (int u = 0; u < XPT; ++u) {
+                int c = c0 + tid + u * nthr;
+                c = c < ncols ? c : ncols - 1;
+                xr[j][u] = g[c];
+            }
+        }
+    };
+    request(0);
+    const double* xrow = xs + (b - c0);
+    for (int grp = 0; grp < ng; ++grp) {
+        const int v0 = (g0 + grp) * VB;
+        const int nv = nvec - v0 < VB ? nvec - v0 : VB;
+        // the operands of the group's systems: requested here, used after the sums out of LDS
+        double o2[VB], o1[VB], ow1[VB], ow2[VB], ox[VB];
+#pragma unroll
+        for (int j = 0; j < VB; ++j) {
+            const int v = v0 + (j < nv ? j : 0);
+            const bool go = j < nv && RL_KCONST(pf.pc)[(size_t)v * RL_RP_PCW] != 0.0;
+            const unsigned nb = go ? nb8 : 0u;
+            const size_t at = (size_t)v * nrows;
+            o2[j] = rl_row_load(X2 + at, nb, off8);
+            o1[j] = rl_row_load(pf.r1 + at, nb, off8);
+            ow1[j] = rl_row_load(pf.w1 + at, nb, off8);
+            ow2[j] = rl_row_load(pf.w2 + at, nb, off8);
+            ox[j] = rl_row_load(pf.x + at, nb, off8);
+        }
+#pragma unroll
+        for (int j = 0; j < VB; ++j)
+#pragma unroll
+            for (int u = 0; u < XPT; ++u) {
+                const int i = tid + u * nthr;
+                if (i < len) xs[(size_t)j * xcap + i] = xr[j][u];
+            }
+        __syncthreads();
+        if (grp + 1 < ng) request(grp + 1);
+#pragma unroll
+        for (int j = 0; j < VB; ++j) {
+            const int v = v0 + (j < nv ? j : 0);
+            rl_kconst cp = RL_KCONST(pf.pc) + (size_t)v * RL_RP_PCW;
+            double c[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) c[k] = cp[k];
+            double accA = 0.0, accC = 0.0;
+            if (j < nv && c[0] != 0.0) {
+                const size_t at = (size_t)v * nrows;
+                double q = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q = fma(w[e], xrow[(size_t)j * xcap + e], q);
+                if (diag != nullptr) q = fma(dg, o2[j], q);
+                // the element work of k_minres2_p, statement by statement
+                if (c[1] != 0.0) {
+                    const double wn = (o1[j] * c[2] - c[3] * ow1[j] - c[4] * ow2[j]) * c[5];
+                    const double xi = ox[j] + c[6] * wn;
+                    rl_row_store(pf.w1 + at, nb8, off8, wn);
+                    rl_row_store(pf.x + at, nb8, off8, xi);
+                    accC = live ? xi * xi : 0.0;
+                }
+                const double yi = q * c[7] - c[8] * o1[j];
+                rl_row_store(pf.r1 + at, nb8, off8, yi);
+                accA = live ? (o2[j] * c[7]) * yi : 0.0;
+            }
+            const int slot = grp * VB + j;
+#if defined(RL_EMU)
+            {
+                double* red = ws + (size_t)vgroups * VB * 8;
+                accA = rp_block_sum(accA, red, tid);
+                accC = rp_block_sum(accC, red, tid);
+                if (tid == 0) {
+                    ws[(size_t)slot * 8] = accA;
+                    ws[(size_t)slot * 8 + 1] = accC;
+                }
+            }
+#else
+            rp_wave_sum2(accA, accC);
+            if (lane == 0) {
+                ws[((size_t)slot * 4 + wave) * 2] = accA;
+                ws[((size_t)slot * 4 + wave) * 2 + 1] = accC;
+            }
+#endif
+        }
+        __syncthreads();
+    }
+    const int nbx = gridDim.x;
+    for (int it = tid; it < ng * VB; it += nthr) {
+        const int v = g0 * VB + it;
+        if (v < nvec) {
+#if defined(RL_EMU)
+            const double a = ws[(size_t)it * 8], cc = ws[(size_t)it * 8 + 1];
+#else
+            const double* p = ws + (size_t)it * 8;
+            const double a = (p[0] + p[2]) + (p[4] + p[6]), cc = (p[1] + p[3]) + (p[5] + p[7]);
+#endif
+            pf.partA[(size_t)v * nbx + bx] = a;
+            pf.partC[(size_t)v * nbx + bx] = cc;
+        }
+    }
+}

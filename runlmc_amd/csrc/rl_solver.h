@@ -1325,6 +1325,50 @@ k_minres2_bh(Minres2Bufs mb, int nblk, int par, double rtol, int maxiter) {
     if (threadIdx.x == 0) mb.coef[rhs] = go ? alfa / so[S_BETA] : 0.0;
 }
 
+// B's vector work as a kernel of its own, for rounds whose P runs inside the W product
+// (k_spmv_w_staged_p, rl_rowpoly.h) but whose operator has no projection to carry B: after
+// k_minres2_bh (stopping tests, coef)   y_r = y' - coef y_{r-1},  partB = partial ||y_r||^2 --
+// k_minres2_b's statements without its scalar head (every workgroup of B re-summed the
+// partial sums of its system: with one partial per W row block that is 2 x 3907 values).
+//   grid (nblk, nrhs)
+__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+k_minres2_bv(Minres2Bufs mb, int n, int par) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    if (mb.I[rhs * I_NFIELDS + I_ACTIVE] == 0) return;      // (frozen, or stopped by this round's head)
+    const double coef = mb.coef[rhs];
+    const double* r2 = mb.tri[1 - par];
+    double* y = mb.tri[par];
+    int lo, hi;
+    block_range(n, &lo, &hi);
+    const size_t off = (size_t)rhs * n;
+    constexpr int PF = 4;
+    double acc = 0.0;
+    int it0 = lo + threadIdx.x;
+    for (; it0 + (PF - 1) * (int)blockDim.x < hi; it0 += PF * blockDim.x) {
+        double ty[PF], tr[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            ty[u] = y[off + it0 + u * blockDim.x];
+            tr[u] = r2[off + it0 + u * blockDim.x];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const double yi = ty[u] - coef * tr[u];
+            y[off + it0 + u * blockDim.x] = yi;
+            acc = fma(yi, yi, acc);
+        }
+    }
+    for (int i = it0; i < hi; i += blockDim.x) {
+        const double yi = y[off + i] - coef * r2[off + i];
+        y[off + i] = yi;
+        acc = fma(yi, yi, acc);
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) mb.partB[(size_t)rhs * gridDim.x + blockIdx.x] = acc;
+}
+
 // P's scalar head (Minres2Bufs::fuse_p): everything of k_minres2_p that is per SYSTEM --
 // the sums of the partial dot products, the plane rotation of the iteration being finished,
 // the new scalar state, the Lanczos record -- once per system instead of once per

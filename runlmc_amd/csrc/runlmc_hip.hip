@@ -114,6 +114,9 @@ struct RlKnobs {
     bool rp_pfuse = true;        // RUNLMC_NO_RP_PFUSE turns off MINRES's P inside the row-polynomial expansion
                                  // (k_minres2_ph + k_rp_expand<.., true>; rl_rowpoly.h RpPFuse): C5 round 2.30 ms
                                  // against 2.62 with P as its own kernel (profiles/r05/rp_pfuse_ab.txt, run 3)
+    bool w_pfuse = true;         // RUNLMC_NO_W_PFUSE turns off MINRES's P inside the staged W product of rounds whose
+                                 // operator is not in the row-polynomial form (k_spmv_w_staged_p, k_minres2_bv):
+                                 // C5 matern round 3.71 ms against 4.18, mix 3.98 against 4.41
     bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
@@ -187,6 +190,7 @@ static RlKnobs read_knobs() {
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
     k.rp_pfuse = !flag("RUNLMC_NO_RP_PFUSE");
+    k.w_pfuse = !flag("RUNLMC_NO_W_PFUSE");
     k.rp_runlen = (int)num("RUNLMC_RP_RUNLEN", 0);
     // (k_spmv_w_poly exists for ranks 24, 32 and 36: a larger value would hand it coefficients
     // of a rank it has no instantiation for)
@@ -3211,14 +3215,55 @@ static int ski_wt_int(rl_ski* s, const double* Xp, double* G, int nvec, hipStrea
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
+// does the W product of a batch take the staged form?
+static bool w_staged_ok(const rl_ski* s, int nvec) {
+    constexpr int VB = 8;
+    const size_t lds = (size_t)VB * s->w_xmax * sizeof(double);
+    return s->W4_base != nullptr && s->w_xmax > 0 && lds <= 64 * 1024 &&
+           s->w_xmax <= 4 * RL_THREADS &&
+           ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) && !s->kn.no_staged_wt;
+}
 static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const double* diag,
                      const double* X2p, hipStream_t st) {
     // large batch, structured W: staged form (see ski_wt_int)
     constexpr int VB = 8;
     const size_t lds = (size_t)VB * s->w_xmax * sizeof(double);
-    if (s->W4_base != nullptr && s->w_xmax > 0 && lds <= 64 * 1024 &&
-        s->w_xmax <= 4 * RL_THREADS &&
-        ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) && !s->kn.no_staged_wt) {
+    const RpPFuse pf = s->rp_pfuse;          // (by value: the solver clears the handle's copy)
+    if (pf.pc != nullptr) {
+        // MINRES's P inside the product (the solver checked w_staged_ok): no output vector
+        if (!w_staged_ok(s, nvec) || s->n >= (1 << 28))
+            return fail(RL_EINVAL, "internal: MINRES update fused into a W product that does not run staged");
+        trace_once("W product: k_spmv_w_staged_p (MINRES's P inside)");
+        static unsigned long long seenp = 0;
+        if (first_on_device(&seenp)) {
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged_p<VB, 1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged_p<VB, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_spmv_w_staged_p<VB, 4>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        }
+        const unsigned gx = (s->n + RL_THREADS - 1) / RL_THREADS;
+        const int vg = staged_vgroups();
+        const dim3 grid(gx, ((nvec + VB - 1) / VB + vg - 1) / vg);
+        size_t ldsp = lds + (size_t)vg * VB * 8 * sizeof(double);
+#if defined(RL_EMU)
+        ldsp += 256 * sizeof(double);
+#endif
+        if (ldsp > 64 * 1024)
+            return fail(RL_EINVAL, "internal: k_spmv_w_staged_p: tile above 64 KB");
+#define RL_W_STAGED_P(XPT)                                                                      \
+    RL_LAUNCH((k_spmv_w_staged_p<VB, XPT>), grid, dim3(RL_THREADS), ldsp, st,                   \
+              (const int*)s->W4_base, (const double*)s->W4_w, s->n, s->ngrid, nvec, G, diag,    \
+              X2p, s->w_xmax, vg, pf)
+        if (s->w_xmax <= RL_THREADS) RL_W_STAGED_P(1);
+        else if (s->w_xmax <= 2 * RL_THREADS) RL_W_STAGED_P(2);
+        else RL_W_STAGED_P(4);
+#undef RL_W_STAGED_P
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
+    if (w_staged_ok(s, nvec)) {
         trace_once("W product: k_spmv_w_staged");
         static unsigned long long seen = 0;
         if (first_on_device(&seen)) {
@@ -3508,13 +3553,18 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
         }
     }
     // (the solver asked for its vector update inside the projection: no other path does it)
-    if (s->rp_fuse.r2 != nullptr || s->rp_pfuse.pc != nullptr)
+    if (s->rp_fuse.r2 != nullptr)
         return fail(RL_EINVAL, "internal: MINRES update fused into a projection that does not run");
+    // (the solver asked for P inside the W product: the staged kernel, a single term, and the
+    // grid vector written -- not the W kernel that expands the polynomial form itself)
+    const bool wp = s->rp_pfuse.pc != nullptr;
+    if (wp && (!s->extra.empty() || !w_staged_ok(s, nvec)))
+        return fail(RL_EINVAL, "internal: MINRES update fused into a W product that does not run staged");
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     // a polynomial-form operator hands its mixed coefficients to the W kernel instead of
     // writing the grid vector (the grid handle says whether it took that path)
     s->g->expand_deferred = false;
-    s->g->defer_expand = ski_w_poly_ok(s, nvec);
+    s->g->defer_expand = !wp && ski_w_poly_ok(s, nvec);
     const int rc = rl_gridop_mvm(s->g, s->G1, s->G2, nvec, st);
     s->g->defer_expand = false;
     if (rc != RL_OK) return rc;
@@ -3522,6 +3572,7 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
         s->g->expand_deferred = false;
         RL_TRY(ski_w_poly(s, Yp, nvec, diag, Xp, st));
     } else {
+        if (wp && s->rp_mid) s->rp_mid(st);       // (P's scalar head: k_minres2_ph)
         RL_TRY(ski_w_int(s, s->G2, Yp, nvec, diag, Xp, st));
     }
     for (const SkiTerm& t : s->extra) {       // Yp += W_t K_t W_t^T Xp
@@ -3898,6 +3949,8 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
         if (rc != RL_OK) return rc;
         if (mb.fuse_p) {
             RL_LAUNCH(k_minres2_bh, dim3(nrhs), blk, red, st, mb, mb.np, par, rtol, maxiter);
+            // (P inside the W product: no projection carries B's vector work)
+            if (!mb.fuse_b) RL_LAUNCH(k_minres2_bv, grid, blk, red, st, mb, n, par);
             return RL_OK;
         }
     }
@@ -4169,6 +4222,33 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
                 mb.partC = mb.partA[1] + (size_t)nrhs * np;
                 trace_once("minres round: P inside the row-polynomial expansion (k_minres2_ph)");
             }
+        } else if (mb.W_indptr == nullptr && mb.poly_part == nullptr && s->kn.w_pfuse &&
+                   s->extra.empty() && w_staged_ok(s, nrhs) && n < (1 << 28) &&
+                   // (an operator wholly in the polynomial form has better rounds: row-polynomial
+                   // ones, or the W kernel that expands the coefficients itself)
+                   !(s->g->lr_ok && !s->g->lr_dirty) && !(rp_ok(s, nrhs) && rp_ready(s, nrhs))) {
+            // interpolation products around a grid product (filter / transform forms): P inside
+            // the staged W product (k_minres2_ph + k_spmv_w_staged_p), B = k_minres2_bh + k_minres2_bv
+            const int np = (n + RL_THREADS - 1) / RL_THREADS;
+            const size_t needp = (size_t)nrhs * (RL_RP_PCW + 1 + 3 * (size_t)np);
+            if (s->rp_pp_cap < needp) {
+                if (s->rp_pp) RL_HIP(hipFree(s->rp_pp));
+                s->rp_pp = nullptr;
+                s->rp_pp_cap = 0;
+                RL_HIP(hipMalloc((void**)&s->rp_pp, needp * sizeof(double)));
+                s->rp_pp_cap = needp;
+            }
+            RL_HIP(hipMemsetAsync(s->rp_pp, 0, needp * sizeof(double), st));
+            mb.fuse_p = nrhs;
+            mb.pc = s->rp_pp;
+            mb.coef = s->rp_pp + (size_t)nrhs * RL_RP_PCW;
+            mb.np = np;
+            mb.partA[0] = mb.coef + nrhs;
+            mb.partA[1] = mb.partA[0] + (size_t)nrhs * np;
+            mb.partC = mb.partA[1] + (size_t)nrhs * np;
+            mb.nrmB = mb.partB;               // (k_minres2_bv's partial norms, one per solver block)
+            mb.nrm_n = nblk;
+            trace_once("minres round: P inside the staged W product (k_minres2_ph, k_spmv_w_staged_p)");
         }
         RL_LAUNCH(k_minres2_init, grid, blk, 0, st, Bi, n, (const double*)w.part[0], mb);
         if (mb.poly_part != nullptr)        // projection of W^T y_0 for the first round's P

@@ -1746,6 +1746,68 @@ def check_w_poly_product():
                 os.environ[k_] = v
 
 
+def check_minres_p_in_w():
+    """MINRES's P inside the staged W product (rl_rowpoly.h k_spmv_w_staged_p + k_minres2_ph /
+    k_minres2_bh / k_minres2_bv: the default round of an operator that is not wholly in the
+    polynomial form, large batches) against the same solve with W, P and B as kernels of their
+    own (RUNLMC_NO_W_PFUSE), forced onto small systems: Matern tops (filter form) and a mix of
+    filter and polynomial tops; 19 systems (two full groups of eight and three) and 5; iterates
+    after five iterations to 1e-12 (another order of the partial sums of alfa), the recorded
+    Lanczos coefficients, and a solve that ends -- systems stop at different rounds and are
+    frozen (empty descriptors: nothing of them is read or written)."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import solve_batch
+    knobs = ('RUNLMC_STAGED_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_W_PFUSE')
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    rng = np.random.RandomState(31)
+    try:
+        os.environ['RUNLMC_STAGED_WT'] = '1'
+        os.environ['RUNLMC_NO_FUSE_W'] = '1'
+        os.environ['RUNLMC_NO_FUSE_WT'] = '1'
+        from runlmc_amd import _lib as _l0
+        sizes = (1500, 1200) if _l0.get_library().is_hip else (700, 450)
+        for (kern, D, Q), m_data in zip((('matern', 3, 2), ('mix', 2, 3)), sizes):
+            p = synth.make_problem(D, Q, 1, m_data, eps=1.0, kern=kern)
+            fk = synth.functional_kernel(p)
+            ad = (0,)
+            V = rng.randn(19, p.n)
+
+            def solve(fused, kk, maxiter, tol=1e-6):
+                os.environ.pop('RUNLMC_NO_W_PFUSE', None)
+                if not fused:
+                    os.environ['RUNLMC_NO_W_PFUSE'] = '1'
+                K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+                op = K.device_operator()
+                op.grid.set_form_gate(0)
+                assert 2 in op.grid.top_forms()[0], op.grid.top_forms()     # (a filter top: not row-polynomial)
+                out = solve_batch(op, torch.from_numpy(V[:kk]).to(op.device), tol=tol,
+                                  maxiter=maxiter, lanczos_cap=8)
+                os.environ.pop('RUNLMC_NO_W_PFUSE', None)
+                return out[0].cpu().numpy(), np.asarray(out[1]), np.asarray(out[3]), out[4]
+            for kk in (19, 5) if kern == 'matern' else (19,):
+                Xf, itf, stf, lzf = solve(True, kk, 5)
+                Xn, itn, stn, lzn = solve(False, kk, 5)
+                assert np.abs(Xf - Xn).max() <= 1e-12 * np.abs(Xn).max(), (kern, kk, np.abs(Xf - Xn).max())
+                assert not np.array_equal(Xf, Xn)        # (another summation order: the fused round ran)
+                assert np.array_equal(itf, itn) and np.array_equal(stf, stn)
+                assert np.abs(lzf).max() > 0 and np.abs(lzf - lzn).max() <= 1e-12 * np.abs(lzn).max()
+            from runlmc_amd import _lib as _l
+            hip = _l.get_library().is_hip
+            if kern == 'matern' or hip:
+                # (the emulator pays per row, system and round: eleven systems there)
+                kk = 19 if hip else 11
+                Xf, itf, stf, _ = solve(True, kk, 400, tol=1e-3)
+                Xn, itn, stn, _ = solve(False, kk, 400, tol=1e-3)
+                assert np.array_equal(stf, stn) and (stf == 1).all(), (stf, stn)
+                assert len(set(itf.tolist())) > 1 and np.abs(itf - itn).max() <= 6, (itf, itn)
+                assert np.abs(Xf - Xn).max() <= 1e-4 * np.abs(Xn).max()
+    finally:
+        for k_, v in saved.items():
+            os.environ.pop(k_, None)
+            if v is not None:
+                os.environ[k_] = v
+
+
 def check_row_polynomial_form():
     """The row-polynomial form of a polynomial-form SKI operator (rl_rowpoly.h: K~ = F M F^T
     + eps with F = W Phi built once per rank; k_rp_project on the fp64 matrix cores, k_rp_expand

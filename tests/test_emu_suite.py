@@ -189,6 +189,10 @@ def test_filter_form():
     ps.check_filter_form()
 
 
+def test_minres_p_in_w():
+    ps.check_minres_p_in_w()
+
+
 def test_slfm_identity_quirk():
     ps.check_slfm_identity_quirk()
 
