@@ -761,7 +761,8 @@ static int gridop_create_impl(int device, int D, int m, int m1, int m2, int max_
     // gate (2^20 elements) asks for it, so handles that see small batches only (the
     // real-data fits) never pay the verification.  (Until round 4 grids under 2048 points
     // were excluded: RBF at m = 1000 then saturated at 6-11 % on the single-tile kernel.)
-    g->lr_try = m1 == 0 && m >= 2 * RL_LR_RMAX && !g->kn.no_lowrank;
+    // (m < 2^28: k_lr_project addresses a row's elements by 32-bit byte offsets)
+    g->lr_try = m1 == 0 && m >= 2 * RL_LR_RMAX && m < (1 << 28) && !g->kn.no_lowrank;
     // the solver's two-kernel polynomial rounds: grids of >= 2048 points by default,
     // shorter ones on request (RUNLMC_POLY_ROUND=1)
     g->lr_round_try = g->lr_try && (m >= 2048 || g->kn.poly_round);
@@ -3223,6 +3224,19 @@ static bool w_staged_ok(const rl_ski* s, int nvec) {
            s->w_xmax <= 4 * RL_THREADS &&
            ((size_t)s->n * nvec >= ((size_t)1 << 22) || s->kn.staged_wt) && !s->kn.no_staged_wt;
 }
+// ... and with MINRES's P inside (k_spmv_w_staged_p: the partial sums' words next to the tile,
+// row accesses by 32-bit byte offsets)?
+static size_t w_staged_p_lds(const rl_ski* s) {
+    constexpr int VB = 8;
+    size_t lds = ((size_t)VB * s->w_xmax + (size_t)staged_vgroups() * VB * 8) * sizeof(double);
+#if defined(RL_EMU)
+    lds += 256 * sizeof(double);
+#endif
+    return lds;
+}
+static bool w_staged_p_ok(const rl_ski* s, int nvec) {
+    return w_staged_ok(s, nvec) && w_staged_p_lds(s) <= 64 * 1024 && s->n < (1 << 28);
+}
 static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const double* diag,
                      const double* X2p, hipStream_t st) {
     // large batch, structured W: staged form (see ski_wt_int)
@@ -3231,7 +3245,7 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
     const RpPFuse pf = s->rp_pfuse;          // (by value: the solver clears the handle's copy)
     if (pf.pc != nullptr) {
         // MINRES's P inside the product (the solver checked w_staged_ok): no output vector
-        if (!w_staged_ok(s, nvec) || s->n >= (1 << 28))
+        if (!w_staged_p_ok(s, nvec))
             return fail(RL_EINVAL, "internal: MINRES update fused into a W product that does not run staged");
         trace_once("W product: k_spmv_w_staged_p (MINRES's P inside)");
         static unsigned long long seenp = 0;
@@ -3246,12 +3260,7 @@ static int ski_w_int(rl_ski* s, const double* G, double* Yp, int nvec, const dou
         const unsigned gx = (s->n + RL_THREADS - 1) / RL_THREADS;
         const int vg = staged_vgroups();
         const dim3 grid(gx, ((nvec + VB - 1) / VB + vg - 1) / vg);
-        size_t ldsp = lds + (size_t)vg * VB * 8 * sizeof(double);
-#if defined(RL_EMU)
-        ldsp += 256 * sizeof(double);
-#endif
-        if (ldsp > 64 * 1024)
-            return fail(RL_EINVAL, "internal: k_spmv_w_staged_p: tile above 64 KB");
+        const size_t ldsp = w_staged_p_lds(s);
 #define RL_W_STAGED_P(XPT)                                                                      \
     RL_LAUNCH((k_spmv_w_staged_p<VB, XPT>), grid, dim3(RL_THREADS), ldsp, st,                   \
               (const int*)s->W4_base, (const double*)s->W4_w, s->n, s->ngrid, nvec, G, diag,    \
@@ -3558,7 +3567,7 @@ static int ski_mvm_int(rl_ski* s, const double* Xp, double* Yp, int nvec, hipStr
     // (the solver asked for P inside the W product: the staged kernel, a single term, and the
     // grid vector written -- not the W kernel that expands the polynomial form itself)
     const bool wp = s->rp_pfuse.pc != nullptr;
-    if (wp && (!s->extra.empty() || !w_staged_ok(s, nvec)))
+    if (wp && (!s->extra.empty() || !w_staged_p_ok(s, nvec)))
         return fail(RL_EINVAL, "internal: MINRES update fused into a W product that does not run staged");
     RL_TRY(ski_wt_int(s, Xp, s->G1, nvec, st, bump));
     // a polynomial-form operator hands its mixed coefficients to the W kernel instead of
@@ -4223,7 +4232,7 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
                 trace_once("minres round: P inside the row-polynomial expansion (k_minres2_ph)");
             }
         } else if (mb.W_indptr == nullptr && mb.poly_part == nullptr && s->kn.w_pfuse &&
-                   s->extra.empty() && w_staged_ok(s, nrhs) && n < (1 << 28) &&
+                   s->extra.empty() && w_staged_p_ok(s, nrhs) &&
                    // (an operator wholly in the polynomial form has better rounds: row-polynomial
                    // ones, or the W kernel that expands the coefficients itself)
                    !(s->g->lr_ok && !s->g->lr_dirty) && !(rp_ok(s, nrhs) && rp_ready(s, nrhs))) {
