@@ -82,6 +82,8 @@ __device__ __forceinline__ double lr_point(int n, int m) {
 // (Round 3, same protocol: two rows per wave and a ring of four lane-steps at rank 24 --
 // 148 registers, three waves per SIMD, half as much again in flight per CU: 0.497 / 0.498 /
 // 0.498 ms against 0.494 / 0.492 / 0.492.  Neither occupancy nor bytes in flight bound it.)
+// (Round 5: three rows per wave and a ring of two at rank 36 -- 256 registers, 8 spilled:
+// 336 against 300-315 us per C5 projection.)
 // (Measured and dropped, round 3: the projection as a tall-skinny product on the fp64
 // matrix cores -- v_mfma_f64_16x16x4_f64, 16 rows x 16 functions per tile, basis tile
 // in LDS, sums never reduced across lanes, 124 VGPRs.  The instruction's A layout puts

@@ -2,7 +2,8 @@
     python -m runlmc_amd.build --emu --asan
     LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 python tests/asan_drive_r05.py) over the kernels round 5 added or changed (emulator build):
 k_sf_carries2, k_sf_scan1, k_sf_apply (exact-D loops), k_lr_pw_diff / k_lr_pw_scale with the
-selector-coupled power iteration, k_minres2_ph + k_rp_expand<.., true> (the default solver round)."""
+selector-coupled power iteration, k_minres2_ph + k_rp_expand<.., true> (the default solver round), k_spmv_w_staged_p + k_minres2_bv, the
+plain expansion's ring of requests (rl_row_load / rl_row_store)."""
 import os, sys
 os.environ['RUNLMC_DEBUG'] = '1'
 os.environ['RUNLMC_STAGED_WT'] = '1'; os.environ['RUNLMC_NO_FUSE_W'] = '1'; os.environ['RUNLMC_NO_FUSE_WT'] = '1'
@@ -44,4 +45,21 @@ op = K.device_operator(); op.grid.set_form_gate(0)
 V = rng.randn(19, p.n)
 out = solve_batch(op, torch.from_numpy(V).to(op.device), tol=1e-3, maxiter=60, lanczos_cap=8)
 print('pfuse iterations', np.asarray(out[1]), 'istop', np.asarray(out[3]))
+# 4. MINRES with P inside the staged W product (k_spmv_w_staged_p, k_minres2_bv): Matern tops, ragged
+#    outputs, 11 systems (a full group of eight and three), a solve that ends (frozen systems)
+p = synth.make_problem(3, 2, 1, 500, eps=1.0, kern='matern')
+fk = synth.functional_kernel(p)
+K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+op = K.device_operator(); op.grid.set_form_gate(0)
+V = rng.randn(11, p.n)
+out = solve_batch(op, torch.from_numpy(V).to(op.device), tol=1e-3, maxiter=200, lanczos_cap=8)
+print('P-in-W iterations', np.asarray(out[1]), 'istop', np.asarray(out[3]))
+# 5. the plain expansion with the noise term (rl_ski_mvm: ring of three requests, buffer accesses) at a
+#    row count that is no multiple of 256 and a batch that is no multiple of 3
+p = synth.make_problem(3, 2, 1, 700, eps=1.0, kern='rbf')
+fk = synth.functional_kernel(p)
+K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+op = K.device_operator(); op.grid.set_form_gate(0)
+Y = op.matmat_host(rng.randn(7, p.n))
+print('row-polynomial product', np.abs(Y).max())
 print('ASAN DRIVE DONE')
