@@ -1025,8 +1025,13 @@ k_spmv_w_staged_p(const int* __restrict__ base, const double* __restrict__ w4, i
             const double* g = G + (size_t)(v0 + (j < nv ? j : 0)) * ncols;
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
+                // (positions past the range -- up to xcap - len of them -- repeat its last
+                // element: a hit in the same line instead of a fetch of the neighbour's range;
+                // the PMC counters showed the staged kernels fetching 1.2-2.3x their operand)
                 int c = c0 + tid + u * nthr;
+                c = c < c1 ? c : c1 - 1;
                 c = c < ncols ? c : ncols - 1;
+                c = c > 0 ? c : 0;
                 xr[j][u] = g[c];
             }
         }
