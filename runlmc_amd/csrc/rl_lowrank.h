@@ -226,54 +226,66 @@ k_lr_project(const double* __restrict__ X, int nrows, int m, const double* __res
 // apply the dense coefficient map
 //     Zhat[a][i] = nu_i sum_q sum_b B_q[a][b] sum_j C_q[i][j] (nu_j Z[b][j])
 // (nu: the basis normalisation, see lr_point above).
-//   grid (nvec)   block 256   LDS: Z [D][r] + W [Q][D][r]
+//   grid (nvec)   block RL_LR_MIXT = 1024 (four groups of 256)
+//   LDS: Z [D][r] + W [Q][D][r] + S [max(4, Q)][D][r]   (lr_mix_lds below; operators whose
+//   tables would pass 64 KB -- sixteen outputs at rank 48 with more than four terms -- run with
+//   S inside W's space and the last step as one chain per output: split3 = 0)
 //   Cq [Q][r][r], Bq [Q][D][D] (single-top products pass Q = 1, B = identity)
+// The kernel is three dependent steps of a few thousand multiply-adds: latency, not work.
+// With 256 threads each step was a chain (25 chunk loads in four batches; five outputs of
+// 24 loads each; 50 multiply-adds per output): 15-19 us between the two streaming kernels
+// of every product and every solver round.  Four groups of threads split the chunks
+// (group k: chunks k, k + 4, ...; the four sums meet in LDS in a fixed order), the second
+// step's Q D r outputs and the third step's sum over q go one per thread.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+#define RL_LR_MIXT 1024
+// LDS bytes of k_lr_mix and whether its last step runs split over q (host side)
+static inline size_t lr_mix_lds(int D, int r, int Q, int* split3) {
+    const size_t dr = (size_t)D * r, q4 = (size_t)(Q > 4 ? Q : 4);
+    const size_t full = (1 + (size_t)Q + q4) * dr * sizeof(double);
+    *split3 = full <= 64 * 1024 ? 1 : 0;
+    return *split3 ? full : (1 + q4) * dr * sizeof(double);
+}
+__global__ void __launch_bounds__(RL_LR_MIXT)
 k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, int Q,
          const double* __restrict__ Cq, const double* __restrict__ Bq,
          const double* __restrict__ nu, double* __restrict__ Zhat,
-         const int* __restrict__ run_ptr) {
+         const int* __restrict__ run_ptr, int split3) {
     RL_SMEM(smem);
     double* Z = reinterpret_cast<double*>(smem);          // [D][r]
-    double* W = Z + D * r;                                 // [Q][D][r]
+    double* W = Z + D * r;                                 // [Q][D][r]  (split3 = 0: [max(4, Q)][D][r])
+    double* S = split3 ? W + Q * D * r : W;                // [max(4, Q)][D][r]
     const int v = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int nrows = nvec * D;
-    if (run_ptr != nullptr) {
-        // partial sums of k_rp_project (rl_rowpoly.h): part[run][v][j], the runs of output b
-        // are run_ptr[b] .. run_ptr[b + 1]; summed in a fixed order, eight loads in flight
-        for (int e = tid; e < D * r; e += nthr) {
+    const int grp = tid >> 8, t = tid & 255, ngrp = nthr >> 8;        // (nthr a multiple of 256)
+    const int nrows = nvec * D, Dr = D * r;
+    // step 1: group grp sums its share of the chunks (or, for k_rp_project's partial sums
+    // part[run][v][j], of the runs run_ptr[b] .. run_ptr[b + 1] of output b) in ascending order
+    for (int e = t; e < Dr; e += 256) {
+        int c0 = 0, c1 = nchunks;
+        size_t stride = (size_t)nrows * r;
+        const double* src = part + (size_t)v * Dr + e;
+        if (run_ptr != nullptr) {
             const int b = e / r, j = e - b * r;
-            const int c0 = run_ptr[b], c1 = run_ptr[b + 1];
-            const size_t stride = (size_t)nvec * r;
-            const double* src = part + (size_t)v * r + j;
-            double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int c = c0;
-            for (; c + 8 <= c1; c += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(c + u) * stride];
-            }
-            for (; c < c1; ++c) s8[0] += src[(size_t)c * stride];
-            Z[e] = nu[j] * (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
+            c0 = run_ptr[b];
+            c1 = run_ptr[b + 1];
+            stride = (size_t)nvec * r;
+            src = part + (size_t)v * r + j;
         }
-    } else
-    for (int e = tid; e < D * r; e += nthr) {
-        // chunks summed in a fixed order (eight interleaved running sums, so that
-        // eight loads are in flight; the same order on every run and every rank)
-        const double* src = part + (size_t)v * D * r + e;
-        const size_t stride = (size_t)nrows * r;
-        double s8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        int c = 0;
-        for (; c + 8 <= nchunks; c += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += src[(size_t)(c + u) * stride];
-        }
-        for (; c < nchunks; ++c) s8[0] += src[(size_t)c * stride];
-        Z[e] = nu[e % r] * (((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7])));
+        double s = 0.0;
+        for (int c = c0 + grp; c < c1; c += ngrp) s += src[(size_t)c * stride];
+        S[grp * Dr + e] = s;
     }
     __syncthreads();
-    for (int e = tid; e < Q * D * r; e += nthr) {
-        const int q = e / (D * r), rem = e - q * D * r;
+    for (int e = tid; e < Dr; e += nthr) {
+        double s = 0.0;
+        if (ngrp == 4) s = (S[e] + S[Dr + e]) + (S[2 * Dr + e] + S[3 * Dr + e]);
+        else for (int k = 0; k < ngrp; ++k) s += S[k * Dr + e];
+        Z[e] = nu[e % r] * s;
+    }
+    __syncthreads();
+    // step 2: W[q][b][i] = sum_j C_q[i][j] Z[b][j]
+    for (int e = tid; e < Q * Dr; e += nthr) {
+        const int q = e / Dr, rem = e - q * Dr;
         const int b = rem / r, i = rem - b * r;
         const double* c = Cq + ((size_t)q * r + i) * r;
         const double* z = Z + b * r;
@@ -282,14 +294,32 @@ k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, i
         W[e] = s;
     }
     __syncthreads();
-    for (int e = tid; e < D * r; e += nthr) {
-        const int a = e / r, i = e - a * r;
-        double s = 0.0;
-        for (int q = 0; q < Q; ++q) {
-            const double* bq = Bq + ((size_t)q * D + a) * D;
-            for (int b = 0; b < D; ++b) s = fma(bq[b], W[(q * D + b) * r + i], s);
+    if (!split3) {
+        for (int e = tid; e < Dr; e += nthr) {
+            const int a = e / r, i = e - a * r;
+            double s = 0.0;
+            for (int q = 0; q < Q; ++q) {
+                const double* bq = Bq + ((size_t)q * D + a) * D;
+                for (int b = 0; b < D; ++b) s = fma(bq[b], W[(q * D + b) * r + i], s);
+            }
+            Zhat[(size_t)v * Dr + e] = nu[i] * s;
         }
-        Zhat[((size_t)v * D + a) * r + i] = nu[i] * s;
+        return;
+    }
+    // step 3: T[q][a][i] = sum_b B_q[a][b] W[q][b][i], then the sum over q in ascending order
+    for (int e = tid; e < Q * Dr; e += nthr) {
+        const int q = e / Dr, rem = e - q * Dr;
+        const int a = rem / r, i = rem - a * r;
+        const double* bq = Bq + ((size_t)q * D + a) * D;
+        double s = 0.0;
+        for (int b = 0; b < D; ++b) s = fma(bq[b], W[(q * D + b) * r + i], s);
+        S[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < Dr; e += nthr) {
+        double s = 0.0;
+        for (int q = 0; q < Q; ++q) s += S[q * Dr + e];
+        Zhat[(size_t)v * Dr + e] = nu[e % r] * s;
     }
 }
 

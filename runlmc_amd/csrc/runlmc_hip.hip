@@ -1599,9 +1599,11 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
                       const double* Bq, hipStream_t st, int accumulate = 0) {
     const int nrows = nvec * g->D;
     const int chunks = lr_project<R>(g, X, nrows, st);
-    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + Q) * g->D * R * sizeof(double), st,
+    int split3 = 0;
+    const size_t mix_lds = lr_mix_lds(g->D, R, Q, &split3);
+    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(RL_LR_MIXT), mix_lds, st,
               (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
-              (const double*)g->lr_nu, g->lr_zhat, (const int*)nullptr);
+              (const double*)g->lr_nu, g->lr_zhat, (const int*)nullptr, split3);
     // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
     // the evaluation costs more than the two vector passes it saves -- measured, C5
     // periodic: 5.03 against 4.17 ms per solver round)
@@ -3471,10 +3473,12 @@ static void rp_launch(rl_ski* s, const double* F, const int* base, const double*
               dim3(256), lds, st, Xp, s->n, nvec, F, (const int*)s->rp_runs, s->rp_nruns, s->rp_part,
               bump, base, w4, g->m, (const double*)g->lr_beta, RpFuse{nullptr, nullptr, nullptr});
 projected:
-    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(256), (size_t)(1 + g->Q) * g->D * R * sizeof(double), st,
+    int split3 = 0;
+    const size_t mix_lds = lr_mix_lds(g->D, R, g->Q, &split3);
+    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(RL_LR_MIXT), mix_lds, st,
               (const double*)s->rp_part, 0, nvec, g->D, R, g->Q, (const double*)g->lr_C,
               (const double*)g->lr_B, (const double*)g->lr_nu, g->lr_zhat,
-              (const int*)s->rp_run_ptr);
+              (const int*)s->rp_run_ptr, split3);
     if (s->rp_mid) s->rp_mid(st);
     const RpPFuse pf = s->rp_pfuse;          // (by value: the solver clears the handle's copy)
     if (pf.pc != nullptr) {
