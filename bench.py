@@ -635,6 +635,18 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
     }
     if traffic is not None:
         out['roofline']['traffic_GBps'] = traffic / (wall_ms * 1e-3) / 1e9
+    if headline:
+        # what THIS box does when it merely copies the step's vectors (a stock elementwise
+        # kernel: read X once, write Y once -- the algorithmic traffic of the product), same
+        # clock: the interface's 8 TB/s is `peak`, this is what a read-once / write-once
+        # kernel pair can be held against (tools/lr_pattern_probe.hip)
+        c_ms, _ = time_steps(lambda: torch.mul(X, 1.0, out=Y), 20, 5, world, dev)
+        c_ms = max_over_ranks(c_ms, world, dev)
+        copy_gbs = 2.0 * X.numel() * 8 / (c_ms * 1e-3) / 1e9
+        out['roofline']['copy_same_vectors'] = {
+            'GBps': copy_gbs, 'ms': c_ms, 'kind': 'measured in this run',
+            'what': 'torch.mul(X, 1.0, out=Y) on the step\'s %d x %d fp64 vectors' % tuple(X.shape)}
+        out['roofline']['frac_of_copy'] = achieved / copy_gbs
 
     if poly:
         # the same product forced onto the transform (FFT) kernels, same clock:

@@ -21,6 +21,10 @@
 // Same operator, another summation order (roundoff-level agreement, as k_spmv_w_poly).
 // Rows are in the handle's SORTED order (by output, then by grid position), so the rows of
 // an output are contiguous; F is degree-major, F[j * n + i].
+// Round 5: MINRES's two vector kernels ride inside these two -- B in the projection (FB,
+// RpFuse; round 4), P in the expansion (FP, RpPFuse) -- and, for operators that are NOT
+// wholly in the polynomial form, P rides inside the staged W product (k_spmv_w_staged_p at
+// the end of this file: it shares RpPFuse and the scalar head k_minres2_ph).
 #pragma once
 #include "rl_device.h"
 #include "rl_lowrank.h"
