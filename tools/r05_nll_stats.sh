@@ -7,7 +7,7 @@ for fam in ${FAMS:-rbf matern}; do
   rm -rf /tmp/nllp; mkdir -p /tmp/nllp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/nllp -- python3 $R/tools/nll_breakdown.py c5 128 $fam > /tmp/nllp/out.txt 2> /tmp/nllp/err.txt
   f=$(find /tmp/nllp -name '*kernel_stats.csv' | head -1)
-  [ -n "$f" ] && head -16 "$f" | cut -c1-260 > $O/c5_nll_${fam}_kernel_stats.csv
+  [ -n "$f" ] && head -16 "$f" > $O/c5_nll_${fam}_kernel_stats.csv
   grep "rep" /tmp/nllp/out.txt | tail -3 > $O/c5_nll_${fam}_breakdown.txt
-  cat $O/c5_nll_${fam}_breakdown.txt; cut -d, -f1-5 $O/c5_nll_${fam}_kernel_stats.csv | cut -c1-150 | head -9
+  cat $O/c5_nll_${fam}_breakdown.txt; head -3 $O/c5_nll_${fam}_kernel_stats.csv | cut -c1-120
 done
