@@ -1585,32 +1585,26 @@ static size_t lr_min_elements(const rl_gridop* g) {
 
 // launches the projection, returns the number of chunks (partial sums per row)
 template <int R>
-static int lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st) {
+static int lr_project(rl_gridop* g, const double* X, int nrows, hipStream_t st,
+                      double* part = nullptr) {
     const int steps = lr_steps(g, nrows, R);
     const int chunks = ((g->m + 1) / 2 + 64 * steps - 1) / (64 * steps);
     RL_LAUNCH((k_lr_project<R>), dim3(chunks, (nrows + RL_LR_ROWS(R) - 1) / RL_LR_ROWS(R)),
               dim3(64 * RL_LR_WAVES), (size_t)RL_LR_WAVES * R * 65 * sizeof(double), st, X, nrows,
-              g->m, (const double*)g->lr_beta, steps, g->lr_part);
+              g->m, (const double*)g->lr_beta, steps, part != nullptr ? part : g->lr_part);
     return chunks;
 }
-
 template <int R>
-static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q, const double* Cq,
-                      const double* Bq, hipStream_t st, int accumulate = 0) {
-    const int nrows = nvec * g->D;
-    const int chunks = lr_project<R>(g, X, nrows, st);
+static void lr_mix(rl_gridop* g, const double* part, int chunks, int nvec, int Q, const double* Cq,
+                   const double* Bq, double* zhat, hipStream_t st) {
     int split3 = 0;
     const size_t mix_lds = lr_mix_lds(g->D, R, Q, &split3);
-    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(RL_LR_MIXT), mix_lds, st,
-              (const double*)g->lr_part, chunks, nvec, g->D, R, Q, Cq, Bq,
-              (const double*)g->lr_nu, g->lr_zhat, (const int*)nullptr, split3);
-    // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
-    // the evaluation costs more than the two vector passes it saves -- measured, C5
-    // periodic: 5.03 against 4.17 ms per solver round)
-    if (g->defer_expand && !accumulate && R <= g->kn.w_poly_rmax) {
-        g->expand_deferred = true;
-        return;
-    }
+    RL_LAUNCH(k_lr_mix, dim3(nvec), dim3(RL_LR_MIXT), mix_lds, st, part, chunks, nvec, g->D, R, Q,
+              Cq, Bq, (const double*)g->lr_nu, zhat, (const int*)nullptr, split3);
+}
+template <int R>
+static void lr_expand(rl_gridop* g, const double* zhat, int nrows, double* Y, int accumulate,
+                      hipStream_t st) {
     // rows per expansion workgroup: the basis values of a slot are generated once
     // per workgroup (48 instructions against 14 per row and slot).  16 rows when
     // that makes at least two resident rounds of workgroups (measured at C5, 1290
@@ -1626,10 +1620,32 @@ static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q,
     }
     if (accumulate)
         RL_LAUNCH((k_lr_expand<R, true>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
-                  st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
+                  st, zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
     else
         RL_LAUNCH((k_lr_expand<R, false>), dim3(nbx, (nrows + rpb - 1) / rpb), dim3(256), 0,
-                  st, (const double*)g->lr_zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
+                  st, zhat, nrows, g->m, (const double*)g->lr_beta, rpb, Y);
+}
+template <int R>
+static void lr_launch(rl_gridop* g, const double* X, double* Y, int nvec, int Q, const double* Cq,
+                      const double* Bq, hipStream_t st, int accumulate = 0) {
+    const int nrows = nvec * g->D;
+    const bool deferred = g->defer_expand && !accumulate && R <= g->kn.w_poly_rmax;
+    // (Measured and dropped, round 5: a large batch as TWO half batches, the second one a
+    // projection behind on a side stream, so that the first half's expansion writes while the
+    // second half's projection reads -- the box copies the step's vectors at 5.2-5.8 TB/s where
+    // reads-then-writes reach 4.3-4.8.  C5, same box, two alternations: 0.482 / 0.482 ms split
+    // against 0.458 / 0.428 as one batch (periodic 0.546 / 0.547 against 0.518 / 0.508): the two
+    // queues' workgroups do not share the chip the way one kernel's loads and stores do.)
+    const int chunks = lr_project<R>(g, X, nrows, st);
+    lr_mix<R>(g, g->lr_part, chunks, nvec, Q, Cq, Bq, g->lr_zhat, st);
+    // (ski_mvm_int: the W kernel expands, k_spmv_w_poly -- ranks 24 and 32 only: at rank 48
+    // the evaluation costs more than the two vector passes it saves -- measured, C5
+    // periodic: 5.03 against 4.17 ms per solver round)
+    if (deferred) {
+        g->expand_deferred = true;
+        return;
+    }
+    lr_expand<R>(g, g->lr_zhat, nrows, Y, accumulate, st);
 }
 
 // Y = Phi [sum_q B_q (x) C_q] Phi^T X for tops [q0, q0 + Q) with coupling Bq
