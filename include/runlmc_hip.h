@@ -36,11 +36,11 @@ typedef struct rl_gridop rl_gridop;
 typedef struct rl_ski rl_ski;
 
 /* Version of this ABI: bumped whenever a declared signature changes (2: rl_solve_batch_lanczos
- * gained `method`, round 4; 3: rl_gridop_form_stats added, round 5; callers built against an
- * older version must be rebuilt).  A binding
+ * gained `method`, round 4; 3: rl_gridop_form_stats added, round 5; 4: rl_ski_factor,
+ * rl_solve_direct added, round 6; callers built against an older version must be rebuilt).  A binding
  * compares rl_abi_version() with the RL_ABI_VERSION it was written against before its
  * first call (runlmc_amd/_lib.py does) instead of finding out through shifted arguments. */
-#define RL_ABI_VERSION 3
+#define RL_ABI_VERSION 4
 int rl_abi_version(void);
 
 const char* rl_last_error(void);
@@ -214,6 +214,44 @@ int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, int 
                            double tol, int check_every, int maxiter, int* iters_out,
                            double* resid_out, int* istop_out, double* lanczos_out,
                            int lanczos_cap, void* stream);
+
+/* ---- direct solves through the polynomial form ------------------------------
+ * The reference's Iterative.solve takes a preconditioner from the operator
+ * (runlmc/approx/iterative.py:47-51: M = getattr(K, 'preconditioner', None), handed to
+ * SciPy's minres / cg) and no reference operator provides one.  This library does, for
+ * operators whose top rows are ALL in the polynomial-subspace form (rl_gridop_form,
+ * rank r): such a K~ is  F M F^T + diag(eps)  with F = W Phi block-diagonal by output
+ * (n x D r) -- a diagonal plus rank D r -- and the Woodbury identity gives
+ *     K~^-1 b = E^-1 b - E^-1 F Z F^T E^-1 b          (Z: D r x D r, host Cholesky)
+ *     log det K~ = sum_d n_d log eps_d + log det(I + L^T M L),   F^T E^-1 F = L L^T
+ * (csrc/rl_direct.h).  With M = K~^-1 to roundoff a preconditioned iteration IS
+ * iterative refinement, and the reference's own residual rule ends it.
+ *
+ * rl_ski_factor: (re)builds the factorisation for the CURRENT parameters and noise
+ * (cached on the handle until either changes; runs the pending set-time verification of
+ * the polynomial form whatever the batch gate).  *available = 0 when the operator has
+ * no such form (a top row on the transform or filter kernels, several grids, a 2-D
+ * grid, D > 16, noise not constant per output, an output with fewer rows than the
+ * basis) -- rl_last_error() then says which; that is not an error.  *logdet receives
+ * log det K~ of the handle's operator -- the quantity the reference computes by a dense
+ * Cholesky (models/interpolated_llgp.py:262-276) -- and *cond an estimate of the condition
+ * number of the D r x D r system (squared ratio of its Cholesky pivots).  Any pointer may
+ * be NULL.                                                                              */
+int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond);
+/* X[v] = K~^-1 B[v]:  x = M b, then  x += M (b - K~ x)  while the reference's rule
+ * ||b - K~ x||_2 < tol (iterative.py:36-42,54-58) does not hold, at most max_refine
+ * times (the residual is taken through the handle's ordinary product, rl_ski_mvm's
+ * path).  B, X dev [nrhs][n], may not alias.
+ *   iters_out host [nrhs]  applications of M (1 + refinements) -- the count a
+ *                          preconditioned Krylov method would report
+ *   resid_out host [nrhs]  final ||b - K~ x||_2
+ *   istop_out host [nrhs]  10 = the reference's residual rule; 12 = tolerance not
+ *                          reached within max_refine refinements (the iterate is
+ *                          returned, as the reference returns its own: iterative.py:55-58)
+ * RL_ELIMIT when rl_ski_factor would report *available = 0.  Synchronises.            */
+int rl_solve_direct(rl_ski* s, const double* B, double* X, int nrhs, double tol,
+                    int max_refine, int* iters_out, double* resid_out, int* istop_out,
+                    void* stream);
 
 /* ---- partial sums of the Hutchinson gradient --------------------------------
  * Replace the P*(N+1) operator products of StochasticDeriv.d_normal_quadratic

@@ -53,10 +53,12 @@ _SIGNATURES = {
     'rl_ski_apply_w': [_vp, _vp, _vp, _i, _vp],
     'rl_solve_batch': [_vp, _vp, _vp, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp],
     'rl_solve_batch_lanczos': [_vp, _vp, _vp, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    'rl_ski_factor': [_vp, _c_int_p, _c_dbl_p, _c_dbl_p],
+    'rl_solve_direct': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp],
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 }
-ABI_VERSION = 3      # include/runlmc_hip.h: RL_ABI_VERSION
+ABI_VERSION = 4      # include/runlmc_hip.h: RL_ABI_VERSION
 _RESTYPE = {'rl_last_error': ctypes.c_char_p, 'rl_backend': ctypes.c_char_p}
 
 

@@ -242,6 +242,18 @@ class SkiOp:
             raise ValueError('noise and lens must have one entry per output')
         self.lib.call('rl_ski_set_noise', self._h, host_ptr(noise), host_ptr(lens))
 
+    def factor(self):
+        """(available, logdet, cond): builds / refreshes the Woodbury factorisation of
+        K~ = F M F^T + diag(eps) for the current parameters (include/runlmc_hip.h:
+        rl_ski_factor).  available is False when some top row is not in the polynomial
+        form (or the operator is otherwise outside it); `reason` then says why."""
+        av, ld, cond = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        self.lib.call('rl_ski_factor', self._h, ctypes.byref(av), ctypes.byref(ld),
+                      ctypes.byref(cond))
+        self.factor_reason = ('' if av.value else
+                              self.lib.cdll.rl_last_error().decode())
+        return bool(av.value), float(ld.value), float(cond.value)
+
     def mvm(self, X, out=None):
         if out is None:
             out = torch.empty_like(X)
@@ -296,6 +308,22 @@ def solve_batch(ski, B, method=MINRES, tol=1e-4, check_every=100, maxiter=0,
     ski.lib.call('rl_solve_batch', ski.handle, dev_ptr(B), dev_ptr(X), k,
                  int(method), float(tol), int(check_every), int(maxiter),
                  host_ptr(iters), host_ptr(resid), host_ptr(istop),
+                 ski.lib.stream_ptr(ski.device))
+    return X, iters, resid, istop
+
+
+def solve_direct(ski, B, tol=1e-4, max_refine=4):
+    """Device batched solve K~ X = B through the polynomial form's Woodbury
+    factorisation + iterative refinement to the reference's residual rule
+    (include/runlmc_hip.h: rl_solve_direct).  Returns (X, iterations, residuals,
+    istop); NotImplementedError when the operator has no such form."""
+    k = B.shape[0]
+    X = torch.empty_like(B)
+    iters = np.zeros(k, dtype=np.int32)
+    istop = np.zeros(k, dtype=np.int32)
+    resid = np.zeros(k, dtype=np.float64)
+    ski.lib.call('rl_solve_direct', ski.handle, dev_ptr(B), dev_ptr(X), k, float(tol),
+                 int(max_refine), host_ptr(iters), host_ptr(resid), host_ptr(istop),
                  ski.lib.stream_ptr(ski.device))
     return X, iters, resid, istop
 

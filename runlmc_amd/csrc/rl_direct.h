@@ -1,0 +1,130 @@
+// Direct solves through the polynomial form (round 6).
+//
+// When every top row of the grid operator is in the polynomial-subspace form
+// (rl_lowrank.h) the SKI operator of reference approx/ski.py:13-16 is, to the 2e-13 the
+// form is verified to at set time,
+//
+//     K~ = F M F^T + E,     F = W Phi  block-diagonal by output (n x D r; rl_rowpoly.h),
+//                           M = sum_q B_q (x) C_q  (D r x D r),   E = diag(eps_d) per output
+//
+// -- a diagonal plus rank D r (240 at BASELINE's C5).  With G = F^T E^-1 F (block-diagonal:
+// G_d = F_d^T F_d / eps_d, the Gram matrices F_d^T F_d built ONCE per handle and rank) and
+// G = L L^T,  S = I + L^T M L  (symmetric positive definite, D r x D r, host Cholesky):
+//
+//     K~^-1 b = E^-1 b - E^-1 F Z F^T E^-1 b,     Z = L^-T (I - S^-1) L^-1
+//     log det K~ = sum_d n_d log eps_d + log det S                        (exactly)
+//
+// i.e. ONE projection (k_rp_project), one dense D r x D r map on the coefficients
+// (k_dz_mix below) and ONE expansion (k_rp_expand with 1/eps as its diagonal) per batch,
+// where the Krylov solve of reference approx/iterative.py:23-62 runs hundreds of rounds
+// and, at C5's conditioning, never reaches the reference's own 1e-4 residual rule in fp64.
+// The reference's hook for exactly this is its preconditioner argument
+// (iterative.py:47-51: M = getattr(K, 'preconditioner', None)); with M = K~^-1 to roundoff
+// a preconditioned iteration is iterative refinement: x += M (b - K~ x) until the
+// reference's rule ||b - K~ x||_2 < tol holds (host loop: runlmc_hip.hip, rl_solve_direct).
+//
+// Scalings: the streaming kernels work with the UNNORMALISED polynomials q_j (Phi_j = nu_j
+// q_j), so the host folds nu and 1/eps into the map it uploads:
+//     Zs[(a,i)][(b,j)] = -(nu_i / eps_a) Z[(a,i)][(b,j)] (nu_j / eps_b)
+//     x = (1/eps) (.) b + F_q (Zs (F_q^T b))
+#pragma once
+#include "rl_device.h"
+
+#define RL_DZ_VB 4            // vectors per k_dz_mix workgroup (the map's rows are read once for them)
+
+// ---------------------------------------------------------------------------
+// k_dz_mix: zhat[v][e] = sum_f Zt[f][e] S[v][f],   S[v][(b, j)] = sum_{runs c of output b}
+// part[c][v][j]  (k_rp_project's partial sums, ascending run order as in k_lr_mix).
+//   grid (ceil(nvec / RL_DZ_VB))   block 256   LDS: S [RL_DZ_VB][D r]
+// Zt is the map TRANSPOSED (it is symmetric; the layout only says that consecutive
+// threads read consecutive addresses).  A thread owns output coefficients e, e + 256, ...
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_dz_mix(const double* __restrict__ part, const int* __restrict__ run_ptr, int nvec, int D, int r,
+         const double* __restrict__ Zt, double* __restrict__ zhat) {
+    RL_SMEM(smem);
+    double* S = reinterpret_cast<double*>(smem);          // [RL_DZ_VB][Dr]
+    const int tid = threadIdx.x, Dr = D * r;
+    const int v0 = blockIdx.x * RL_DZ_VB;
+    for (int e = tid; e < Dr; e += 256) {
+        const int b = e / r, j = e - b * r;
+        const int c0 = run_ptr[b], c1 = run_ptr[b + 1];
+#pragma unroll
+        for (int k = 0; k < RL_DZ_VB; ++k) {
+            const int v = v0 + k < nvec ? v0 + k : nvec - 1;
+            const double* src = part + (size_t)v * r + j;
+            double s = 0.0;
+            for (int c = c0; c < c1; ++c) s += src[(size_t)c * nvec * r];
+            S[k * Dr + e] = s;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < Dr; e += 256) {
+        double acc[RL_DZ_VB];
+#pragma unroll
+        for (int k = 0; k < RL_DZ_VB; ++k) acc[k] = 0.0;
+        for (int f = 0; f < Dr; ++f) {
+            const double z = Zt[(size_t)f * Dr + e];
+#pragma unroll
+            for (int k = 0; k < RL_DZ_VB; ++k) acc[k] = fma(z, S[k * Dr + f], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < RL_DZ_VB; ++k)
+            if (v0 + k < nvec) zhat[(size_t)(v0 + k) * Dr + e] = acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_dz_resid: R[v][i] = B[v][i] - R[v][i]  (R holds K~ x on entry), partial[v][blk] = the
+// block's sum of squares (fixed order).   grid (nblk, nrhs)   block 256
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_dz_resid(const double* __restrict__ B, double* __restrict__ R, int n,
+           double* __restrict__ partial) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const double* pb = B + (size_t)rhs * n;
+    double* pr = R + (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const double d = pb[i] - pr[i];
+        pr[i] = d;
+        acc = fma(d, d, acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)rhs * gridDim.x + blockIdx.x] = red[0];
+}
+
+// resid[v] = sqrt(sum of the system's partials)   grid (ceil(nrhs / 64))   block 64
+__global__ void __launch_bounds__(64)
+k_dz_norms(const double* __restrict__ partial, int nblk, int nrhs, double* __restrict__ resid) {
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= nrhs) return;
+    double s = 0.0;
+    for (int c = 0; c < nblk; ++c) s += partial[(size_t)v * nblk + c];
+    resid[v] = sqrt(s);
+}
+
+// ---------------------------------------------------------------------------
+// k_dz_axpy: X[v] += T[v] for the systems still being refined (go[v] != 0).
+//   grid (nblk, nrhs)   block 256
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_dz_axpy(double* __restrict__ X, const double* __restrict__ T, int n,
+          const int* __restrict__ go) {
+    const int rhs = blockIdx.y;
+    if (!go[rhs]) return;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    double* px = X + (size_t)rhs * n;
+    const double* pt = T + (size_t)rhs * n;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) px[i] += pt[i];
+}

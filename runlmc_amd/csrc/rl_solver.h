@@ -33,6 +33,7 @@ enum { I_ISTOP = 0, I_ITN, I_ACTIVE, I_NFIELDS };
 // exit reasons beyond SciPy's istop codes
 #define RL_ISTOP_RESIDUAL 10   // reference rule: ||b - A x|| < tol at a check
 #define RL_ISTOP_ZERO_RHS 11
+#define RL_ISTOP_DIRECT_STALL 12   // rl_solve_direct: tolerance not reached within max_refine refinements
 
 // Deterministic block sums.  On the GPU: shuffles inside each wavefront (no
 // barrier), one partial per wavefront through LDS, every thread adds the few

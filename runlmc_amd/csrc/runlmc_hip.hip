@@ -414,6 +414,9 @@ struct rl_gridop {
     double* lr_C = nullptr;     // dev [max_tops][r][r]
     double* lr_M = nullptr;     // dev [D][24][D][24]: the whole coefficient map (polynomial rounds)
     std::vector<double> lr_hC;  // host copy of lr_C for it
+    std::vector<double> lr_hB;  // host [Q][D][D]: the couplings lr_B holds (direct solves, rl_direct.h)
+    std::vector<double> lr_hnu; // host copy of lr_nu
+    unsigned long long param_ver = 0;   // bumped by every parameter update (what a factorisation was built for)
     double* lr_B = nullptr;     // dev [max_tops][D][D]
     double* lr_eye = nullptr;   // dev [D][D]
     double* lr_part = nullptr;  // projection partial sums
@@ -1020,6 +1023,7 @@ static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector
         return fail(RL_ELIMIT, "rl_gridop_set: total rank exceeds max_tops*D");
     g->lr_ok = false;
     g->lr_dirty = false;
+    ++g->param_ver;
     int rc = set_common(g, Q, tops);
     if (rc == RL_OK) rc = set_factors(g, A, W, Qi, kap);
     g->st_ok = false;
@@ -1519,6 +1523,7 @@ static int lr_make_basis(rl_gridop* g) {
     RL_TRY(upload(&g->lr_phiJ, phiJ));
     RL_TRY(upload(&g->lr_beta, beta));
     RL_TRY(upload(&g->lr_nu, nu));
+    g->lr_hnu = nu;
     return RL_OK;
 }
 
@@ -2437,6 +2442,7 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         const int r = g->lr_r;
         if (nfilt == 0) {
             RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
+            g->lr_hB = B;
             g->lr_ok = true;
             if (r == RL_LR_RS && !g->kn.no_poly_round) {
                 // the whole coefficient map of the solver's polynomial rounds
@@ -2863,6 +2869,25 @@ struct rl_ski {
     SolverWork ws;
     bool ws_valid = false;
     size_t ws_vec_cap = 0, ws_rhs_cap = 0, ws_part_cap = 0;
+    // direct solves through the polynomial form (rl_direct.h): K~ = F M F^T + E
+    unsigned long long noise_ver = 0;   // bumped by rl_ski_set_noise
+    std::vector<double> h_noise;        // host copy of noise_diag (internal row order)
+    std::vector<int> h_run_ptr, h_out_end;   // host copies of rp_run_ptr / rp_out_end
+    std::vector<double> dz_U;           // host [D][r][r]: F_d^T F_d on the unnormalised q_j, per (handle, rank)
+    int dz_U_R = 0;
+    double* dz_Zt = nullptr;            // dev [D r][D r]: the solve map, scalings folded in
+    size_t dz_Zt_cap = 0;
+    double* dz_inv = nullptr;           // dev [n]: 1 / eps per row
+    bool dz_valid = false;              // ... for the parameters / noise of the versions below
+    unsigned long long dz_param_ver = 0, dz_noise_ver = 0;
+    int dz_R = 0;
+    double dz_logdet = 0.0;             // log det K~ of that factorisation
+    double dz_cond = 0.0;               // ratio of the largest to the smallest pivot of chol(S), squared
+    double *dz_res = nullptr, *dz_cor = nullptr;   // dev [cap][n]: residuals, corrections
+    size_t dz_vec_cap = 0;
+    double* dz_part = nullptr;          // dev [cap][RL_DZ_NBLK] partial sums, then [cap] norms
+    int* dz_go = nullptr;               // dev [cap]: systems still being refined
+    size_t dz_rhs_cap = 0;
 };
 
 // Small batches want every (row, vector) on its own thread (latency-bound);
@@ -3109,7 +3134,8 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
                     s->WT_data, s->noise_diag, s->G1, s->G2, s->perm, s->P1, s->P2,
                     s->W4_base, s->W4_w, s->WT_lo, s->lanczos_buf, s->poly_tab, s->poly_ob,
                     s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part, s->rp_nrm, s->rp_pp,
-                    s->rp_base_c, s->rp_w4_c};
+                    s->rp_base_c, s->rp_w4_c, s->dz_Zt, s->dz_inv, s->dz_res, s->dz_cor, s->dz_part,
+                    s->dz_go};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;
@@ -3154,6 +3180,8 @@ extern "C" int rl_ski_set_noise(rl_ski* s, const double* noise, const int* lens)
     RL_HIP(hipMemcpy(s->noise_diag, diag.data(), diag.size() * sizeof(double),
                      hipMemcpyHostToDevice));
     s->has_noise = true;
+    s->h_noise.swap(diag);
+    ++s->noise_ver;
     return RL_OK;
 }
 
@@ -3434,6 +3462,8 @@ static int rp_prepare(rl_ski* s, int nvec) {
         RL_TRY(upload_raw((void**)&s->rp_run_ptr, run_ptr.data(), run_ptr.size() * sizeof(int)));
         RL_TRY(upload_raw((void**)&s->rp_out_end, out_end.data(), out_end.size() * sizeof(int)));
         s->rp_nruns = run_ptr[D];
+        s->h_run_ptr = run_ptr;
+        s->h_out_end = out_end;
     }
     const size_t need = (size_t)s->rp_nruns * nvec * R;
     if (s->rp_part_cap < need) {
@@ -3738,6 +3768,7 @@ extern "C" int rl_ski_mvm(rl_ski* s, const double* X, double* Y, int nvec, void*
 // batched Krylov solves
 // ---------------------------------------------------------------------------
 #include "rl_solver.h"
+#include "rl_direct.h"
 
 static void free_work(SolverWork& w) {
     for (double*& p : w.vec) { if (p) (void)hipFree(p); p = nullptr; }
@@ -4466,6 +4497,415 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
         if (iters_out) iters_out[r] = hI[(size_t)r * I_NFIELDS + I_ITN];
         if (istop_out) istop_out[r] = hI[(size_t)r * I_NFIELDS + I_ISTOP];
         if (resid_out) resid_out[r] = hR[r];
+    }
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Direct solves through the polynomial form (rl_direct.h): K~ = F M F^T + E
+// ---------------------------------------------------------------------------
+#define RL_DZ_NBLK 120          // partial sums per system of the residual norms
+
+// in-place Cholesky factor (lower, row-major n x n; the strict upper part is left alone);
+// false when a pivot is not positive
+static bool dz_chol(std::vector<double>& a, int n) {
+    for (int i = 0; i < n; ++i) {
+        double* ai = a.data() + (size_t)i * n;
+        for (int j = 0; j <= i; ++j) {
+            const double* aj = a.data() + (size_t)j * n;
+            double s = ai[j];
+            for (int k = 0; k < j; ++k) s -= ai[k] * aj[k];
+            if (j < i) {
+                ai[j] = s / aj[j];
+            } else {
+                if (!(s > 0.0) || !std::isfinite(s)) return false;
+                ai[i] = std::sqrt(s);
+            }
+        }
+    }
+    return true;
+}
+// x = L^-1 (lower, row-major; x's strict upper part zero)
+static void dz_tri_inverse(const std::vector<double>& L, int n, std::vector<double>& x) {
+    x.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double* xi = x.data() + (size_t)i * n;
+        const double* li = L.data() + (size_t)i * n;
+        xi[i] = 1.0;
+        for (int k = 0; k < i; ++k) {
+            const double lik = li[k];
+            if (lik == 0.0) continue;
+            const double* xk = x.data() + (size_t)k * n;
+            for (int j = 0; j <= k; ++j) xi[j] -= lik * xk[j];
+        }
+        const double inv = 1.0 / li[i];
+        for (int j = 0; j <= i; ++j) xi[j] *= inv;
+    }
+}
+
+template <int R>
+static void rp_project_plain(rl_ski* s, const double* Xp, int nvec, hipStream_t st) {
+    rl_gridop* g = s->g;
+    constexpr int NT = (R + 15) / 16;
+    const RpFuse nofz{nullptr, nullptr, nullptr};
+    if (nvec <= RL_RP_VG + 1 && (nvec <= RL_RP_VG || nvec % RL_RP_VG == 1) && !s->kn.no_rp_small) {
+        const size_t lds1 = (((size_t)16 * NT + RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
+        RL_LAUNCH((k_rp_project1<R, false>), dim3(s->rp_nruns), dim3(256), lds1, st, Xp, s->n, nvec,
+                  (const double*)s->rp_F, (const int*)s->rp_runs, s->rp_part, (int*)nullptr,
+                  (const int*)s->W4_base, (const double*)s->W4_w, g->m, (const double*)g->lr_beta, nofz);
+        return;
+    }
+    const size_t lds = (((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
+    const int vblk = RL_RP_NG(R) * RL_RP_VG;
+    RL_LAUNCH((k_rp_project<R, false>), dim3(8 * ((s->rp_nruns + 7) / 8) * ((nvec + vblk - 1) / vblk)),
+              dim3(256), lds, st, Xp, s->n, nvec, (const double*)s->rp_F, (const int*)s->rp_runs,
+              s->rp_nruns, s->rp_part, (int*)nullptr, (const int*)s->W4_base, (const double*)s->W4_w,
+              g->m, (const double*)g->lr_beta, nofz);
+}
+// Yp = F zhat + diag (.) X2
+template <int R>
+static void rp_expand_plain(rl_ski* s, const double* zhat, double* Yp, int nvec, const double* diag,
+                            const double* X2, hipStream_t st) {
+    rl_gridop* g = s->g;
+    const RpPFuse nopf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (s->kn.rp_fly & 1)
+        RL_LAUNCH((k_rp_expand<R, true, false, true>), dim3((s->n + 255) / 256), dim3(256), 0, st, zhat,
+                  (const double*)s->rp_F, s->n, nvec, g->D, (const int*)s->rp_out_end, Yp, diag, X2,
+                  s->kn.rp_stagger, (const int*)s->W4_base, (const double*)s->W4_w, g->m,
+                  (const double*)g->lr_beta, nopf);
+    else
+        RL_LAUNCH((k_rp_expand<R, false, false, true>), dim3((s->n + 255) / 256), dim3(256), 0, st, zhat,
+                  (const double*)s->rp_F, s->n, nvec, g->D, (const int*)s->rp_out_end, Yp, diag, X2,
+                  s->kn.rp_stagger, (const int*)s->W4_base, (const double*)s->W4_w, g->m,
+                  (const double*)g->lr_beta, nopf);
+}
+#define RL_DZ_RANKS(CALL)                                                               \
+    switch (s->g->lr_r) {                                                                \
+        case 24: CALL(24); break;                                                        \
+        case 32: CALL(32); break;                                                        \
+        case 36: CALL(36); break;                                                        \
+        case 40: CALL(40); break;                                                        \
+        case 48: CALL(48); break;                                                        \
+        default: return fail(RL_EINVAL, "direct solve: bad basis size");                 \
+    }
+
+// May this handle's operator be inverted through its polynomial form?  Runs the pending
+// verification of the forms (whatever the batch gate says: the decision is the operator's,
+// not a batch's).  `why` receives the reason when not.
+static int dz_available(rl_ski* s, bool* ok, const char** why) {
+    rl_gridop* g = s->g;
+    *ok = false;
+    *why = "";
+    if (!s->extra.empty()) { *why = "kernels on several grids"; return RL_OK; }
+    if (g->wide) { *why = "more than 16 outputs"; return RL_OK; }
+    if (s->W4_base == nullptr || s->h_base.empty() || s->ngrid != g->D * g->m) {
+        *why = "W is not a cubic interpolant of a 1-D grid"; return RL_OK;
+    }
+    if (!g->lr_try || g->kn.no_rp || (s->kn.rp_fly & 2)) { *why = "polynomial form switched off or grid not eligible"; return RL_OK; }
+    if (s->n >= (1 << 28)) { *why = "n >= 2^28"; return RL_OK; }
+    if (g->Q < 1) { *why = "no parameters set"; return RL_OK; }
+    if (!s->has_noise || (int)s->h_noise.size() != s->n) { *why = "no noise set"; return RL_OK; }
+    RL_HIP(hipSetDevice(g->device));
+    RL_TRY(lr_ensure(g));
+    if (!g->lr_ok) { *why = "not every top row is in the polynomial form"; return RL_OK; }
+    if ((int)g->lr_hC.size() < g->Q * g->lr_r * g->lr_r || (int)g->lr_hB.size() < g->Q * g->D * g->D ||
+        (int)g->lr_hnu.size() < g->lr_r) { *why = "no host copy of the coefficient maps"; return RL_OK; }
+    *ok = true;
+    return RL_OK;
+}
+
+// builds (or rebuilds, after a parameter / noise update) the factorisation; *ok = false with
+// a reason when the operator has no such form or the factorisation breaks down
+static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
+    rl_gridop* g = s->g;
+    RL_TRY(dz_available(s, ok, why));
+    if (!*ok) { s->dz_valid = false; return RL_OK; }
+    const int R = g->lr_r, D = g->D, n = s->n, Dr = D * R, Q = g->Q;
+    if (s->dz_valid && s->dz_param_ver == g->param_ver && s->dz_noise_ver == s->noise_ver && s->dz_R == R)
+        return RL_OK;
+    s->dz_valid = false;
+    *ok = false;
+    hipStream_t st = nullptr;
+    RL_TRY(rp_prepare(s, std::max(R, 1)));
+    if (s->rp_F == nullptr || s->rp_R != R) { *why = "no table of F"; return RL_OK; }
+    // per-output noise, rows per output
+    std::vector<double> eps(D, 0.0);
+    std::vector<int> rows(D, 0);
+    for (int d = 0, a = 0; d < D; ++d) {
+        const int b = s->h_out_end[d];
+        rows[d] = b - a;
+        if (b > a) {
+            eps[d] = s->h_noise[a];
+            for (int i = a; i < b; ++i)
+                if (s->h_noise[i] != eps[d]) { *why = "noise is not constant per output"; return RL_OK; }
+        } else {
+            eps[d] = 1.0;
+        }
+        if (!(eps[d] > 0.0) || !std::isfinite(eps[d])) { *why = "noise is not positive"; return RL_OK; }
+        a = b;
+    }
+    // Gram matrices of F on the unnormalised basis, once per (handle, rank): the columns of F
+    // ARE a batch of R vectors (degree-major table)
+    if (s->dz_U_R != R) {
+#define RL_DZ_PROJ(R_) rp_project_plain<R_>(s, s->rp_F, R_, st)
+        RL_DZ_RANKS(RL_DZ_PROJ);
+#undef RL_DZ_PROJ
+        RL_HIP(hipGetLastError());
+        std::vector<double> part((size_t)s->rp_nruns * R * R);
+        RL_HIP(hipMemcpy(part.data(), s->rp_part, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+        s->dz_U.assign((size_t)D * R * R, 0.0);
+        for (int d = 0; d < D; ++d)
+            for (int c = s->h_run_ptr[d]; c < s->h_run_ptr[d + 1]; ++c)
+                for (int e = 0; e < R * R; ++e)
+                    s->dz_U[(size_t)d * R * R + e] += part[(size_t)c * R * R + e];
+        s->dz_U_R = R;
+    }
+    const double* nu = g->lr_hnu.data();
+    // G_d = nu nu^T (.) U_d / eps_d = L_d L_d^T; Li_d = L_d^-1
+    std::vector<std::vector<double>> L(D), Li(D);
+    for (int d = 0; d < D; ++d) {
+        L[d].assign((size_t)R * R, 0.0);
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < R; ++j) {
+                const double u = 0.5 * (s->dz_U[((size_t)d * R + i) * R + j] + s->dz_U[((size_t)d * R + j) * R + i]);
+                L[d][(size_t)i * R + j] = nu[i] * nu[j] * u / eps[d];
+            }
+        if (!dz_chol(L[d], R)) { *why = "an output has too few (or degenerate) rows for the basis"; return RL_OK; }
+        for (int i = 0; i < R; ++i)
+            for (int j = i + 1; j < R; ++j) L[d][(size_t)i * R + j] = 0.0;
+        dz_tri_inverse(L[d], R, Li[d]);
+    }
+    // S = I + L^T M L, M_ab = sum_q B_q[a][b] C_q  (C symmetrised)
+    std::vector<double> S((size_t)Dr * Dr, 0.0), Mab((size_t)R * R), T1((size_t)R * R);
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) {
+            std::fill(Mab.begin(), Mab.end(), 0.0);
+            bool any = false;
+            for (int q = 0; q < Q; ++q) {
+                const double bq = 0.5 * (g->lr_hB[((size_t)q * D + a) * D + b] + g->lr_hB[((size_t)q * D + b) * D + a]);
+                if (bq == 0.0) continue;
+                any = true;
+                const double* C = g->lr_hC.data() + (size_t)q * R * R;
+                for (int i = 0; i < R; ++i)
+                    for (int j = 0; j < R; ++j)
+                        Mab[(size_t)i * R + j] += bq * 0.5 * (C[(size_t)i * R + j] + C[(size_t)j * R + i]);
+            }
+            if (!any) continue;
+            // T1 = M_ab L_b   (L_b lower: column j of L_b has rows >= j)
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = j; k < R; ++k) acc += Mab[(size_t)i * R + k] * L[b][(size_t)k * R + j];
+                    T1[(size_t)i * R + j] = acc;
+                }
+            // A_ab = L_a^T T1
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = i; k < R; ++k) acc += L[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
+                    S[((size_t)a * R + i) * Dr + (size_t)b * R + j] = acc;
+                    S[((size_t)b * R + j) * Dr + (size_t)a * R + i] = acc;
+                }
+        }
+    for (int i = 0; i < Dr; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double v = 0.5 * (S[(size_t)i * Dr + j] + S[(size_t)j * Dr + i]);
+            S[(size_t)i * Dr + j] = v;
+            S[(size_t)j * Dr + i] = v;
+        }
+    for (int i = 0; i < Dr; ++i) S[(size_t)i * Dr + i] += 1.0;
+    if (!dz_chol(S, Dr)) { *why = "I + L^T M L is not positive definite (M is not positive semi-definite to roundoff)"; return RL_OK; }
+    double logdet = 0.0, pmin = 1e300, pmax = 0.0;
+    for (int i = 0; i < Dr; ++i) {
+        const double p = S[(size_t)i * Dr + i];
+        logdet += 2.0 * std::log(p);
+        pmin = std::min(pmin, p);
+        pmax = std::max(pmax, p);
+    }
+    for (int d = 0; d < D; ++d) logdet += rows[d] * std::log(eps[d]);
+    // Y = I - S^-1 = I - X^T X, X = chol(S)^-1
+    std::vector<double> X;
+    dz_tri_inverse(S, Dr, X);
+    std::vector<double> Y((size_t)Dr * Dr, 0.0);
+    for (int k = 0; k < Dr; ++k) {
+        const double* xk = X.data() + (size_t)k * Dr;
+        for (int i = 0; i <= k; ++i) {
+            const double xi = xk[i];
+            if (xi == 0.0) continue;
+            double* yi = Y.data() + (size_t)i * Dr;
+            for (int j = 0; j <= i; ++j) yi[j] -= xi * xk[j];
+        }
+    }
+    for (int i = 0; i < Dr; ++i) {
+        Y[(size_t)i * Dr + i] += 1.0;
+        for (int j = 0; j < i; ++j) Y[(size_t)j * Dr + i] = Y[(size_t)i * Dr + j];
+    }
+    // Z_ab = Li_a^T Y_ab Li_b, scaled:  Zs = -(nu_i / eps_a) Z (nu_j / eps_b)
+    std::vector<double> Zs((size_t)Dr * Dr, 0.0);
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) {
+            // T1 = Y_ab Li_b  (Li_b lower)
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = j; k < R; ++k)
+                        acc += Y[((size_t)a * R + i) * Dr + (size_t)b * R + k] * Li[b][(size_t)k * R + j];
+                    T1[(size_t)i * R + j] = acc;
+                }
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = i; k < R; ++k) acc += Li[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
+                    const double v = -(nu[i] / eps[a]) * acc * (nu[j] / eps[b]);
+                    Zs[((size_t)a * R + i) * Dr + (size_t)b * R + j] = v;
+                    Zs[((size_t)b * R + j) * Dr + (size_t)a * R + i] = v;
+                }
+        }
+    for (double v : Zs)
+        if (!std::isfinite(v)) { *why = "the solve map is not finite"; return RL_OK; }
+    if (s->dz_Zt_cap < Zs.size()) {
+        if (s->dz_Zt) RL_HIP(hipFree(s->dz_Zt));
+        s->dz_Zt = nullptr;
+        s->dz_Zt_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->dz_Zt, Zs.size() * sizeof(double)));
+        s->dz_Zt_cap = Zs.size();
+    }
+    RL_HIP(hipMemcpy(s->dz_Zt, Zs.data(), Zs.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> inv((size_t)n);
+    for (int i = 0; i < n; ++i) inv[i] = 1.0 / s->h_noise[i];
+    if (!s->dz_inv) RL_HIP(hipMalloc((void**)&s->dz_inv, (size_t)n * sizeof(double)));
+    RL_HIP(hipMemcpy(s->dz_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->dz_logdet = logdet;
+    s->dz_cond = (pmax / pmin) * (pmax / pmin);
+    s->dz_param_ver = g->param_ver;
+    s->dz_noise_ver = s->noise_ver;
+    s->dz_R = R;
+    s->dz_valid = true;
+    *ok = true;
+    return RL_OK;
+}
+
+// out = K~^-1 in (to roundoff), both in internal row order; in and out may not alias
+static int dz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st) {
+    rl_gridop* g = s->g;
+    const int R = g->lr_r, D = g->D;
+#define RL_DZ_PROJ(R_) rp_project_plain<R_>(s, in, nvec, st)
+    RL_DZ_RANKS(RL_DZ_PROJ);
+#undef RL_DZ_PROJ
+    RL_LAUNCH(k_dz_mix, dim3((nvec + RL_DZ_VB - 1) / RL_DZ_VB), dim3(256),
+              (size_t)RL_DZ_VB * D * R * sizeof(double), st, (const double*)s->rp_part,
+              (const int*)s->rp_run_ptr, nvec, D, R, (const double*)s->dz_Zt, g->lr_zhat);
+#define RL_DZ_EXP(R_) rp_expand_plain<R_>(s, g->lr_zhat, out, nvec, s->dz_inv, in, st)
+    RL_DZ_RANKS(RL_DZ_EXP);
+#undef RL_DZ_EXP
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond) {
+    if (!s) return fail(RL_EINVAL, "rl_ski_factor: NULL handle");
+    bool ok = false;
+    const char* why = "";
+    RL_TRY(dz_ensure(s, &ok, &why));
+    if (available) *available = ok ? 1 : 0;
+    if (logdet) *logdet = ok ? s->dz_logdet : 0.0;
+    if (cond) *cond = ok ? s->dz_cond : 0.0;
+    if (!ok) g_err = std::string("direct solve not available: ") + why;
+    return RL_OK;
+}
+
+extern "C" int rl_solve_direct(rl_ski* s, const double* B, double* X, int nrhs, double tol,
+                               int max_refine, int* iters_out, double* resid_out, int* istop_out,
+                               void* stream) {
+    if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_direct: NULL argument");
+    if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_direct: nrhs < 0");
+    if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_direct: tol must be > 0");
+    if (max_refine < 0) return fail(RL_EINVAL, "rl_solve_direct: max_refine < 0");
+    if (nrhs == 0) return RL_OK;
+    rl_gridop* g = s->g;
+    RL_HIP(hipSetDevice(g->device));
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+    const char* why = "";
+    RL_TRY(dz_ensure(s, &ok, &why));
+    if (!ok) return fail(RL_ELIMIT, std::string("rl_solve_direct: not available for this operator: ") + why);
+    const int n = s->n, R = g->lr_r;
+    // everything the kernels below allocate lazily
+    RL_TRY(rp_prepare(s, std::max(nrhs, R)));
+    RL_TRY(ski_reserve(s, nrhs));
+    RL_TRY(gridop_prepare(g, nrhs));
+    if (rp_ok(s, nrhs)) RL_TRY(rp_prepare(s, nrhs));
+    RL_TRY(ski_reserve_perm(s, nrhs));
+    const size_t ve = (size_t)nrhs * n;
+    if (s->dz_vec_cap < ve) {
+        if (s->dz_res) RL_HIP(hipFree(s->dz_res));
+        if (s->dz_cor) RL_HIP(hipFree(s->dz_cor));
+        s->dz_res = s->dz_cor = nullptr;
+        s->dz_vec_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->dz_res, ve * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&s->dz_cor, ve * sizeof(double)));
+        s->dz_vec_cap = ve;
+    }
+    if (s->dz_rhs_cap < (size_t)nrhs) {
+        if (s->dz_part) RL_HIP(hipFree(s->dz_part));
+        if (s->dz_go) RL_HIP(hipFree(s->dz_go));
+        s->dz_part = nullptr;
+        s->dz_go = nullptr;
+        s->dz_rhs_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->dz_part, (size_t)nrhs * (RL_DZ_NBLK + 1) * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&s->dz_go, (size_t)nrhs * sizeof(int)));
+        s->dz_rhs_cap = (size_t)nrhs;
+    }
+    const double* Bi = B;
+    double* Xi = X;
+    if (s->permuted) {
+        permute_rows(s, B, s->P1, nrhs, 0, st);
+        Bi = s->P1;
+        Xi = s->P2;
+    }
+    const int nblk = std::max(1, std::min(RL_DZ_NBLK, (n + 1023) / 1024));
+    double* norms = s->dz_part + (size_t)nrhs * RL_DZ_NBLK;
+    std::vector<double> res((size_t)nrhs, 0.0), best((size_t)nrhs, 1e300);
+    std::vector<int> go((size_t)nrhs, 1), its((size_t)nrhs, 1), stop((size_t)nrhs, 0);
+    trace_once("solve: direct, through the polynomial form (k_rp_project / k_dz_mix / k_rp_expand)");
+    RL_TRY(dz_apply(s, Bi, Xi, nrhs, st));
+    for (int it = 0;; ++it) {
+        // r = b - K~ x and its norm; the reference's rule ends a system (iterative.py:36-42,54-58)
+        RL_TRY(ski_mvm_int(s, Xi, s->dz_res, nrhs, st));
+        RL_LAUNCH(k_dz_resid, dim3(nblk, nrhs), dim3(256), 256 * sizeof(double), st, Bi, s->dz_res, n,
+                  s->dz_part);
+        RL_LAUNCH(k_dz_norms, dim3((nrhs + 63) / 64), dim3(64), 0, st, (const double*)s->dz_part, nblk,
+                  nrhs, norms);
+        RL_HIP(hipGetLastError());
+        RL_HIP(hipMemcpyAsync(res.data(), norms, (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, st));
+        RL_HIP(hipStreamSynchronize(st));
+        int active = 0;
+        for (int v = 0; v < nrhs; ++v) {
+            if (!go[v]) continue;
+            if (res[v] < tol) {
+                go[v] = 0;
+                stop[v] = RL_ISTOP_RESIDUAL;
+            } else if (!std::isfinite(res[v]) || it >= max_refine) {
+                go[v] = 0;
+                stop[v] = RL_ISTOP_DIRECT_STALL;
+            } else {
+                ++active;
+            }
+        }
+        if (active == 0) break;
+        RL_HIP(hipMemcpyAsync(s->dz_go, go.data(), (size_t)nrhs * sizeof(int), hipMemcpyHostToDevice, st));
+        RL_TRY(dz_apply(s, s->dz_res, s->dz_cor, nrhs, st));
+        RL_LAUNCH(k_dz_axpy, dim3(nblk, nrhs), dim3(256), 0, st, Xi, (const double*)s->dz_cor, n,
+                  (const int*)s->dz_go);
+        for (int v = 0; v < nrhs; ++v) its[v] += go[v];
+    }
+    if (s->permuted) permute_rows(s, Xi, X, nrhs, 1, st);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(st));
+    for (int v = 0; v < nrhs; ++v) {
+        if (iters_out) iters_out[v] = its[v];
+        if (resid_out) resid_out[v] = res[v];
+        if (istop_out) istop_out[v] = stop[v];
     }
     return RL_OK;
 }

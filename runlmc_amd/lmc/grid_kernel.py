@@ -22,7 +22,7 @@ import torch
 from ..linalg.matrix import Matrix, check_vector, check_block
 from ..linalg.diag import Diag
 from ..linalg.sum_matrix import SumMatrix
-from .._native import GridOp, SkiOp
+from .._native import GridOp, SkiOp, solve_direct
 from .._lib import as_f64
 
 
@@ -166,6 +166,48 @@ class GridKernel(Matrix):
         return self.ski.as_numpy()
 
 
+class FactoredInverse(Matrix):
+    """K~^-1 through the Woodbury factorisation of K~ = F M F^T + diag(eps) that an
+    operator wholly in the polynomial form admits (csrc/rl_direct.h): what
+    ``LMCOperator.preconditioner`` hands to ``Iterative.solve`` -- the reference reads
+    the same attribute (approx/iterative.py:47: ``M = getattr(K, 'preconditioner', None)``)
+    and no reference operator sets it.  As a Matrix it applies K~^-1 (one pass, no
+    refinement); ``solve`` refines to the reference's residual rule."""
+
+    MAX_REFINE = 4
+
+    def __init__(self, skiop):
+        super().__init__(skiop.n, skiop.n)
+        self._skiop = skiop
+
+    def solve(self, B, tol=1e-4, max_refine=None):
+        """B: (k, n) tensor on the device.  (X, applications of K~^-1, residuals, istop)."""
+        return solve_direct(self._skiop, B, tol=tol,
+                            max_refine=self.MAX_REFINE if max_refine is None else max_refine)
+
+    def logdet(self):
+        """log det K~, exactly (determinant lemma) -- the reference's dense
+        ``log_det_K`` (models/interpolated_llgp.py:262-276) without the Cholesky."""
+        ok, ld, _ = self._skiop.factor()
+        if not ok:
+            raise ValueError(self._skiop.factor_reason)
+        return ld
+
+    def matmat_device(self, X):
+        return solve_direct(self._skiop, X.contiguous(), tol=np.finfo(np.float64).max,
+                            max_refine=0)[0]
+
+    def matvec(self, x):
+        x = check_vector(x, self.shape[1])
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)[None, :])
+        return self.matmat_device(t.to(self._skiop.device)).cpu().numpy()[0]
+
+    def matmat(self, X):
+        X = check_block(X, self.shape[1])
+        t = torch.from_numpy(np.ascontiguousarray(X.T, dtype=np.float64))
+        return self.matmat_device(t.to(self._skiop.device)).cpu().numpy().T
+
+
 class LMCOperator(SumMatrix):
     """K~ = sum over active-dimension sets of GridKernel + Diag(noise): the
     SumMatrix gen_grid_kernel returns (reference grid_kernel.py:66-74), with
@@ -187,6 +229,15 @@ class LMCOperator(SumMatrix):
 
     def device_operator(self):
         return self._skiop
+
+    @property
+    def preconditioner(self):
+        """The attribute the reference's Iterative.solve looks for (approx/iterative.py:47).
+        A FactoredInverse when every top row of the CURRENT parameters is in the
+        polynomial form (the factorisation is rebuilt on the device handle whenever
+        parameters or noise changed), else None -- the Krylov path as before."""
+        ok = self._skiop.factor()[0]
+        return FactoredInverse(self._skiop) if ok else None
 
     @property
     def device(self):

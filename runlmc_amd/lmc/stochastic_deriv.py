@@ -18,9 +18,11 @@ class StochasticDerivService:
     # Lanczos steps kept per system for the log-determinant quadrature
     LANCZOS_CAP = 256
 
-    def __init__(self, metrics, pool, n_it, tol, group=None, scipy_exits=None, maxiter=0):
-        # (the first four arguments are the reference's; scipy_exits / maxiter go to
-        # Iterative.solve_device unchanged: None = Iterative.SCIPY_EXITS, 0 = n iterations)
+    def __init__(self, metrics, pool, n_it, tol, group=None, scipy_exits=None, maxiter=0,
+                 precondition=None):
+        # (the first four arguments are the reference's; scipy_exits / maxiter / precondition go
+        # to Iterative.solve_device unchanged: None = Iterative.SCIPY_EXITS, 0 = n iterations,
+        # None = Iterative.PRECONDITION)
         self.metrics = metrics
         self._pool = pool          # interface compatibility only
         self._n_it = int(n_it)
@@ -28,6 +30,7 @@ class StochasticDerivService:
         self._group = group
         self._scipy_exits = scipy_exits
         self._maxiter = int(maxiter)
+        self._precondition = precondition
 
     def draw_probes(self, n):
         """+-1 probes from NumPy's legacy global RNG exactly as the reference
@@ -91,11 +94,18 @@ class StochasticDerivService:
                     np.ascontiguousarray(mine_rows, dtype=np.float64)).to(dev)
         Xf, iters, resid, istop, lanczos = Iterative.solve_device(
             K, Bfull, minres=True, tol=self._tol, maxiter=self._maxiter,
-            lanczos_cap=self.LANCZOS_CAP, scipy_exits=self._scipy_exits)
+            lanczos_cap=self.LANCZOS_CAP, scipy_exits=self._scipy_exits,
+            precondition=self._precondition)
         idx = torch.tensor(order, device=dev)
         X, B = Xf[idx], Bfull[idx]
         iters, resid, istop = (np.asarray(a)[order] for a in (iters, resid, istop))
-        lanczos = lanczos[order]
+        # (no Lanczos coefficients when the operator's preconditioner answered -- its
+        # factorisation holds log det K~ exactly instead)
+        logdet_exact = None
+        if lanczos is None:
+            logdet_exact = K.preconditioner.logdet()
+        else:
+            lanczos = lanczos[order]
         if self.metrics is not None:
             # mean over the N+1 systems; alpha (solved everywhere) counted once
             lo = 0 if rank == 0 else 1
@@ -108,7 +118,7 @@ class StochasticDerivService:
         broadcast_(alpha, src=0, group=self._group)        # (no-op in a world of one)
         return StochasticDeriv(alpha, B[1:], X[1:], self._n_it, group=self._group,
                                iterations=iters, residuals=resid, istop=istop,
-                               lanczos=lanczos)
+                               lanczos=lanczos, logdet_exact=logdet_exact)
 
     def _concurrent_solve(self, ls):
         """Reference entry point (stochastic_deriv.py:51-52): a list of
@@ -129,7 +139,7 @@ class StochasticDeriv(Derivative):
     ``n_it`` is the GLOBAL probe count (the 1/N of the estimator)."""
 
     def __init__(self, alpha, rs, inv_rs, n_it, group=None, iterations=None,
-                 residuals=None, istop=None, lanczos=None):
+                 residuals=None, istop=None, lanczos=None, logdet_exact=None):
         to_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(a, dtype=np.float64))
         self.alpha_dev = to_t(alpha)
@@ -139,6 +149,7 @@ class StochasticDeriv(Derivative):
         self._group = group
         self.iterations, self.residuals, self.istop = iterations, residuals, istop
         self.lanczos = lanczos
+        self.logdet_exact = logdet_exact
         self._alpha_host = None
 
     @property
@@ -168,8 +179,11 @@ class StochasticDeriv(Derivative):
         return slq_quadratic_forms(self.lanczos[1:], its, sq)
 
     def logdet_K(self):
-        """Hutchinson + Lanczos-quadrature estimate of log det K (mean over
-        all ranks' probes)."""
+        """log det K: exact (determinant lemma, rl_ski_factor) when the solves went
+        through the operator's factorisation, else the Hutchinson + Lanczos-quadrature
+        estimate (mean over all ranks' probes)."""
+        if self.logdet_exact is not None:
+            return self.logdet_exact
         local = self.logdet_probe_estimates()
         tot = torch.tensor([float(local.sum())], dtype=torch.float64)
         all_reduce_sum_(tot, self._group)
