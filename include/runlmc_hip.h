@@ -37,7 +37,8 @@ typedef struct rl_ski rl_ski;
 
 /* Version of this ABI: bumped whenever a declared signature changes (2: rl_solve_batch_lanczos
  * gained `method`, round 4; 3: rl_gridop_form_stats added, round 5; 4: rl_ski_factor,
- * rl_solve_direct added, round 6; callers built against an older version must be rebuilt).  A binding
+ * rl_solve_direct, rl_ski_project,
+ * rl_gridop_project, rl_gridop_poly_coeffs, rl_slq_log_quadrature added, round 6; callers built against an older version must be rebuilt).  A binding
  * compares rl_abi_version() with the RL_ABI_VERSION it was written against before its
  * first call (runlmc_amd/_lib.py does) instead of finding out through shifted arguments. */
 #define RL_ABI_VERSION 4
@@ -81,7 +82,11 @@ int rl_gridop_info(const rl_gridop* g, int* L, int* N1, int* N2, int* colsA, int
  *                  project -> r x r map -> expand (csrc/rl_lowrank.h) -- the
  *                  same operator of bttb.py:144-148, verified per top row
  *                  against the transform kernels inside the set call.
- *   RUNLMC_NO_LOWRANK=1 keeps every handle on the transform kernels.        */
+ *   RUNLMC_NO_LOWRANK=1 keeps every handle on the transform kernels (an A/B
+ *   hook like RUNLMC_NO_FILTER and RUNLMC_LR_MIN below: read ONLY when
+ *   RUNLMC_DEBUG=1 is set as well -- without it the library runs its defaults and
+ *   names every hook it ignored once on stderr; the switches that are always
+ *   read are RUNLMC_POW2_ONLY, RUNLMC_WS_CACHE_MB and RUNLMC_TRACE).           */
 int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements);
 /* The form EACH top row runs in for the current parameters (forms host [Q], may
  * be NULL): 0 transform kernels; 1 polynomial-subspace form; 2 recursive
@@ -92,19 +97,24 @@ int rl_gridop_form(const rl_gridop* g, int* rank, long long* min_elements);
  * *structured = 1 when no top needs the transform kernels, so that operator
  * products of batches above the gate move x and y and nothing else.  Single-top
  * products (rl_gridop_mvm_top) take each top's own form either way.
- * RUNLMC_NO_FILTER=1 switches form 2 off.                                       */
+ * RUNLMC_NO_FILTER=1 (with RUNLMC_DEBUG=1) switches form 2 off.                  */
 int rl_gridop_top_forms(const rl_gridop* g, int* forms, int* structured);
 /* What the last set-time verification of the polynomial form measured for top row q
  * (host out4; zeros when the row was never a candidate): [0] max|T x - Phi C Phi^T x| /
  * max|T x| for the fixed trial vector, [1] the largest response to the first omitted
  * polynomials relative to the largest response inside the subspace, [2] the power
  * iteration's estimate of ||T - Phi C Phi^T||_2 (8 steps through the two products of this
- * handle), [3] the same iteration's ||T||_2.  The row is accepted when [0], [1] <= 2e-13 and
- * [2] <= 2e-13 [3]: a bound on the form's error for every input, not for one draw.
+ * handle, from the unit-norm trial vector), [3] the same iteration's ||T||_2.  The row is
+ * accepted when [0], [1] <= 2e-13 and [2] <= 2e-13 [3].  [2] and [3] are ESTIMATES FROM
+ * BELOW (a power iteration climbs towards the norm; after 8 steps from a vector with a
+ * ~1/sqrt(m) component along the leading eigenvector it holds roughly half of it or
+ * more), not upper bounds: the test catches an error the sampled tests miss in whatever
+ * direction it lies, with a margin of three decades to the honest rows' 2e-16, it does
+ * not prove ||E||_2 <= 2e-13 ||T||_2.
  * (Diagnostics of this library's own forms; the operator is bttb.py:144-148 either way.) */
 int rl_gridop_form_stats(const rl_gridop* g, int q, double* out4);
 /* Moves that batch gate for this handle (0: every batch; < 0: back to the
- * default, 2^20 elements or RUNLMC_LR_MIN).  Below the gate the polynomial
+ * default, 2^20 elements or RUNLMC_LR_MIN under RUNLMC_DEBUG=1).  Below the gate the polynomial
  * form is slower than the transform kernels (too few workgroups).           */
 int rl_gridop_set_form_gate(rl_gridop* g, long long min_elements);
 /* Parameters of the LMC kernel, in the reference's own factored form
@@ -215,6 +225,15 @@ int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, int 
                            double* resid_out, int* istop_out, double* lanczos_out,
                            int lanczos_cap, void* stream);
 
+/* Host helper for that estimate: out[v] = sqnorms[v] * e_1^T log(T_v) e_1 for the Lanczos
+ * tridiagonal T_v of system v (lanczos host [nrhs][cap][2] as rl_solve_batch_lanczos fills
+ * it, k = min(iters[v], cap) steps) -- Gauss quadrature of r^T log(K~) r by the implicit QL
+ * iteration carrying one row of the eigenvector matrix, O(k^2) per system, systems spread
+ * over `nthreads` host threads.  No device work.  (The mean of out over Rademacher probes,
+ * sqnorms = n, estimates log det K~.)                                                      */
+int rl_slq_log_quadrature(const double* lanczos, int nrhs, int cap, const int* iters,
+                          const double* sqnorms, double* out, int nthreads);
+
 /* ---- direct solves through the polynomial form ------------------------------
  * The reference's Iterative.solve takes a preconditioner from the operator
  * (runlmc/approx/iterative.py:47-51: M = getattr(K, 'preconditioner', None), handed to
@@ -238,6 +257,22 @@ int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, int 
  * number of the D r x D r system (squared ratio of its Cholesky pivots).  Any pointer may
  * be NULL.                                                                              */
 int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond);
+/* The pieces of that form, for callers that work in its coefficient space (the gradient's
+ * Gram terms: with T = Phi C Phi^T,  u~_a . T v~_b = c_u[a]^T C c_v[b],  c_u = Phi^T W^T u
+ * -- runlmc_amd/lmc/likelihood.py; reference loops: lmc/likelihood.py:48-96):
+ * rl_ski_project: out[v][d][j] = (Phi^T W^T X[v])[d][j], the r coefficients per output on the
+ * ORTHONORMAL polynomials (dev out [nvec][D][r], *rank = r; X dev [nvec][n], caller's row
+ * order); RL_ELIMIT when rl_ski_factor reports *available = 0.
+ * rl_gridop_poly_coeffs: C_q = Phi^T T_q Phi (symmetrised) of top row q into host out
+ * [r][r] (cap >= r * r values) and *rank = r -- or *rank = 0 when the row is not in the
+ * polynomial form (the pending verification runs first; out may be NULL to ask only).   */
+int rl_ski_project(rl_ski* s, const double* X, int nvec, double* out, int* rank, void* stream);
+/* The same for GRID vectors and any of the basis sizes: out[v][d][j] = (Phi_rank^T X[v][d])[j]
+ * (X dev [nvec][D*m], out dev [nvec][D][rank], rank one of 24, 32, 36, 40, 48) -- for callers
+ * whose derivative rows need a larger basis than the operator's own (Phi is nested: the first
+ * r functions of a larger basis are the smaller one).                                       */
+int rl_gridop_project(rl_gridop* g, const double* X, int nvec, int rank, double* out, void* stream);
+int rl_gridop_poly_coeffs(rl_gridop* g, int q, double* out, int cap, int* rank);
 /* X[v] = K~^-1 B[v]:  x = M b, then  x += M (b - K~ x)  while the reference's rule
  * ||b - K~ x||_2 < tol (iterative.py:36-42,54-58) does not hold, at most max_refine
  * times (the residual is taken through the handle's ordinary product, rl_ski_mvm's

@@ -100,6 +100,27 @@ class GridOp:
         self.lib.call('rl_gridop_form_stats', self._h, int(q), host_ptr(out))
         return tuple(float(v) for v in out)
 
+    def poly_coeffs(self, q):
+        """(rank, C): C = Phi^T T_q Phi (rank x rank, symmetric) when top row q is in the
+        polynomial form for the current parameters, else (0, None) -- include/runlmc_hip.h:
+        rl_gridop_poly_coeffs (runs the pending verification)."""
+        r = ctypes.c_int()
+        buf = np.zeros(48 * 48)
+        self.lib.call('rl_gridop_poly_coeffs', self._h, int(q), host_ptr(buf), buf.size,
+                      ctypes.byref(r))
+        if r.value == 0:
+            return 0, None
+        return r.value, buf[:r.value * r.value].reshape(r.value, r.value).copy()
+
+    def project(self, G, rank):
+        """(k, D, rank) tensor of Phi_rank^T g per output block of the GRID vectors G (k, D*m):
+        rl_gridop_project."""
+        k = G.shape[0]
+        out = torch.empty((k, self.D, int(rank)), dtype=torch.float64, device=self.device)
+        self.lib.call('rl_gridop_project', self._h, dev_ptr(G.contiguous()), k, int(rank),
+                      dev_ptr(out), self.lib.stream_ptr(self.device))
+        return out
+
     def set_form_gate(self, min_elements):
         """Smallest batch (nvec*D*m elements) run in the polynomial form;
         0 = every batch, negative = the library default."""
@@ -254,6 +275,16 @@ class SkiOp:
                               self.lib.cdll.rl_last_error().decode())
         return bool(av.value), float(ld.value), float(cond.value)
 
+    def project(self, X):
+        """(k, D, r) tensor of Phi^T W^T x per output on the orthonormal polynomials of the
+        operator's polynomial form (rl_ski_project); NotImplementedError outside the form."""
+        k = X.shape[0]
+        r = ctypes.c_int()
+        flat = torch.empty((k * self.grid.D * 48,), dtype=torch.float64, device=self.device)
+        self.lib.call('rl_ski_project', self._h, dev_ptr(X.contiguous()), k, dev_ptr(flat),
+                      ctypes.byref(r), self.lib.stream_ptr(self.device))
+        return flat[:k * self.grid.D * r.value].reshape(k, self.grid.D, r.value)
+
     def mvm(self, X, out=None):
         if out is None:
             out = torch.empty_like(X)
@@ -322,16 +353,42 @@ def solve_direct(ski, B, tol=1e-4, max_refine=4):
     iters = np.zeros(k, dtype=np.int32)
     istop = np.zeros(k, dtype=np.int32)
     resid = np.zeros(k, dtype=np.float64)
+    if k == 0:
+        return X, iters, resid, istop
     ski.lib.call('rl_solve_direct', ski.handle, dev_ptr(B), dev_ptr(X), k, float(tol),
                  int(max_refine), host_ptr(iters), host_ptr(resid), host_ptr(istop),
                  ski.lib.stream_ptr(ski.device))
     return X, iters, resid, istop
 
 
-def slq_quadratic_forms(lanczos, iters, sqnorms):
+def slq_quadratic_forms(lanczos, iters, sqnorms, lib=None):
     """r^T log(K) r for each system from its Lanczos tridiagonal (Gauss
     quadrature): ||r||^2 * sum_j tau_j^2 log(theta_j), (theta, first
-    eigenvector components tau) the eigenpairs of T_k.  Host, O(k^2) each."""
+    eigenvector components tau) the eigenpairs of T_k.  The library's host helper
+    (rl_slq_log_quadrature: implicit QL carrying one eigenvector row, O(k^2) per system, the
+    systems over the host's cores) -- LAPACK through SciPy returns whole eigenvector matrices:
+    16 ms per system at the 420 steps of a C5 solve, 2 s for its 128 probes."""
+    import os
+    lib = lib or _lib.get_library()
+    lanczos = np.ascontiguousarray(lanczos, dtype=np.float64)
+    k = lanczos.shape[0]
+    out = np.zeros(k)
+    if k == 0:
+        return out
+    its = np.ascontiguousarray(np.asarray(iters), dtype=np.int32)
+    sq = np.ascontiguousarray(np.asarray(sqnorms), dtype=np.float64)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    lib.call('rl_slq_log_quadrature', host_ptr(lanczos), int(k), int(lanczos.shape[1]),
+             host_ptr(its), host_ptr(sq), host_ptr(out), int(max(1, min(cores, 32))))
+    return out
+
+
+def slq_quadratic_forms_scipy(lanczos, iters, sqnorms):
+    """The same through SciPy's eigh_tridiagonal (whole eigenvector matrices): the check of
+    the library's helper in the tests."""
     from scipy.linalg import eigh_tridiagonal
     out = np.zeros(len(iters))
     for i, k in enumerate(iters):
@@ -343,7 +400,10 @@ def slq_quadratic_forms(lanczos, iters, sqnorms):
         if k == 1:
             theta, tau2 = d[:1], np.ones(1)
         else:
-            theta, vecs = eigh_tridiagonal(d, e)
+            try:
+                theta, vecs = eigh_tridiagonal(d, e)
+            except np.linalg.LinAlgError:
+                theta, vecs = eigh_tridiagonal(d, e, lapack_driver='stev')
             tau2 = vecs[0] ** 2
         keep = theta > 0
         out[i] = sqnorms[i] * np.sum(tau2[keep] * np.log(theta[keep]))

@@ -128,3 +128,33 @@ k_dz_axpy(double* __restrict__ X, const double* __restrict__ T, int n,
     const double* pt = T + (size_t)rhs * n;
     for (int i = lo + threadIdx.x; i < hi; i += 256) px[i] += pt[i];
 }
+
+// ---------------------------------------------------------------------------
+// k_dz_coeffs: out[v][b][j] = nu_j sum_{runs c of output b} part[c][v][j] -- the coefficients
+// Phi^T W^T x of a batch on the NORMALISED basis from k_rp_project's partial sums (ascending run
+// order).   grid (nvec)   block 256
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_dz_coeffs(const double* __restrict__ part, const int* __restrict__ run_ptr, int nvec, int D, int r,
+            const double* __restrict__ nu, double* __restrict__ out) {
+    const int v = blockIdx.x, Dr = D * r;
+    for (int e = threadIdx.x; e < Dr; e += 256) {
+        const int b = e / r, j = e - b * r;
+        const double* src = part + (size_t)v * r + j;
+        double s = 0.0;
+        for (int c = run_ptr[b]; c < run_ptr[b + 1]; ++c) s += src[(size_t)c * nvec * r];
+        out[(size_t)v * Dr + e] = nu[j] * s;
+    }
+}
+
+// out[row][j] = nu_j sum_c part[c][row][j]: the same from k_lr_project's partial sums (grid
+// rows; rl_gridop_project).   grid (ceil(nrows r / 256))   block 256
+__global__ void __launch_bounds__(256)
+k_lr_coeffs(const double* __restrict__ part, int nchunks, int nrows, int r,
+            const double* __restrict__ nu, double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, tot = (size_t)nrows * r;
+    if (e >= tot) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * tot + e];
+    out[e] = nu[e % r] * s;
+}

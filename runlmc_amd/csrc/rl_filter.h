@@ -285,7 +285,17 @@ k_sf_carries2(const double* __restrict__ X, int nrows, int m, int NF, const doub
     double* red = wl + (size_t)NF * HG * 4;                      // emulator only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x, rbase = blockIdx.y * rows_per_wg, g0 = chunk * G;
-    for (int e = tid; e < NF * HG * 4; e += 256) wl[e] = pwp[e];
+    // The weights sit in LDS TRANSPOSED, [NF][p][component][lane]: a lane needs (a, b, c, e) of
+    // its four points t = 2 l + (p & 1) + 128 (p >> 1), and read from the host's [t][4] order --
+    // 32 bytes per lane at a stride of 64 -- lanes l and l + 2 met in the same banks: 58 % of the
+    // kernel's LDS cycles were conflicts (round-5 counters, SQ_LDS_BANK_CONFLICT 3.2e7 of 5.4e7).
+    // Now every read is 64 consecutive doubles.
+    for (int e = tid; e < NF * HG * 4; e += 256) {
+        const int q = e / (HG * 4), rem = e - q * HG * 4;
+        const int t = rem >> 2, c = rem & 3;
+        const int l = (t & 127) >> 1, p = (t & 1) + 2 * (t >> 7);
+        wl[((q * 4 + p) * 4 + c) * 64 + l] = pwp[e];
+    }
     __syncthreads();
     SfPair na[2][RB], nm[2][RB];
     sf_request_rows2<RB>(na, nm, X, nrows, m, rbase + wave * RB, g0, lane);
@@ -317,8 +327,8 @@ k_sf_carries2(const double* __restrict__ X, int nrows, int m, int NF, const doub
             for (int j = 0; j < NV; ++j) acc[j] = 0.0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int t = 2 * lane + (p & 1) + 128 * (p >> 1);
-                const double wa = w[4 * t], wb = w[4 * t + 1], wc = w[4 * t + 2], we = w[4 * t + 3];
+                const double* wp = w + p * 256 + lane;
+                const double wa = wp[0], wb = wp[64], wc = wp[128], we = wp[192];
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
                     acc[r * 4 + 0] = fma(wa, sv[p][r], acc[r * 4 + 0]);

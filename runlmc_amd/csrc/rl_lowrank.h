@@ -402,6 +402,205 @@ k_lr_expand(const double* __restrict__ Zhat, int nrows, int m, const double* __r
 }
 
 // ---------------------------------------------------------------------------
+// Small batches (round 6): k_lr_small_project<R> + k_lr_small_expand<R>, TWO launches.
+// Below the batch gate the three kernels above are three dependent launches of a few
+// workgroups each, and their projection walks a whole row per wave: BASELINE's C2 batch (17
+// vectors, D = 4, m = 5004) took 25 us that way -- the projection alone 17 -- and 18 us on the
+// three transform kernels.  What such a batch needs is its few hundred thousand multiply-adds
+// spread over the WHOLE chip and as few dependent launches as the data flow allows:
+//   k_lr_small_project  grid (D nseg, nvec): workgroup (b, sg, v) projects segment sg of row b
+//                       of vector v (a quarter row, say) -> part[v][b][sg][R]
+//   k_lr_small_expand   grid (D nseg, nvec): workgroup (a, sg, v) sums the vector's partials,
+//                       applies ROW BLOCK a of the coefficient map
+//                         Mf[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
+//                       (host-built per parameter update, forms_setup; the R x D R block is
+//                       re-applied by each of the row's nseg workgroups: 2 304 multiply-adds at
+//                       C2, nothing against a hand-off) and expands its segment of row a.
+// (First built as ONE launch, a workgroup per (row, vector) that projected all D rows itself:
+// 15.6 us whatever the batch -- 720 k multiply-adds through one compute unit's fp64 pipe are
+// 5 us, the expansion 1.3, and the 64-lane sums waited for the slowest wave; stamps in
+// profiles/r06/small_batch_probe.txt.  One launch with an in-kernel hand-off between the
+// projection and the map would save one launch gap and risk a spin-wait; two launches do not.)
+// Same arithmetic as k_lr_project / k_lr_mix / k_lr_expand (point + mirror parity, the monic
+// recurrence), another summation order.  Used only for operators ALREADY verified to be wholly
+// in the polynomial form, D m <= RL_LR_SMALL_MAX elements per vector.
+// Four slots run their recurrences in lockstep (the loop over degrees outermost): one slot at
+// a time is a chain of 24 dependent multiply-adds, 28 cycles a step on this pipe.
+// ---------------------------------------------------------------------------
+#define RL_LR_SMALL_MAX 32768
+#define RL_LR_SMALL_WG 256      // threads of both kernels
+#define RL_LR_SU 4              // slots in lockstep
+#define RL_LR_SMP 32            // map entries a thread requests ahead (D r <= 4 * this: its whole share)
+// segments per row: one pass of a workgroup's 256 threads x 4 lockstep slots each (at most 16)
+static inline int lr_small_nseg(int m) {
+    const int slots = (m + 1) / 2;
+    int nseg = (slots + RL_LR_SMALL_WG * RL_LR_SU - 1) / (RL_LR_SMALL_WG * RL_LR_SU);
+    return nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
+}
+template <int R>
+__global__ void __launch_bounds__(RL_LR_SMALL_WG)
+k_lr_small_project(const double* __restrict__ X, int D, int m, int nseg, const double* __restrict__ beta,
+                   double* __restrict__ part) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);               // [4][R][65]
+    double* wsum = red + (size_t)4 * R * 65;                      // [4][R]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / nseg, sg = blockIdx.x - b * nseg, v = blockIdx.y;
+    const int slots = lr_slots(m), seglen = (slots + nseg - 1) / nseg;
+    const int n0 = sg * seglen, n1 = n0 + seglen < slots ? n0 + seglen : slots;
+    const double* xb = X + ((size_t)v * D + b) * m;
+    double acc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = 0.0;
+    for (int nb = n0 + tid; nb < n1; nb += RL_LR_SMALL_WG * RL_LR_SU) {
+        double s[RL_LR_SU], q[RL_LR_SU], qm[RL_LR_SU], xe[RL_LR_SU], xo[RL_LR_SU];
+#pragma unroll
+        for (int u = 0; u < RL_LR_SU; ++u) {
+            const int n = nb + RL_LR_SMALL_WG * u;
+            const bool live = n < n1;
+            const int nc = live ? n : n1 - 1, mir = m - 1 - nc;
+            const double x0 = live ? xb[nc] : 0.0, x1 = live && mir != nc ? xb[mir] : 0.0;
+            xe[u] = x0 + x1;
+            xo[u] = x0 - x1;
+            s[u] = lr_point(nc, m);
+            q[u] = 1.0;
+            qm[u] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const double nbj = -beta[j];
+#pragma unroll
+            for (int u = 0; u < RL_LR_SU; ++u) {
+                acc[j] = fma(q[u], (j & 1) ? xo[u] : xe[u], acc[j]);
+                const double qn = fma(s[u], q[u], nbj * qm[u]);
+                qm[u] = q[u];
+                q[u] = qn;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) red[((size_t)wave * R + j) * 65 + lane] = acc[j];
+    __syncthreads();
+    // thread (w, j) sums the 64 lanes of wave w, then the four waves meet
+    if (tid < 4 * R) {
+        const double* src = red + (size_t)tid * 65;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+        for (int l = 0; l < 64; l += 4) {
+            s0 += src[l];
+            s1 += src[l + 1];
+            s2 += src[l + 2];
+            s3 += src[l + 3];
+        }
+        wsum[tid] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (tid < R)
+        part[(((size_t)v * D + b) * nseg + sg) * R + tid] =
+            (wsum[tid] + wsum[R + tid]) + (wsum[2 * R + tid] + wsum[3 * R + tid]);
+}
+static inline size_t lr_small_project_lds(int R) { return ((size_t)4 * R * 65 + 4 * R) * sizeof(double); }
+static inline size_t lr_small_expand_lds(int D, int R) { return ((size_t)D * R + 256 + R) * sizeof(double); }
+
+template <int R>
+__global__ void __launch_bounds__(RL_LR_SMALL_WG)
+k_lr_small_expand(const double* __restrict__ part, int D, int m, int nseg, const double* __restrict__ beta,
+                  const double* __restrict__ Mf, double* __restrict__ Y) {
+    RL_SMEM(smem);
+    double* Z = reinterpret_cast<double*>(smem);                  // [D][R]
+    double* P = Z + (size_t)D * R;                                // [256]
+    double* Zh = P + 256;                                         // [R]
+    const int tid = threadIdx.x;
+    const int a = blockIdx.x / nseg, sg = blockIdx.x - a * nseg, v = blockIdx.y;
+    const int DR = D * R;
+    // this thread's share of row block a of the map -- coefficient i = tid / 4, entries pt,
+    // pt + 4, ... -- requested FIRST (it does not depend on the partial sums): the first
+    // RL_LR_SMP entries here, the rest (D r > 4 RL_LR_SMP) in batches below
+    const int i = tid >> 2, pt = tid & 3;
+    const double* mrow = Mf + ((size_t)a * R + (i < R ? i : 0)) * DR;
+    double mreg[RL_LR_SMP];
+#pragma unroll
+    for (int k = 0; k < RL_LR_SMP; ++k) {
+        const int e = pt + 4 * k;
+        mreg[k] = mrow[e < DR ? e : pt];
+    }
+    // the vector's coefficients: segments summed in ascending order
+    for (int e = tid; e < DR; e += RL_LR_SMALL_WG) {
+        const double* src = part + ((size_t)v * DR + e - (e % R)) * nseg + (e % R);
+        double z = 0.0;
+        for (int g = 0; g < nseg; ++g) z += src[(size_t)g * R];
+        Z[e] = z;
+    }
+    __syncthreads();
+    // Zh[i] = sum_e Mf[a][i][e] Z[e]: four partial sums per coefficient (R <= 64, 256 threads)
+    {
+        double sacc = 0.0;
+        if (i < R) {
+#pragma unroll
+            for (int k = 0; k < RL_LR_SMP; ++k) {
+                const int e = pt + 4 * k;
+                if (e < DR) sacc = fma(mreg[k], Z[e], sacc);
+            }
+            for (int e0 = pt + 4 * RL_LR_SMP; e0 < DR; e0 += 4 * RL_LR_SMP) {
+                double mm[RL_LR_SMP];
+#pragma unroll
+                for (int k = 0; k < RL_LR_SMP; ++k) {
+                    const int e = e0 + 4 * k;
+                    mm[k] = mrow[e < DR ? e : pt];
+                }
+#pragma unroll
+                for (int k = 0; k < RL_LR_SMP; ++k) {
+                    const int e = e0 + 4 * k;
+                    if (e < DR) sacc = fma(mm[k], Z[e], sacc);
+                }
+            }
+        }
+        P[tid] = sacc;
+        __syncthreads();
+        if (tid < R) Zh[tid] = (P[4 * tid] + P[4 * tid + 1]) + (P[4 * tid + 2] + P[4 * tid + 3]);
+        __syncthreads();
+    }
+    double zz[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) zz[j] = Zh[j];
+    const int slots = lr_slots(m), seglen = (slots + nseg - 1) / nseg;
+    const int n0 = sg * seglen, n1 = n0 + seglen < slots ? n0 + seglen : slots;
+    double* ya = Y + ((size_t)v * D + a) * m;
+    for (int nb = n0 + tid; nb < n1; nb += RL_LR_SMALL_WG * RL_LR_SU) {
+        double s[RL_LR_SU], q[RL_LR_SU], qm[RL_LR_SU], ev[RL_LR_SU], od[RL_LR_SU];
+#pragma unroll
+        for (int u = 0; u < RL_LR_SU; ++u) {
+            const int n = nb + RL_LR_SMALL_WG * u;
+            s[u] = lr_point(n < n1 ? n : n1 - 1, m);
+            q[u] = 1.0;
+            qm[u] = 0.0;
+            ev[u] = od[u] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const double nbj = -beta[j];
+#pragma unroll
+            for (int u = 0; u < RL_LR_SU; ++u) {
+                if (j & 1) od[u] = fma(zz[j], q[u], od[u]);
+                else ev[u] = fma(zz[j], q[u], ev[u]);
+                const double qn = fma(s[u], q[u], nbj * qm[u]);
+                qm[u] = q[u];
+                q[u] = qn;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RL_LR_SU; ++u) {
+            const int n = nb + RL_LR_SMALL_WG * u;
+            if (n < n1) {
+                const int mir = m - 1 - n;
+                ya[n] = ev[u] + od[u];
+                if (mir != n) ya[mir] = ev[u] - od[u];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row-wise pieces for SMALL systems (rl_solver.h, Minres2Bufs::poly_part): with
 // K_UU = Phi M Phi^T a solver round needs no grid vector at all.  A data row i of
 // output d interpolates the four grid points n_i .. n_i + 3 with weights w_i:

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rl_kernels.h"
@@ -118,6 +119,7 @@ struct RlKnobs {
                                  // operator is not in the row-polynomial form (k_spmv_w_staged_p, k_minres2_bv):
                                  // C5 matern round 3.71 ms against 4.18, mix 3.98 against 4.41
     bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
+    bool no_lr_small = false;    // RUNLMC_NO_LR_SMALL: small batches never take k_lr_small_*
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
                                  // expansion 257 -> 236 us at 129 vectors, 61 -> 42 at 17; projection level at rank
@@ -137,15 +139,16 @@ struct RlKnobs {
 // RUNLMC_WS_CACHE_MB (memory the solver keeps between calls), RUNLMC_TRACE (prints which
 // kernels ran).  Every other one is an A/B or test hook and is read ONLY under
 // RUNLMC_DEBUG=1 -- without it the library runs its defaults whatever the environment says
-// (and says once, on stderr, that it ignored a hook).
+// (and names every hook it ignored on stderr, each once).
 static RlKnobs read_knobs() {
     RlKnobs k;
     const char* dbg = getenv("RUNLMC_DEBUG");
     const bool debug = dbg != nullptr && dbg[0] != '\0' && dbg[0] != '0';
     auto ignored = [](const char* n) {
-        static bool told = false;
-        if (!told) {
-            told = true;
+        // (every ignored variable is named, each once per process)
+        static std::vector<std::string> told;
+        if (std::find(told.begin(), told.end(), std::string(n)) == told.end()) {
+            told.push_back(n);
             fprintf(stderr, "runlmc_hip: %s is a debug switch and is ignored without RUNLMC_DEBUG=1\n", n);
         }
     };
@@ -186,6 +189,7 @@ static RlKnobs read_knobs() {
     k.no_w_poly = flag("RUNLMC_NO_W_POLY");
     k.no_rp = flag("RUNLMC_NO_RP");
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
+    k.no_lr_small = flag("RUNLMC_NO_LR_SMALL");
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
@@ -414,6 +418,11 @@ struct rl_gridop {
     double* lr_C = nullptr;     // dev [max_tops][r][r]
     double* lr_M = nullptr;     // dev [D][24][D][24]: the whole coefficient map (polynomial rounds)
     std::vector<double> lr_hC;  // host copy of lr_C for it
+    double* lr_spart = nullptr; // dev [nvec][D][nseg][r]: partial sums of k_lr_small_project
+    size_t lr_spart_cap = 0;
+    double* lr_Mf = nullptr;    // dev [D][r][D][r]: the coefficient map for k_lr_small_expand (any rank)
+    size_t lr_Mf_cap = 0;
+    bool lr_Mf_ok = false;      // ... built for the current parameters
     std::vector<double> lr_hB;  // host [Q][D][D]: the couplings lr_B holds (direct solves, rl_direct.h)
     std::vector<double> lr_hnu; // host copy of lr_nu
     unsigned long long param_ver = 0;   // bumped by every parameter update (what a factorisation was built for)
@@ -588,6 +597,13 @@ static void set_lds_attrs() {
     RL_SF_ATTR(7); RL_SF_ATTR(8); RL_SF_ATTR(9); RL_SF_ATTR(10); RL_SF_ATTR(11); RL_SF_ATTR(12);
     RL_SF_ATTR(13); RL_SF_ATTR(14); RL_SF_ATTR(15); RL_SF_ATTR(16);
 #undef RL_SF_ATTR
+#define RL_LRS_ATTR(R_)                                                                      \
+    (void)hipFuncSetAttribute((const void*)k_lr_small_project<R_>,                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+    (void)hipFuncSetAttribute((const void*)k_lr_small_expand<R_>,                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    RL_LRS_ATTR(24); RL_LRS_ATTR(32); RL_LRS_ATTR(36); RL_LRS_ATTR(40); RL_LRS_ATTR(48);
+#undef RL_LRS_ATTR
     (void)hipFuncSetAttribute((const void*)k_sf_carries<2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)k_sf_carries<3>,
@@ -851,7 +867,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
-                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_sel, g->lr_Cc, g->lr_Bc,
+                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_sel, g->lr_Cc, g->lr_Bc, g->lr_Mf, g->lr_spart,
                     g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pwp, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
                     g->sf_E, g->sf_Cin, g->sf_next};
     for (void* p : ptrs)
@@ -1022,6 +1038,7 @@ static int set_commit(rl_gridop* g, int Q, const double* tops, const std::vector
     if ((int)W.size() > g->max_fac)
         return fail(RL_ELIMIT, "rl_gridop_set: total rank exceeds max_tops*D");
     g->lr_ok = false;
+    g->lr_Mf_ok = false;
     g->lr_dirty = false;
     ++g->param_ver;
     int rc = set_common(g, Q, tops);
@@ -2133,6 +2150,17 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
             st = st * 6364136223846793005ull + 1442695040888963407ull;
             xr[i] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
         }
+        // every output row of the trial vector has unit 2-norm: the power iteration of (iv)
+        // starts from it, and its step-0 entries ||E v_0||, ||T w_0|| are then Rayleigh-type
+        // lower estimates like the later ones (unnormalised they carried a factor ~sqrt(m / 3)
+        // into the recorded ||T||_2 and loosened the test by it; the sampled tests (i), (ii)
+        // are relative to the result's largest entry and do not see the scale)
+        for (int a = 0; a < D; ++a) {
+            long double ss = 0.0L;
+            for (int i = 0; i < m; ++i) ss += (long double)xr[(size_t)a * m + i] * xr[(size_t)a * m + i];
+            const double inv = ss > 0.0L ? (double)(1.0L / sqrtl(ss)) : 1.0;
+            for (int i = 0; i < m; ++i) xr[(size_t)a * m + i] *= inv;
+        }
         RL_HIP(hipMemcpy(g->lr_scr, xr.data(), vec * sizeof(double), hipMemcpyHostToDevice));
     }
     double* xr = g->lr_scr;
@@ -2168,6 +2196,10 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
         g->lr_r = r;
         const int nvr = (r + RL_LR_EXTRA + D - 1) / D, nrows = nvr * D;
         RL_TRY(lr_reserve(g, std::max(nvr, 1)));
+        // (the grouped power iteration multiplies the C of tops that are no candidates by a zero
+        // coupling: they have to be finite -- a slot may hold what an earlier parameter set, or
+        // another rank's layout, left there)
+        RL_HIP(hipMemsetAsync(g->lr_C, 0, (size_t)g->max_tops * RL_LR_RMAX * RL_LR_RMAX * sizeof(double), st));
         for (int q = 0; q < Q; ++q) {
             if (!want[q]) continue;
             MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones,
@@ -2444,6 +2476,32 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
             RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
             g->lr_hB = B;
             g->lr_ok = true;
+            g->lr_Mf_ok = false;
+            if ((size_t)D * m <= RL_LR_SMALL_MAX && !g->kn.no_lr_small && (int)g->lr_hnu.size() >= r) {
+                // the whole coefficient map of the small-batch product (k_lr_small_expand)
+                //   Mf[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
+                const size_t Dr = (size_t)D * r;
+                std::vector<double> Mf(Dr * Dr, 0.0);
+                for (int q = 0; q < Q; ++q)
+                    for (int a = 0; a < D; ++a)
+                        for (int b = 0; b < D; ++b) {
+                            const double bq = B[((size_t)q * D + a) * D + b];
+                            if (bq == 0.0) continue;
+                            for (int i = 0; i < r; ++i)
+                                for (int j = 0; j < r; ++j)
+                                    Mf[((size_t)a * r + i) * Dr + (size_t)b * r + j] +=
+                                        bq * g->lr_hnu[i] * g->lr_hnu[j] * g->lr_hC[((size_t)q * r + i) * r + j];
+                        }
+                if (g->lr_Mf_cap < Mf.size()) {
+                    if (g->lr_Mf) RL_HIP(hipFree(g->lr_Mf));
+                    g->lr_Mf = nullptr;
+                    g->lr_Mf_cap = 0;
+                    RL_HIP(hipMalloc((void**)&g->lr_Mf, Mf.size() * sizeof(double)));
+                    g->lr_Mf_cap = Mf.size();
+                }
+                RL_HIP(hipMemcpy(g->lr_Mf, Mf.data(), Mf.size() * sizeof(double), hipMemcpyHostToDevice));
+                g->lr_Mf_ok = true;
+            }
             if (r == RL_LR_RS && !g->kn.no_poly_round) {
                 // the whole coefficient map of the solver's polynomial rounds
                 //   M[a][i][b][j] = nu_i nu_j sum_q B_q[a][b] C_q[i][j]
@@ -2638,6 +2696,46 @@ static int mvm_with_mix(rl_gridop* g, const MixParams& mp, const double* X, doub
             trace_once("grid product: recursive-filter part + polynomial part");
             RL_TRY(sf_apply_all(g, X, Y, nvec, stream));
             if (g->lr_np > 0) RL_TRY(lr_apply_compact(g, X, Y, nvec, stream));
+            return RL_OK;
+        }
+    }
+    // A small batch (below the gate) of an operator that IS wholly in the polynomial form: two
+    // launches spread over the chip (k_lr_small_project / k_lr_small_expand, rl_lowrank.h).  The pending verification of
+    // the form runs for such a batch too when the grid could take this path (outside captures;
+    // back-off after rejections as for big batches); a handle whose gate was moved
+    // (rl_gridop_set_form_gate) keeps to what the caller asked for.
+    const bool small_try = !big && g->lr_try && !g->lr_bypass && !g->kn.no_lr_small &&
+                           (size_t)g->D * g->m <= RL_LR_SMALL_MAX && g->lr_min == lr_min_elements(g) &&
+                           !(mp.nfac == 0 && mp.Q == 1 && mp.kappa == g->ones);
+    if (small_try && g->lr_dirty && !stream_capturing(stream)) RL_TRY(lr_ensure(g));
+    if (small_try && !g->lr_dirty && g->lr_ok && g->lr_Mf_ok && nvec <= 65535) {
+        const int nseg = lr_small_nseg(g->m);
+        const size_t need = (size_t)nvec * g->D * nseg * RL_LR_RMAX;
+        if (g->lr_spart_cap < need && !stream_capturing(stream)) {
+            if (g->lr_spart) RL_HIP(hipFree(g->lr_spart));
+            g->lr_spart = nullptr;
+            g->lr_spart_cap = 0;
+            RL_HIP(hipMalloc((void**)&g->lr_spart, need * sizeof(double)));
+            g->lr_spart_cap = need;
+        }
+        if (g->lr_spart_cap >= need) {
+            trace_once("grid product: polynomial-subspace form, small batch (k_lr_small_project / k_lr_small_expand)");
+            const dim3 grid(g->D * nseg, nvec), blk(RL_LR_SMALL_WG);
+#define RL_LR_SMALL(R_)                                                                           \
+            RL_LAUNCH(k_lr_small_project<R_>, grid, blk, lr_small_project_lds(R_), stream, X, g->D, g->m, nseg, \
+                      (const double*)g->lr_beta, g->lr_spart);                                     \
+            RL_LAUNCH(k_lr_small_expand<R_>, grid, blk, lr_small_expand_lds(g->D, R_), stream,     \
+                      (const double*)g->lr_spart, g->D, g->m, nseg, (const double*)g->lr_beta,     \
+                      (const double*)g->lr_Mf, Y)
+            switch (g->lr_r) {
+                case 24: RL_LR_SMALL(24); break;
+                case 32: RL_LR_SMALL(32); break;
+                case 36: RL_LR_SMALL(36); break;
+                case 40: RL_LR_SMALL(40); break;
+                default: RL_LR_SMALL(48); break;
+            }
+#undef RL_LR_SMALL
+            RL_HIP(hipGetLastError());
             return RL_OK;
         }
     }
@@ -3998,7 +4096,7 @@ static int minres2_round(rl_ski* s, const Minres2Bufs& mb, int nrhs, int n, int 
             s->rp_pfuse = RpPFuse{mb.pc, mb.tri[par], mb.w[par], mb.w[1 - par], mb.x,
                                   mb.partA[1 - par], mb.partC};
             const Minres2Bufs mbc = mb;
-            s->rp_mid = [mbc, par, red](hipStream_t q) {
+            s->rp_mid = [mbc, par](hipStream_t q) {
                 RL_LAUNCH(k_minres2_ph, dim3(mbc.fuse_p), dim3(RL_SOLVER_THREADS), red, q, mbc, par);
             };
         }
@@ -4262,7 +4360,13 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
             mb.nrmB = s->rp_nrm + nrhs;
             mb.nrm_n = s->rp_nruns;
             trace_once("minres round: B inside the row-polynomial projection (k_minres2_bh)");
-            if (s->kn.rp_pfuse) {
+            // (the fused expansion keeps 8 doubles of LDS per system: past 1024 systems -- 64 KB --
+            // the launch would fail, so such batches keep P as its own kernel)
+            size_t pfuse_lds = (size_t)nrhs * 8 * sizeof(double);
+#if defined(RL_EMU)
+            pfuse_lds += 256 * sizeof(double);
+#endif
+            if (s->kn.rp_pfuse && pfuse_lds <= (size_t)64 * 1024) {
                 // ... and P inside the expansion (k_minres2_ph + k_rp_expand<.., true>)
                 const int np = (n + 255) / 256;
                 const size_t needp = (size_t)nrhs * (RL_RP_PCW + 3 * (size_t)np);
@@ -4506,6 +4610,41 @@ static int solve_batch_impl(rl_ski* s, const double* B, double* X, int nrhs, int
 // ---------------------------------------------------------------------------
 #define RL_DZ_NBLK 120          // partial sums per system of the residual norms
 
+// sum_k a[k] b[k] with four running sums (the compiler keeps them in two vector registers:
+// a plain reduction loop is not vectorised without -ffast-math)
+static inline double dz_dot(const double* a, const double* b, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+        s0 += a[k] * b[k];
+        s1 += a[k + 1] * b[k + 1];
+        s2 += a[k + 2] * b[k + 2];
+        s3 += a[k + 3] * b[k + 3];
+    }
+    for (; k < n; ++k) s0 += a[k] * b[k];
+    return (s0 + s1) + (s2 + s3);
+}
+// host threads for the independent parts of the factorisation (a few hundred columns each)
+static int dz_threads() {
+    static int n = 0;
+    if (n == 0) {
+        unsigned hc = std::thread::hardware_concurrency();
+        n = (int)std::max(1u, std::min(hc ? hc : 1u, 8u));
+    }
+    return n;
+}
+template <class F>
+static void dz_parallel(int count, int min_per_thread, F body) {
+    const int nt = std::max(1, std::min(dz_threads(), count / std::max(1, min_per_thread)));
+    if (nt <= 1) {
+        body(0, 1);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(body, t, nt);
+    body(0, nt);
+    for (std::thread& th : pool) th.join();
+}
 // in-place Cholesky factor (lower, row-major n x n; the strict upper part is left alone);
 // false when a pivot is not positive
 static bool dz_chol(std::vector<double>& a, int n) {
@@ -4513,8 +4652,7 @@ static bool dz_chol(std::vector<double>& a, int n) {
         double* ai = a.data() + (size_t)i * n;
         for (int j = 0; j <= i; ++j) {
             const double* aj = a.data() + (size_t)j * n;
-            double s = ai[j];
-            for (int k = 0; k < j; ++k) s -= ai[k] * aj[k];
+            const double s = ai[j] - dz_dot(ai, aj, j);
             if (j < i) {
                 ai[j] = s / aj[j];
             } else {
@@ -4525,22 +4663,28 @@ static bool dz_chol(std::vector<double>& a, int n) {
     }
     return true;
 }
-// x = L^-1 (lower, row-major; x's strict upper part zero)
-static void dz_tri_inverse(const std::vector<double>& L, int n, std::vector<double>& x) {
-    x.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) {
-        double* xi = x.data() + (size_t)i * n;
-        const double* li = L.data() + (size_t)i * n;
-        xi[i] = 1.0;
-        for (int k = 0; k < i; ++k) {
-            const double lik = li[k];
-            if (lik == 0.0) continue;
-            const double* xk = x.data() + (size_t)k * n;
-            for (int j = 0; j <= k; ++j) xi[j] -= lik * xk[j];
+// xt = (L^-1)^T, i.e. xt[c][i] = (L^-1)[i][c] (L lower, row-major; row c of xt is the solution
+// of L x = e_c, zero before position c): the n columns are independent -- spread over threads
+static void dz_tri_inverse_t(const std::vector<double>& L, int n, std::vector<double>& xt) {
+    xt.assign((size_t)n * n, 0.0);
+    dz_parallel(n, 32, [&](int first, int step) {
+        for (int c = first; c < n; c += step) {
+            double* x = xt.data() + (size_t)c * n;
+            x[c] = 1.0 / L[(size_t)c * n + c];
+            for (int i = c + 1; i < n; ++i) {
+                const double* li = L.data() + (size_t)i * n;
+                x[i] = -dz_dot(li + c, x + c, i - c) / li[i];
+            }
         }
-        const double inv = 1.0 / li[i];
-        for (int j = 0; j <= i; ++j) xi[j] *= inv;
-    }
+    });
+}
+// x = L^-1 (lower, row-major; x's strict upper part zero) -- the small per-output factors
+static void dz_tri_inverse(const std::vector<double>& L, int n, std::vector<double>& x) {
+    std::vector<double> xt;
+    dz_tri_inverse_t(L, n, xt);
+    x.assign((size_t)n * n, 0.0);
+    for (int c = 0; c < n; ++c)
+        for (int i = c; i < n; ++i) x[(size_t)i * n + c] = xt[(size_t)c * n + i];
 }
 
 template <int R>
@@ -4676,8 +4820,10 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
         dz_tri_inverse(L[d], R, Li[d]);
     }
     // S = I + L^T M L, M_ab = sum_q B_q[a][b] C_q  (C symmetrised)
-    std::vector<double> S((size_t)Dr * Dr, 0.0), Mab((size_t)R * R), T1((size_t)R * R);
-    for (int a = 0; a < D; ++a)
+    std::vector<double> S((size_t)Dr * Dr, 0.0);
+    dz_parallel(D, 1, [&](int first, int step) {
+      std::vector<double> Mab((size_t)R * R), T1((size_t)R * R);
+      for (int a = first; a < D; a += step)
         for (int b = 0; b <= a; ++b) {
             std::fill(Mab.begin(), Mab.end(), 0.0);
             bool any = false;
@@ -4707,6 +4853,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
                     S[((size_t)b * R + j) * Dr + (size_t)a * R + i] = acc;
                 }
         }
+    });
     for (int i = 0; i < Dr; ++i)
         for (int j = 0; j < i; ++j) {
             const double v = 0.5 * (S[(size_t)i * Dr + j] + S[(size_t)j * Dr + i]);
@@ -4723,26 +4870,28 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
         pmax = std::max(pmax, p);
     }
     for (int d = 0; d < D; ++d) logdet += rows[d] * std::log(eps[d]);
-    // Y = I - S^-1 = I - X^T X, X = chol(S)^-1
-    std::vector<double> X;
-    dz_tri_inverse(S, Dr, X);
+    // Y = I - S^-1 = I - X^T X, X = chol(S)^-1: with Xt = X^T stored by rows (row c = column c
+    // of X, zero before position c), S^-1[i][j] = Xt[i] . Xt[j] over positions >= max(i, j)
+    std::vector<double> Xt;
+    dz_tri_inverse_t(S, Dr, Xt);
     std::vector<double> Y((size_t)Dr * Dr, 0.0);
-    for (int k = 0; k < Dr; ++k) {
-        const double* xk = X.data() + (size_t)k * Dr;
-        for (int i = 0; i <= k; ++i) {
-            const double xi = xk[i];
-            if (xi == 0.0) continue;
-            double* yi = Y.data() + (size_t)i * Dr;
-            for (int j = 0; j <= i; ++j) yi[j] -= xi * xk[j];
+    dz_parallel(Dr, 32, [&](int first, int step) {
+        for (int i = first; i < Dr; i += step) {
+            const double* xi = Xt.data() + (size_t)i * Dr;
+            for (int j = 0; j <= i; ++j) {
+                const double* xj = Xt.data() + (size_t)j * Dr;
+                const double v = (i == j ? 1.0 : 0.0) - dz_dot(xi + i, xj + i, Dr - i);
+                Y[(size_t)i * Dr + j] = v;
+            }
         }
-    }
-    for (int i = 0; i < Dr; ++i) {
-        Y[(size_t)i * Dr + i] += 1.0;
+    });
+    for (int i = 0; i < Dr; ++i)
         for (int j = 0; j < i; ++j) Y[(size_t)j * Dr + i] = Y[(size_t)i * Dr + j];
-    }
     // Z_ab = Li_a^T Y_ab Li_b, scaled:  Zs = -(nu_i / eps_a) Z (nu_j / eps_b)
     std::vector<double> Zs((size_t)Dr * Dr, 0.0);
-    for (int a = 0; a < D; ++a)
+    dz_parallel(D, 1, [&](int first, int step) {
+      std::vector<double> T1((size_t)R * R);
+      for (int a = first; a < D; a += step)
         for (int b = 0; b <= a; ++b) {
             // T1 = Y_ab Li_b  (Li_b lower)
             for (int i = 0; i < R; ++i)
@@ -4761,6 +4910,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
                     Zs[((size_t)b * R + j) * Dr + (size_t)a * R + i] = v;
                 }
         }
+    });
     for (double v : Zs)
         if (!std::isfinite(v)) { *why = "the solve map is not finite"; return RL_OK; }
     if (s->dz_Zt_cap < Zs.size()) {
@@ -4811,6 +4961,86 @@ extern "C" int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* 
     if (logdet) *logdet = ok ? s->dz_logdet : 0.0;
     if (cond) *cond = ok ? s->dz_cond : 0.0;
     if (!ok) g_err = std::string("direct solve not available: ") + why;
+    return RL_OK;
+}
+
+extern "C" int rl_ski_project(rl_ski* s, const double* X, int nvec, double* out, int* rank,
+                              void* stream) {
+    if (!s || !X || !out) return fail(RL_EINVAL, "rl_ski_project: NULL argument");
+    if (nvec < 0) return fail(RL_EINVAL, "rl_ski_project: nvec < 0");
+    rl_gridop* g = s->g;
+    bool ok = false;
+    const char* why = "";
+    RL_TRY(dz_ensure(s, &ok, &why));
+    if (!ok) return fail(RL_ELIMIT, std::string("rl_ski_project: not available for this operator: ") + why);
+    if (rank) *rank = g->lr_r;
+    if (nvec == 0) return RL_OK;
+    RL_HIP(hipSetDevice(g->device));
+    hipStream_t st = (hipStream_t)stream;
+    RL_TRY(rp_prepare(s, std::max(nvec, g->lr_r)));
+    const double* Xi = X;
+    if (s->permuted) {
+        RL_TRY(ski_reserve_perm(s, nvec));
+        permute_rows(s, X, s->P1, nvec, 0, st);
+        Xi = s->P1;
+    }
+#define RL_DZ_PROJ(R_) rp_project_plain<R_>(s, Xi, nvec, st)
+    RL_DZ_RANKS(RL_DZ_PROJ);
+#undef RL_DZ_PROJ
+    RL_LAUNCH(k_dz_coeffs, dim3(nvec), dim3(256), 0, st, (const double*)s->rp_part,
+              (const int*)s->rp_run_ptr, nvec, g->D, g->lr_r, (const double*)g->lr_nu, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_project(rl_gridop* g, const double* X, int nvec, int rank, double* out,
+                                 void* stream) {
+    if (!g || !X || !out) return fail(RL_EINVAL, "rl_gridop_project: NULL argument");
+    if (nvec < 0) return fail(RL_EINVAL, "rl_gridop_project: nvec < 0");
+    if (g->wide || !g->lr_try) return fail(RL_ELIMIT, "rl_gridop_project: this grid has no polynomial basis (1-D grids of >= 96 points, D <= 16)");
+    if (rank != 24 && rank != 32 && rank != 36 && rank != 40 && rank != 48)
+        return fail(RL_EINVAL, "rl_gridop_project: rank must be one of 24, 32, 36, 40, 48");
+    if (nvec == 0) return RL_OK;
+    RL_HIP(hipSetDevice(g->device));
+    // (the basis comes with a handle's first verification of the polynomial form)
+    if (g->Q >= 1) RL_TRY(lr_ensure(g));
+    if (!g->lr_beta || !g->lr_nu)
+        return fail(RL_ELIMIT, "rl_gridop_project: no verification of the polynomial form has run on this handle yet");
+    hipStream_t st = (hipStream_t)stream;
+    RL_TRY(lr_reserve(g, nvec));
+    const int nrows = nvec * g->D;
+    int chunks = 0;
+    switch (rank) {
+        case 24: chunks = lr_project<24>(g, X, nrows, st); break;
+        case 32: chunks = lr_project<32>(g, X, nrows, st); break;
+        case 36: chunks = lr_project<36>(g, X, nrows, st); break;
+        case 40: chunks = lr_project<40>(g, X, nrows, st); break;
+        default: chunks = lr_project<48>(g, X, nrows, st); break;
+    }
+    RL_LAUNCH(k_lr_coeffs, dim3(((size_t)nrows * rank + 255) / 256), dim3(256), 0, st,
+              (const double*)g->lr_part, chunks, nrows, rank, (const double*)g->lr_nu, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_poly_coeffs(rl_gridop* g, int q, double* out, int cap, int* rank) {
+    if (!g || !rank) return fail(RL_EINVAL, "rl_gridop_poly_coeffs: NULL argument");
+    if (q < 0 || q >= g->Q) return fail(RL_EINVAL, "rl_gridop_poly_coeffs: q out of range");
+    *rank = 0;
+    if (g->wide || !g->lr_try) return RL_OK;
+    RL_HIP(hipSetDevice(g->device));
+    RL_TRY(lr_ensure(g));
+    if (q >= (int)g->top_form.size() || g->top_form[q] != 1) return RL_OK;
+    const int r = g->lr_r;
+    if ((int)g->lr_hC.size() < (q + 1) * r * r) return RL_OK;
+    if (out != nullptr) {
+        if (cap < r * r) return fail(RL_EINVAL, "rl_gridop_poly_coeffs: out holds fewer than rank^2 values");
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j)
+                out[(size_t)i * r + j] = 0.5 * (g->lr_hC[((size_t)q * r + i) * r + j] +
+                                                g->lr_hC[((size_t)q * r + j) * r + i]);
+    }
+    *rank = r;
     return RL_OK;
 }
 
@@ -4907,6 +5137,105 @@ extern "C" int rl_solve_direct(rl_ski* s, const double* B, double* X, int nrhs, 
         if (resid_out) resid_out[v] = res[v];
         if (istop_out) istop_out[v] = stop[v];
     }
+    return RL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Stochastic Lanczos quadrature on the host: r^T log(K~) r from a system's Lanczos tridiagonal
+// ---------------------------------------------------------------------------
+// Eigenvalues of the symmetric tridiagonal (diagonal d[0..n), off-diagonals e[0..n-1)) into d
+// and the FIRST components of its normalised eigenvectors into z -- all a Gauss quadrature
+// needs (Golub & Welsch): the implicit QL iteration with Wilkinson shifts, its plane rotations
+// applied to one row of the eigenvector matrix instead of all n (O(n^2) in all; LAPACK's
+// drivers return the whole matrix, O(n^3) or an MRRR pass that gives up on the strongly
+// graded tridiagonals of a converged Lanczos run).  false: an eigenvalue did not settle.
+static bool slq_ql_first_row(std::vector<double>& d, std::vector<double>& e, std::vector<double>& z) {
+    const int n = (int)d.size();
+    e.resize(n);
+    e[n - 1] = 0.0;
+    z.assign(n, 0.0);
+    z[0] = 1.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m = l;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= eps * dd) break;
+            }
+            if (m == l) break;
+            if (iter++ == 80) return false;
+            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+            double r = std::hypot(g, 1.0);
+            g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
+            double s = 1.0, c = 1.0, p = 0.0;
+            int i = m - 1;
+            for (; i >= l; --i) {
+                double f = s * e[i];
+                const double b = c * e[i];
+                r = std::hypot(f, g);
+                e[i + 1] = r;
+                if (r == 0.0) {
+                    d[i + 1] -= p;
+                    e[m] = 0.0;
+                    break;
+                }
+                s = f / r;
+                c = g / r;
+                g = d[i + 1] - p;
+                r = (d[i] - g) * s + 2.0 * c * b;
+                p = s * r;
+                d[i + 1] = g + p;
+                g = c * r - b;
+                f = z[i + 1];
+                z[i + 1] = s * z[i] + c * f;
+                z[i] = c * z[i] - s * f;
+            }
+            if (r == 0.0 && i >= l) continue;
+            d[l] -= p;
+            e[l] = g;
+            e[m] = 0.0;
+        } while (m != l);
+    }
+    return true;
+}
+
+extern "C" int rl_slq_log_quadrature(const double* lanczos, int nrhs, int cap, const int* iters,
+                                     const double* sqnorms, double* out, int nthreads) {
+    if (!lanczos || !iters || !sqnorms || !out) return fail(RL_EINVAL, "rl_slq_log_quadrature: NULL argument");
+    if (nrhs < 0 || cap < 1) return fail(RL_EINVAL, "rl_slq_log_quadrature: bad sizes");
+    std::vector<int> bad((size_t)std::max(nrhs, 1), 0);
+    auto work = [&](int first, int step) {
+        std::vector<double> d, e, z;
+        for (int v = first; v < nrhs; v += step) {
+            const int k = std::min(iters[v], cap);
+            out[v] = 0.0;
+            if (k < 1) continue;
+            const double* lz = lanczos + (size_t)v * cap * 2;
+            d.resize(k);
+            e.assign(k, 0.0);
+            for (int j = 0; j < k; ++j) d[j] = lz[2 * j];
+            for (int j = 0; j + 1 < k; ++j) e[j] = lz[2 * j + 1];
+            if (!slq_ql_first_row(d, e, z)) {
+                bad[v] = 1;
+                continue;
+            }
+            double acc = 0.0;
+            for (int j = 0; j < k; ++j)
+                if (d[j] > 0.0) acc += z[j] * z[j] * std::log(d[j]);
+            out[v] = sqnorms[v] * acc;
+        }
+    };
+    const int nt = std::max(1, std::min(nthreads, nrhs));
+    if (nt == 1) {
+        work(0, 1);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work, t, nt);
+        for (std::thread& th : pool) th.join();
+    }
+    for (int v = 0; v < nrhs; ++v)
+        if (bad[v]) return fail(RL_EHIP, "rl_slq_log_quadrature: an eigenvalue of a Lanczos tridiagonal did not converge");
     return RL_OK;
 }
 

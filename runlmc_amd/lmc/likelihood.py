@@ -103,6 +103,59 @@ class ApproxLMCLikelihood(LMCLikelihood):
         return -0.5 * (self.log_det_K() + self.normal_quadratic() +
                        n * np.log(2 * np.pi))
 
+    # -- Gram terms in the coefficient space of a polynomial-form operator ----------
+    # (False: always the streaming products below)
+    COEFFICIENT_GRAMS = True
+
+    def _coefficient_grams(self, skiop, term, grid, qs, U, V):
+        """P[t, v, a, b] = u~_a . T_t v~_b for the term's top rows k_q and dk_q/dtheta WITHOUT a
+        grid vector, when the operator is wholly in the polynomial form (round 6): every such
+        T is Phi C_T Phi^T to the accepted 2e-13, so with c_u = Phi^T W^T u (D x r per vector:
+        rl_ski_project, one pass over the batch)  u~_a . T v~_b = c_u[a]^T C_T c_v[b]  -- two
+        projections and a tiny contraction instead of two interpolation products, one batched
+        Toeplitz product and one Gram pass per top row.  The C of k_q come from the operator's
+        own handle; the derivative rows are verified in a handle of their own (same grid, same
+        basis: a smaller rank is the leading block).  None when anything is outside the form:
+        the caller then runs the streaming products."""
+        if term != 0 or len(skiop.grids) != 1 or grid.sizes is not None and len(grid.sizes) > 1:
+            return None
+        try:
+            if not skiop.factor()[0]:
+                return None
+        except NotImplementedError:
+            return None
+        R = grid.form()[0]
+        if R <= 0 or grid.Q < len(qs):
+            return None
+        Cs = []
+        for i in range(len(qs)):
+            r, C = grid.poly_coeffs(i)
+            if r != R:
+                return None
+            Cs.append(C)
+        dt = [as_f64(np.ravel(g)) for q in qs for g in self.materialized_grads[q]]
+        Rall = R
+        if dt:
+            D = grid.D
+            gop = _grad_operator(D, grid.m, len(dt), grid.device_index, sizes=grid.sizes)
+            gop.set_lmc(np.stack(dt), [None] * len(dt), [np.zeros(D)] * len(dt))
+            for t in range(len(dt)):
+                r, C = gop.poly_coeffs(t)
+                if r == 0:
+                    return None
+                Rall = max(Rall, r)
+                Cs.append(C)
+        Cs = [np.pad(C, ((0, Rall - C.shape[0]),) * 2) for C in Cs]
+        if Rall == R:
+            cU, cV = skiop.project(U), skiop.project(V)
+        else:
+            # the derivative rows need a larger basis than the operator's own: interpolate to
+            # the grid and project there on the first Rall polynomials (the basis is nested)
+            cU = grid.project(skiop.apply_wt(U, term), Rall)
+            cV = grid.project(skiop.apply_wt(V, term), Rall)
+        Ct = torch.from_numpy(np.stack(Cs)).to(skiop.device)
+        return torch.einsum('vai,tij,vbj->tvab', cU, Ct, cV).contiguous()
+
     # -- the batched partial sums ------------------------------------------------
     def _partials(self):
         if self._parts is not None:
@@ -145,6 +198,11 @@ class ApproxLMCLikelihood(LMCLikelihood):
                     tops_t.append(as_f64(np.ravel(g)))
                     own_t.append((q, p_))
             nt = len(tops_t)
+            Pc = self._coefficient_grams(skiop, term, grid, qs, U, V) if self.COEFFICIENT_GRAMS else None
+            if Pc is not None:
+                owner += own_t
+                blocks.append(Pc)
+                continue
             gop = _grad_operator(D, grid.m, nt, grid.device_index, sizes=grid.sizes)
             gop.set_lmc(np.stack(tops_t), [None] * nt, [np.zeros(D)] * nt)
             Ut = skiop.apply_wt(U, term)

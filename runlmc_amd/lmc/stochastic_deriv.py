@@ -14,9 +14,20 @@ from ..approx.iterative import Iterative
 from ..util.dist import rank_world, shard_rows, all_reduce_sum_, broadcast_
 
 
+def _host_cores():
+    import os
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
 class StochasticDerivService:
-    # Lanczos steps kept per system for the log-determinant quadrature
-    LANCZOS_CAP = 256
+    # Lanczos steps kept per system for the log-determinant quadrature.  None: as many as a
+    # solve may run (maxiter, else n), at most LANCZOS_MAX -- until round 5 a fixed 256 cut the
+    # quadrature below the 400-500 iterations a C5 solve runs.  (16 bytes per step and system.)
+    LANCZOS_CAP = None
+    LANCZOS_MAX = 4096
 
     def __init__(self, metrics, pool, n_it, tol, group=None, scipy_exits=None, maxiter=0,
                  precondition=None):
@@ -38,14 +49,28 @@ class StochasticDerivService:
         matrix (seed the RNG identically) and keeps its own rows."""
         return np.random.randint(0, 2, (self._n_it, n)) * 2 - 1
 
+    def draw_probes_device(self, n, device, seed=None):
+        """+-1 probes drawn ON the device (int8, n_it x n; torch's generator, not NumPy's
+        stream: the same estimator, another draw).  Every rank must pass the same seed."""
+        gen = torch.Generator(device=device)
+        if seed is not None:
+            gen.manual_seed(int(seed))
+        bits = torch.randint(0, 2, (self._n_it, n), dtype=torch.int8, device=device, generator=gen)
+        return bits * 2 - 1
+
     def generate(self, K, y, rs=None):
         """Solve K alpha = y and K s_i = r_i for this rank's probes.  `rs`
         (n_it x n, entries +-1) may be passed explicitly (parity tests)."""
         n = K.shape[0]
         if rs is None:
             rs = self.draw_probes(n)
-        rs = np.asarray(rs)
-        if rs.shape != (self._n_it, n):
+        # (a torch tensor on the operator's device is taken as it is -- +-1 entries of any
+        # dtype, e.g. drawn there with draw_probes_device: no host pass over N x n entries,
+        # which at C5 costs ten times what the solves through the factorisation do)
+        on_device = isinstance(rs, torch.Tensor)
+        if not on_device:
+            rs = np.asarray(rs)
+        if tuple(rs.shape) != (self._n_it, n):
             raise ValueError('probes must have shape {}'.format((self._n_it, n)))
         mine = shard_rows(self._n_it, self._group)
         dev = K.device
@@ -76,16 +101,28 @@ class StochasticDerivService:
             yat = 0
         Bfull = torch.zeros((nrow, n), dtype=torch.float64, device=dev)
         Bfull[yat] = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64)).to(dev)
-        if nm:
+        if nm and on_device:
+            Bfull[first:first + nm] = mine_rows.to(device=dev, dtype=torch.float64)
+        elif nm:
             # (signed integer kinds only: the values are checked BEFORE they are narrowed --
             # 255 or 257 would wrap to -1 / +1 in one byte and pass a check made afterwards)
             small = mine_rows.dtype.kind == 'i'
+            # (the two host passes over N x n entries run on all the host's cores whatever
+            # OMP_NUM_THREADS says -- the reference asks for 1, for NumPy's sake, and torch
+            # would then walk the 1 GB of C5's probes on one core: 110 ms of a 160 ms step)
+            threads = torch.get_num_threads()
+            try:
+                torch.set_num_threads(max(threads, min(_host_cores(), 32)))
+                if small:
+                    wide = torch.from_numpy(mine_rows)
+                    lo, hi = torch.aminmax(wide)
+                    small = int(lo) >= -1 and int(hi) <= 1
+                if small:
+                    narrow8 = wide.to(torch.int8)
+            finally:
+                torch.set_num_threads(threads)
             if small:
-                wide = torch.from_numpy(mine_rows)
-                lo, hi = torch.aminmax(wide)                      # (torch: all host cores)
-                small = int(lo) >= -1 and int(hi) <= 1
-            if small:
-                narrow = wide.to(torch.int8).to(dev)
+                narrow = narrow8.to(dev)
                 small = bool((narrow != 0).all())                 # (+-1 by contract; anything else:
             if small:                                             # the plain way)
                 Bfull[first:first + nm] = narrow
@@ -94,7 +131,8 @@ class StochasticDerivService:
                     np.ascontiguousarray(mine_rows, dtype=np.float64)).to(dev)
         Xf, iters, resid, istop, lanczos = Iterative.solve_device(
             K, Bfull, minres=True, tol=self._tol, maxiter=self._maxiter,
-            lanczos_cap=self.LANCZOS_CAP, scipy_exits=self._scipy_exits,
+            lanczos_cap=(self.LANCZOS_CAP or min(self._maxiter or n, self.LANCZOS_MAX)),
+            scipy_exits=self._scipy_exits,
             precondition=self._precondition)
         idx = torch.tensor(order, device=dev)
         X, B = Xf[idx], Bfull[idx]

@@ -76,5 +76,8 @@ class Case:
 
 ALL_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_mid', 'lmc_2d']
 DENSE_CASES = ['lmc_small', 'lmc_c1', 'lmc_q1', 'lmc_2d']
+# every top row smooth over the grid (round 6): the operators the device inverts directly;
+# dense alpha / K~^-1 r / log det / gradients from the reference's own dense Cholesky + loops
+SMOOTH_CASES = ['lmc_smooth']
 # the reference's real-data workloads (BASELINE configs 3 and 4)
 DATASET_CASES = ['fx2007', 'weather']

@@ -338,6 +338,18 @@ def gen_lmc():
               n_probes=2, dense=False, n_mv=2)
 
 
+def gen_smooth():
+    """Round 6: a model whose top rows are ALL smooth over the grid (RBF, periodic with long
+    length scales on [0, 1]; grid of 150 + 4 points) -- the operators the device library
+    inverts directly through K~ = F M F^T + E (csrc/rl_direct.h).  The reference's dense
+    Cholesky of K~.as_numpy() gives alpha, K~^-1 r_i, log det K~ and, through its own loops, the
+    four gradient families: what that path is held to."""
+    _lmc_case('lmc_smooth', seed=16, D=3,
+              kdescs=[('rbf', 2.0), ('periodic', 1.0, 1.5), ('rbf', 6.0)],
+              ranks=[1, 2, 1], lens=[180, 200, 160], m=150, n_probes=5,
+              store_dense=False)
+
+
 def gen_slfm_quirk():
     """The reference's 'slfm' representation puts an IDENTITY on the grid in the
     place of a part the model does not have (runlmc/lmc/grid_kernel.py:87-88:
@@ -419,12 +431,15 @@ def _main():
         return
     if '--2d-only' in sys.argv:
         return gen_2d()
+    if '--smooth-only' in sys.argv:
+        return gen_smooth()
     if '--split-only' in sys.argv:
         return gen_split()
     if '--datasets-only' not in sys.argv:
         gen_linalg()
         gen_interp()
         gen_lmc()
+        gen_smooth()
         gen_2d()
         gen_split()
         gen_slfm_quirk()

@@ -420,10 +420,16 @@ def check_logdet_slq(name):
     c = Case(name)
     fk, K, gk = build_operator(c)
     ad = c.ad
-    svc = StochasticDerivService(None, None, len(c.rs), 1e-4)
+    svc = StochasticDerivService(None, None, len(c.rs), 1e-4, precondition=False)
     lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
                               c.Ys, svc, probes=c.rs)
     est = lik.deriv.logdet_probe_estimates()
+    # the library's quadrature (implicit QL, one eigenvector row) against LAPACK's eigenpairs
+    from runlmc_amd._native import slq_quadratic_forms_scipy
+    its = np.asarray(lik.deriv.iterations)[1:]
+    np.testing.assert_allclose(
+        est, slq_quadratic_forms_scipy(lik.deriv.lanczos[1:], its, np.full(len(its), float(c.n))),
+        rtol=1e-10)
     exact_ld = float(c.g['logdet_dense'])
     if 'K_dense' in c.g:
         w, V = np.linalg.eigh(c.g['K_dense'])
@@ -698,11 +704,15 @@ def check_solver_fusions():
     # (the switches are read when a handle is created: one operator per mode.  The
     # four-kernel iteration exists in the emulator build only; the product build
     # ignores its switch and runs the two-kernel rounds there as well.)
-    knobs = ('RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_MINRES_V1', 'RUNLMC_SOLVER_MAXBLK')
+    knobs = ('RUNLMC_NO_FUSE_WT', 'RUNLMC_NO_FUSE_W', 'RUNLMC_MINRES_V1', 'RUNLMC_SOLVER_MAXBLK',
+             'RUNLMC_NO_LR_SMALL')
     saved = {k: os.environ.pop(k, None) for k in knobs}
     res = {}
     try:
-        for mode, env in (('fused', {}), ('no_wt', {'RUNLMC_NO_FUSE_WT': '1'}),
+        # (RUNLMC_NO_LR_SMALL: every mode's grid product on the transform kernels -- this test
+        # compares the SOLVER's variants bit for bit; unfused, a small batch of this smooth
+        # operator would otherwise take the one-launch polynomial product, round 6)
+        for mode, env in (('fused', {}), ('no_wt', {'RUNLMC_NO_FUSE_WT': '1', 'RUNLMC_NO_LR_SMALL': '1'}),
                           ('no_w', {'RUNLMC_NO_FUSE_W': '1'}),
                           # one workgroup per system: the long-system loops of P and B
                           ('long_rows', {'RUNLMC_SOLVER_MAXBLK': '1', 'RUNLMC_NO_FUSE_W': '1'}),
@@ -821,8 +831,12 @@ def check_polynomial_form():
             g.set_lmc(smooth, A, kap)
             rank, gate = g.form()
             assert rank in (24, 32, 36, 40, 48), rank
-            assert gate > k * D * m          # default gate: these batches stay on the FFT path
-            fft = g.matmat_host(X)
+            assert gate > k * D * m          # default gate: these batches are below it
+            small = g.matmat_host(X)         # ... the one-launch polynomial product (round 6)
+            g.set_form_gate(1 << 60)
+            fft = g.matmat_host(X)           # the transform kernels
+            g.set_form_gate(-1)
+            _close(small, fft, 1e-12)
             g0 = g
             ref = oracle(smooth)
             _close(fft, ref)
@@ -2031,3 +2045,320 @@ def check_generate_probe_dtypes():
         u = (rs + 1).astype(np.uint16)           # entries 0 / 2
         d = svc.generate(K, p.y, u)
         assert np.array_equal(d._rs, u.astype(np.float64))
+
+
+# --- round 6: direct solves through the polynomial form (csrc/rl_direct.h) --------------
+def _synth_problem_and_oracle(D, Q, m_data, kern, eps=0.1):
+    """A synthetic problem of the reference benchmark's recipe, its device operator and the
+    oracle's DENSE K~ (through the oracle's FFT operator, column by column)."""
+    from runlmc_amd.util import synth
+    from oracle.kernels import KernelSpec, RBFSpec, Matern32Spec, StdPeriodicSpec
+    p = synth.make_problem(D, Q, 1, m_data, eps=eps, kern=kern)
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, gks = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    spec = KernelSpec(p.D, synth.kernel_objects(p.kern_desc, rbf=RBFSpec, periodic=StdPeriodicSpec,
+                                                matern=Matern32Spec),
+                      list(p.coreg_vecs), list(p.coreg_diags), p.noise)
+    spec.set_input_dim(1)
+    op = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    return p, fk, K, gks[ad], spec, op
+
+
+def _dense_spd(op, n):
+    Kd = np.array([op.matvec(e) for e in np.eye(n)]).T
+    return 0.5 * (Kd + Kd.T)
+
+
+def check_direct_solve(kern='rbf', m_data=400):
+    """K~ = F M F^T + E inverted through the Woodbury identity (rl_solve_direct) against the
+    oracle's DENSE solve of the same K~: alpha and probe solves at 1e-9 of the largest entry,
+    log det K~ (determinant lemma, rl_ski_factor) against the dense Cholesky at 1e-11 relative,
+    the residuals the device reports against the oracle's own product; the reference's hook
+    (Iterative.solve reads K.preconditioner, approx/iterative.py:47) takes that path by default
+    and `precondition=False` keeps the Krylov solve; parameter and noise updates rebuild the
+    factorisation; gradients of a whole step against the oracle's loops on dense solves."""
+    import scipy.linalg as la
+    p, fk, K, gk, spec, op = _synth_problem_and_oracle(3, 2, m_data, kern)
+    ski = K.device_operator()
+    ok, logdet, cond = ski.factor()
+    assert ok, ski.factor_reason
+    Kd = _dense_spd(op, p.n)
+    cf = la.cho_factor(Kd)
+    ld_ref = 2.0 * np.log(np.diag(cf[0])).sum()
+    assert abs(logdet - ld_ref) <= 1e-11 * abs(ld_ref), (logdet, ld_ref)
+    M = K.preconditioner
+    assert M is not None and abs(M.logdet() - ld_ref) <= 1e-11 * abs(ld_ref)
+    rng = np.random.RandomState(11)
+    rs = rng.randint(0, 2, (4, p.n)) * 2 - 1
+    B = np.vstack([p.y] + [r.astype(float) for r in rs])
+    Xref = la.cho_solve(cf, B.T).T
+    # the reference's entry point, default path: the preconditioner answers
+    X, iters, resid = Iterative.solve(K, B, verbose=True, tol=1e-9)
+    assert np.all(np.asarray(iters) <= 3), iters
+    assert np.all(np.asarray(resid) < 1e-9), resid
+    for i in range(len(B)):
+        _close(X[i], Xref[i], rel=1e-9)
+        true_res = np.linalg.norm(B[i] - op.matvec(X[i]))
+        # (the residual the device reports is taken through ITS product -- the polynomial form,
+        # accepted at 2e-13 ||T||_2 of the transform kernels: the oracle's FFT operator sees
+        # that difference times ||x||, a few 1e-9 here)
+        assert true_res < 2e-8 and abs(true_res - resid[i]) < 2e-8, (true_res, resid[i])
+    x1 = Iterative.solve(K, p.y, tol=1e-9)
+    assert x1.shape == (p.n,)
+    _close(x1, Xref[0], rel=1e-9)
+    # one application of M (the Matrix face of the preconditioner) is already K~^-1 to ~1e-9
+    _close(M.matvec(p.y), Xref[0], rel=1e-7)
+    _close(M.matmat(B.T).T, Xref, rel=1e-7)
+    # CG with the preconditioner: same path (the reference hands M to either method)
+    Xc = Iterative.solve(K, B, minres=False, tol=1e-9)
+    _close(Xc, Xref, rel=1e-9)
+    # the Krylov solve is still there
+    Xk, itk, resk = Iterative.solve(K, B, verbose=True, tol=1e-4, precondition=False)
+    assert np.all(np.asarray(itk) > 3), itk
+    xo, ito, erro, _ = iterative_solve(op.matvec, B[0], tol=1e-4)
+    assert abs(int(itk[0]) - ito) <= 3, (itk[0], ito)
+    # a whole step: solves through the factorisation, the exact log-det, gradients against
+    # the oracle's per-parameter loops on DENSE solves with the same probes
+    svc = StochasticDerivService(None, None, len(rs), 1e-9)
+    ad = (0,)
+    lik = ApproxLMCLikelihood(fk, K, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.Ys, svc, probes=rs)
+    assert lik.deriv.lanczos is None and lik.deriv.logdet_exact is not None
+    assert abs(lik.log_det_K() - ld_ref) <= 1e-11 * abs(ld_ref)
+    ll_ref = -0.5 * (ld_ref + p.y.dot(Xref[0]) + p.n * np.log(2 * np.pi))
+    assert abs(lik.log_likelihood() - ll_ref) <= 1e-10 * abs(ll_ref)
+    ref = olik.stochastic_gradients(spec, p.grid_dists, p.W, p.WT, p.lens, Xref[0], rs, Xref[1:])
+    got = (lik.coreg_vec_gradients(), lik.coreg_diags_gradients(), lik.kernel_gradients(),
+           lik.noise_gradient())
+    # (each family against its own largest entry: the noise gradient is three decades above
+    # the coupling gradients here)
+    for fam, key in ((got[0], 'coreg_vec'), (got[1], 'coreg_diag'), (got[2], 'kernel')):
+        scale = max(max(np.abs(np.asarray(a)).max() for a in ref[key]), 1.0)
+        for q in range(p.Q):
+            assert np.abs(np.asarray(fam[q]) - np.asarray(ref[key][q])).max() < 1e-8 * scale, key
+    assert np.abs(got[3] - ref['noise']).max() < 1e-8 * max(np.abs(ref['noise']).max(), 1.0)
+    # those Gram terms came out of the coefficient space (two projections + a contraction,
+    # likelihood.py: _coefficient_grams); the streaming products give the same gradients
+    skiop = K.device_operator()
+    U = lik.deriv.inv_rs_dev[:2].contiguous()
+    Pc = lik._coefficient_grams(skiop, 0, skiop.grids[0], list(fk.active_dims[ad]), U, U)
+    assert Pc is not None and Pc.shape[1:] == (2, p.D, p.D)
+    ApproxLMCLikelihood.COEFFICIENT_GRAMS = False
+    try:
+        lik2 = ApproxLMCLikelihood(fk, K, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.Ys, svc, probes=rs)
+        got2 = (lik2.coreg_vec_gradients(), lik2.coreg_diags_gradients(), lik2.kernel_gradients(),
+                lik2.noise_gradient())
+    finally:
+        ApproxLMCLikelihood.COEFFICIENT_GRAMS = True
+    for fam, fam2 in zip(got[:3], got2[:3]):
+        for q in range(p.Q):
+            x, y2 = np.asarray(fam[q]), np.asarray(fam2[q])
+            assert np.abs(x - y2).max() <= 1e-9 * max(np.abs(y2).max(), 1.0)
+    assert np.abs(got[3] - got2[3]).max() <= 1e-9 * np.abs(got2[3]).max()
+    # parameter update: the factorisation follows (log det of the scaled kernel part)
+    fk2 = functional_kernel_for_synth(p, scale=1.7)
+    gk.update(fk2, p.grid_dists)
+    spec.coreg_vecs = [np.sqrt(1.7) * a for a in spec.coreg_vecs]
+    spec.coreg_diags = [1.7 * k for k in spec.coreg_diags]
+    op2 = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    Kd2 = _dense_spd(op2, p.n)
+    cf2 = la.cho_factor(Kd2)
+    ld2 = 2.0 * np.log(np.diag(cf2[0])).sum()
+    assert abs(K.preconditioner.logdet() - ld2) <= 1e-11 * abs(ld2)
+    _close(Iterative.solve(K, p.y, tol=1e-9), la.cho_solve(cf2, p.y), rel=1e-9)
+    # noise update
+    noise2 = p.noise * np.array([0.5, 2.0, 1.0])
+    K.update_noise(noise2, p.lens)
+    Kd3 = Kd2 + np.diag(np.repeat(noise2 - p.noise, p.lens))
+    cf3 = la.cho_factor(Kd3)
+    ld3 = 2.0 * np.log(np.diag(cf3[0])).sum()
+    assert abs(K.preconditioner.logdet() - ld3) <= 1e-11 * abs(ld3)
+    _close(Iterative.solve(K, p.y, tol=1e-9), la.cho_solve(cf3, p.y), rel=1e-9)
+    return dict(kern=kern, n=p.n, rank=gk._op.form()[0], cond=cond, logdet=logdet,
+                iterations=[int(v) for v in iters])
+
+
+def functional_kernel_for_synth(p, scale=1.0):
+    """The synthetic problem's FunctionalKernel with its couplings scaled."""
+    from runlmc_amd.util import synth
+    fk = synth.functional_kernel(p)
+    fk.coreg_vecs = [np.sqrt(scale) * a for a in fk.coreg_vecs]
+    fk.coreg_diags = [scale * k for k in fk.coreg_diags]
+    return fk
+
+
+def check_direct_unavailable():
+    """Operators outside the form keep the Krylov path: a Matern top (filter form), a short grid,
+    a 2-D grid; the C entry point says why and rl_solve_direct refuses with RL_ELIMIT."""
+    from runlmc_amd._native import solve_direct
+    p, fk, K, gk, spec, op = _synth_problem_and_oracle(2, 2, 300, 'matern')
+    assert K.preconditioner is None
+    ski = K.device_operator()
+    ok, ld, _ = ski.factor()
+    assert not ok and 'polynomial form' in ski.factor_reason, ski.factor_reason
+    try:
+        solve_direct(ski, torch.from_numpy(p.y[None, :]).to(ski.device))
+        raise AssertionError('rl_solve_direct accepted an operator outside the form')
+    except NotImplementedError as e:
+        assert 'not available' in str(e)
+    x, it, err = Iterative.solve(K, p.y, verbose=True)          # Krylov, as before
+    xo, ito, erro, _ = iterative_solve(op.matvec, p.y, tol=1e-4)
+    assert abs(it - ito) <= 3
+    for name in ('lmc_small', 'lmc_2d'):
+        c = Case(name)
+        _, Kc, _ = build_operator(c)
+        assert Kc.preconditioner is None, name
+    # bad arguments
+    p2, fk2, K2, gk2, spec2, op2 = _synth_problem_and_oracle(2, 1, 200, 'rbf')
+    ski2 = K2.device_operator()
+    b = torch.from_numpy(p2.y[None, :]).to(ski2.device)
+    for kw in (dict(tol=0.0), dict(tol=-1.0), dict(max_refine=-1)):
+        try:
+            solve_direct(ski2, b, **kw)
+            raise AssertionError(kw)
+        except ValueError:
+            pass
+    X, it, rs, st = solve_direct(ski2, b[:0].contiguous())
+    assert X.shape == (0, p2.n)
+
+
+def check_direct_golden(name='lmc_smooth'):
+    """A model whose top rows are all smooth, run through the REFERENCE (tests/golden/
+    make_golden.py: gen_smooth): log det K~, alpha, K~^-1 r_i from its dense Cholesky of
+    K~.as_numpy() and the four gradient families from its own loops on those dense solves --
+    against the device's factorisation (determinant lemma at 1e-9, solves refined to 1e-9 at
+    1e-8 of the largest entry, gradients of the whole step at 1e-8)."""
+    c = Case(name)
+    fk, K, gk = build_operator(c)
+    M = K.preconditioner
+    assert M is not None, K.device_operator().factor_reason
+    ld = M.logdet()
+    ref = float(c.g['logdet_dense'])
+    assert abs(ld - ref) <= 1e-9 * abs(ref), (ld, ref)
+    B = np.vstack([c.y] + [r.astype(float) for r in c.rs])
+    X, iters, resid = Iterative.solve(K, B, verbose=True, tol=1e-9)
+    assert np.all(np.asarray(resid) < 1e-9) and np.all(np.asarray(iters) <= 3), (iters, resid)
+    _close(X[0], c.g['alpha_dense'], rel=1e-8)
+    _close(X[1:], c.g['inv_rs_dense'], rel=1e-8)
+    ad = c.ad
+    svc = StochasticDerivService(None, None, len(c.rs), 1e-9)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)}, c.Ys, svc,
+                              probes=c.rs)
+    _compare_grads(lik, c, rel=1e-8)
+    assert abs(lik.log_det_K() - ref) <= 1e-9 * abs(ref)
+    ll_ref = -0.5 * (ref + c.y.dot(c.g['alpha_dense']) + c.n * np.log(2 * np.pi))
+    assert abs(lik.log_likelihood() - ll_ref) <= 1e-9 * abs(ll_ref)
+    # the reference's real-data workload: claimed only if its fitted kernel is in the form
+    c2 = Case('fx2007')
+    _, K2, _ = build_operator(c2)
+    M2 = K2.preconditioner
+    out = dict(logdet=ld, logdet_dense=ref, iterations=[int(v) for v in iters],
+               fx2007_available=M2 is not None)
+    if M2 is not None:
+        ref2 = float(c2.g['logdet_dense'])
+        assert abs(M2.logdet() - ref2) <= 1e-9 * abs(ref2)
+        _close(Iterative.solve(K2, c2.y, tol=1e-8), c2.g['alpha_dense'], rel=1e-7)
+    else:
+        out['fx2007_reason'] = K2.device_operator().factor_reason
+    return out
+
+
+def check_direct_row_orders():
+    """Inputs that are not sorted (the handle permutes rows internally) and a caller who
+    interleaves the outputs' rows: with one noise level everywhere the factorisation is
+    available and answers in the CALLER's order; with per-output noise in interleaved rows it
+    says so and the Krylov path answers."""
+    import scipy.linalg as la
+    from runlmc_amd._native import GridOp, SkiOp, solve_direct
+    from runlmc_amd.util import synth
+    p = synth.make_problem(2, 2, 1, 300, kern="rbf")
+    tops = synth.tops(p)
+    rng = np.random.RandomState(5)
+    perm = rng.permutation(p.n)
+    W = p.W.tocsr()[perm]
+    WT = W.transpose().tocsr()
+    WT.sort_indices()
+    Bs = ops.coreg_mats(list(p.coreg_vecs), list(p.coreg_diags))
+    toeps = [ops.BTTBOracle(t) for t in tops]
+    g = GridOp(p.D, p.m, p.Q)
+    g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
+    s = SkiOp(g, W, WT)
+    eps = 0.07
+    s.set_noise(np.full(p.D, eps), p.lens)
+    ok, ld, _ = s.factor()
+    assert ok, s.factor_reason
+
+    def mv(x):
+        return W @ ops.grid_sum_matvec(Bs, toeps, WT @ x) + eps * x
+    Kd = np.array([mv(e) for e in np.eye(p.n)]).T
+    Kd = 0.5 * (Kd + Kd.T)
+    cf = la.cho_factor(Kd)
+    assert abs(ld - 2 * np.log(np.diag(cf[0])).sum()) <= 1e-11 * abs(ld)
+    B = rng.randn(3, p.n)
+    X, it, rs, st = solve_direct(s, torch.from_numpy(B).to(s.device), tol=1e-9)
+    _close(X.cpu().numpy(), la.cho_solve(cf, B.T).T, rel=1e-9)
+    assert np.all(st == 10)
+    # per-output noise while the caller's rows interleave outputs: not constant per output
+    s.set_noise(np.array([0.05, 0.2]), p.lens)
+    ok, _, _ = s.factor()
+    assert not ok and 'noise' in s.factor_reason, s.factor_reason
+
+
+def check_small_batch_polynomial():
+    """Batches BELOW the gate of an operator wholly in the polynomial form: one launch
+    (k_lr_small: projection of all D rows, coefficient map, expansion of one row per workgroup)
+    against the oracle's FFT statement, for D below / equal to / above the kernel's eight waves,
+    odd and even grids, ranks 24 and above; the small batch itself triggers the pending
+    verification (rank reported afterwards); RUNLMC_NO_LR_SMALL and a moved gate keep the
+    transform kernels; a Matern top keeps them too."""
+    from runlmc_amd._native import GridOp
+    rng = np.random.RandomState(21)
+    cases = [(4, 3, 5004, 'rbf'), (2, 2, 1501, 'rbf'), (10, 3, 700, 'rbf'), (3, 2, 2000, 'periodic'),
+             (1, 1, 400, 'rbf')]
+    out = []
+    for D, Q, m, kind in cases:
+        t = np.linspace(0, 1, m)
+        if kind == 'rbf':
+            tops = np.array([np.exp(-0.5 * (1.0 + 2.0 * q) * t ** 2) for q in range(Q)])
+        else:
+            tops = np.array([np.exp(-2.0 * np.sin(np.pi * t / (1.0 + 0.7 * q)) ** 2) for q in range(Q)])
+        A = [rng.randn(1 + q % 2, D) for q in range(Q)]
+        kap = [np.abs(rng.randn(D)) + 0.1 for _ in range(Q)]
+        Bs = ops.coreg_mats(A, kap)
+        toeps = [ops.BTTBOracle(tt) for tt in tops]
+        g = GridOp(D, m, Q)
+        g.set_lmc(tops, A, kap)
+        for nvec in (1, 3, 17):
+            X = rng.randn(nvec, D * m)
+            got = g.matmat_host(X)
+            ref = np.array([ops.grid_sum_matvec(Bs, toeps, v) for v in X])
+            _close(got, ref, rel=1e-11)
+        rank, gate = g.form()
+        assert rank in (24, 32, 36, 40, 48), (D, Q, m, kind, rank)
+        assert 17 * D * m < gate
+        forms, structured = g.top_forms()
+        assert all(f == 1 for f in forms) and structured
+        out.append((D, m, kind, rank))
+        # a moved gate: the caller's choice stands (transform kernels below it)
+        g.set_form_gate(1 << 60)
+        _close(g.matmat_host(X), ref, rel=1e-11)
+        g.set_form_gate(-1)
+        # new parameters: the map follows
+        kap2 = [2.0 * k for k in kap]
+        g.set_lmc(tops, A, kap2)
+        Bs2 = ops.coreg_mats(A, kap2)
+        ref2 = np.array([ops.grid_sum_matvec(Bs2, toeps, v) for v in X])
+        _close(g.matmat_host(X), ref2, rel=1e-11)
+    # an operator with a Matern top is not wholly polynomial: transform kernels as before
+    m = 1500
+    t = np.linspace(0, 1, m)
+    tops = np.array([np.exp(-0.5 * t ** 2), (1 + 3.0 * t) * np.exp(-3.0 * t)])
+    A = [rng.randn(1, 3), rng.randn(1, 3)]
+    kap = [np.abs(rng.randn(3)) + 0.1 for _ in range(2)]
+    g = GridOp(3, m, 2)
+    g.set_lmc(tops, A, kap)
+    X = rng.randn(5, 3 * m)
+    Bs = ops.coreg_mats(A, kap)
+    toeps = [ops.BTTBOracle(tt) for tt in tops]
+    _close(g.matmat_host(X), np.array([ops.grid_sum_matvec(Bs, toeps, v) for v in X]), rel=1e-11)
+    return out

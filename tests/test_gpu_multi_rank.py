@@ -113,9 +113,30 @@ def test_sharded_block_through_rccl_in_a_world_of_one():
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-3000:]
 
 
-def test_bench_refuses_wrong_world_size():
-    """--gpus N without N ranks must fail loudly, with the launch line."""
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher: the script starts its two ranks itself
+    (a torch.distributed.run child; here both on cuda:0 over gloo), relays rank 0's line and
+    exits with the children's status; the line relates the sharded step to the one-rank step."""
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                        '--dist-backend', 'gloo', '--same-gpu'] + COMMON,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                       timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j['n_gpus'] == 2 and j['config']['parallelism'] == 'probe-shard x2'
+    assert j['nll_grad']['speedup_vs_one_rank'] > 0 and j['nll_grad']['one_rank_seconds'] > 0
+    assert j['nll_grad']['bits_equal_across_ranks'] == {'alpha': True, 'gradient': True}
+
+
+def test_bench_refuses_a_launcher_of_another_size():
+    """Under a launcher whose WORLD_SIZE is not --gpus the script fails loudly, with the
+    launch line (it does not start ranks inside ranks)."""
+    env = dict(os.environ, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'] + COMMON,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=env)
     assert r.returncode != 0
     assert 'torch.distributed.run' in (r.stderr + r.stdout)

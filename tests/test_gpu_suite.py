@@ -181,3 +181,25 @@ def test_polynomial_gate_boundary():
 def test_polynomial_rounds():
     ps.check_polynomial_rounds()
 
+
+
+# --- round 6: direct solves through the polynomial form ---------------------------------
+@pytest.mark.parametrize('kern,m_data', [('rbf', 400), ('periodic', 600), ('rbf', 1500)])
+def test_direct_solve(kern, m_data):
+    print(ps.check_direct_solve(kern, m_data))
+
+
+def test_direct_unavailable():
+    ps.check_direct_unavailable()
+
+
+def test_direct_golden():
+    print(ps.check_direct_golden())
+
+
+def test_direct_row_orders():
+    ps.check_direct_row_orders()
+
+
+def test_small_batch_polynomial():
+    print(ps.check_small_batch_polynomial())

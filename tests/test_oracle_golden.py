@@ -7,7 +7,7 @@ from oracle import operators as ops
 from oracle import interp
 from oracle import likelihood as lik
 from oracle.solver import iterative_solve
-from cases import Case, ALL_CASES, DENSE_CASES, DATASET_CASES, GOLDEN
+from cases import Case, ALL_CASES, DENSE_CASES, DATASET_CASES, SMOOTH_CASES, GOLDEN
 
 import os
 
@@ -105,7 +105,7 @@ def test_interpolation():
                                g['mi_dense'], **TIGHT)
 
 
-@pytest.mark.parametrize('name', ALL_CASES + DATASET_CASES)
+@pytest.mark.parametrize('name', ALL_CASES + DATASET_CASES + SMOOTH_CASES)
 def test_lmc_operator(name):
     c = Case(name)
     spec = c.spec()
@@ -139,6 +139,25 @@ def test_dense_and_logdet():
                                float(c.g['logdet_dense']), rtol=1e-12)
 
 
+@pytest.mark.parametrize('name', SMOOTH_CASES)
+def test_dense_solves_and_logdet_smooth(name):
+    """The oracle's dense K~ of the smooth case: alpha, K~^-1 r_i and log det K~ against the
+    reference's own dense Cholesky values (what the device's direct solve is held to)."""
+    import scipy.linalg as la
+    c = Case(name)
+    op = lik.LMCOperatorOracle(c.spec(), c.grid_dists, c.W, c.WT, c.lens)
+    Kd = op.as_numpy()
+    Kd = 0.5 * (Kd + Kd.T)
+    cf = la.cho_factor(Kd)
+    np.testing.assert_allclose(2 * np.log(np.diag(cf[0])).sum(), float(c.g['logdet_dense']),
+                               rtol=1e-11)
+    ref = c.g['alpha_dense']
+    np.testing.assert_allclose(la.cho_solve(cf, c.y), ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    ref = c.g['inv_rs_dense']
+    np.testing.assert_allclose(la.cho_solve(cf, c.rs.T.astype(float)).T, ref, rtol=0,
+                               atol=1e-8 * np.abs(ref).max())
+
+
 def test_exact_dense_twin():
     """oracle.likelihood.exact_gradients against the reference's own ExactLMCLikelihood
     (likelihood.py:137-217, exact_deriv.py) run on a small seeded model (exact_small.npz,
@@ -169,7 +188,7 @@ def test_exact_dense_twin():
                                atol=1e-9 * np.abs(g['grad_noise']).max())
 
 
-@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'])
+@pytest.mark.parametrize('name', DENSE_CASES + ['fx2007'] + SMOOTH_CASES)
 def test_gradients_fixed_probes(name):
     """Reference gradient loops fed dense solves + stored probes: fully
     deterministic, so the oracle must match to roundoff."""
@@ -188,7 +207,7 @@ def test_gradients_fixed_probes(name):
                                atol=1e-9)
 
 
-@pytest.mark.parametrize('name', ALL_CASES)
+@pytest.mark.parametrize('name', ALL_CASES + SMOOTH_CASES)
 def test_reference_solver_wrapper(name):
     """The reference's Iterative.solve iterates, iteration counts and
     residuals (SciPy under it) vs the oracle's restated MINRES/CG."""
