@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05', 'traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r06', 'traffic.json')
 
 
 def parse():
@@ -506,6 +506,9 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
         tdist.all_reduce(lo, op=tdist.ReduceOp.MIN, group=group)
         info['bits_equal_across_ranks'] = {'alpha': bool(hi[0] == lo[0]),
                                            'gradient': bool(hi[1] == lo[1])}
+    for k_ in ('nll', 'logdet', 'logdet_sem'):
+        if k_ in info and not np.isfinite(info[k_]):
+            info[k_] = None                       # (strict JSON has no NaN)
     if keep_gradient:
         info['_gradient'] = flat_gradient(g)      # (popped by the caller: not part of the line)
     info['seconds'] = best
@@ -552,6 +555,13 @@ def product_form(g, batch, D, m):
     rank_poly, gate = g.form()
     big = batch * D * m >= gate
     names = [FORM_NAMES[f] for f in forms]
+    if (not big and structured and all(f == 1 for f in forms) and D * m <= 32768
+            and gate == (1 << 20)):
+        # (csrc/rl_lowrank.h: RL_LR_SMALL_MAX; a batch below the gate of an operator wholly in
+        # the polynomial form, round 6)
+        return 'poly', names, ('grid MVM, polynomial-subspace form for a batch below the gate: two '
+                               'launches spread over the chip (k_lr_small_project -> '
+                               'k_lr_small_expand, rank %d), D=%d' % (rank_poly, D))
     if not (big and structured):
         return 'fft', names, ('grid MVM (column transforms + row transforms with the D x D mix '
                               '+ adjoint column transforms), D=%d' % D)
@@ -783,11 +793,19 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
                                precondition=False)
             grad_kry = kry.pop('_gradient')
             kry['seconds'] = max_over_ranks(kry['seconds'], world, dev)
+            if world > 1:
+                # the probe-parallel axis proper (reference lmc/stochastic_deriv.py:39-52): the
+                # same Krylov step on one rank alone against the sharded one
+                one = gpu_nll_grad(pe, probes, n_probes, group=None, repeats=1, precondition=False)
+                one_s = max_over_ranks(one['seconds'], world, dev)
+                kry['one_rank_seconds'] = one_s
+                kry['speedup_vs_one_rank'] = one_s / kry['seconds']
             kry.update(n_probes_global=n_probes, eps=eps,
                        gradient_rel_distance_to_default_step=rel_dist(grad_kry, grad_default),
                        logdet_exact=info['logdet'],
-                       logdet_slq_minus_exact=kry['logdet'] - info['logdet'])
-            if kry.get('logdet_sem'):
+                       logdet_slq_minus_exact=(kry['logdet'] - info['logdet']
+                                               if kry['logdet'] is not None else None))
+            if kry.get('logdet_sem') and kry['logdet'] is not None:
                 kry['logdet_slq_minus_exact_in_sem'] = (kry['logdet'] - info['logdet']) / kry['logdet_sem']
             if world == 1 and n_probes >= 16 and not args.no_extra:
                 share = n_probes // 8

@@ -38,7 +38,8 @@ typedef struct rl_ski rl_ski;
 /* Version of this ABI: bumped whenever a declared signature changes (2: rl_solve_batch_lanczos
  * gained `method`, round 4; 3: rl_gridop_form_stats added, round 5; 4: rl_ski_factor,
  * rl_solve_direct, rl_ski_project,
- * rl_gridop_project, rl_gridop_poly_coeffs, rl_slq_log_quadrature added, round 6; callers built against an older version must be rebuilt).  A binding
+ * rl_gridop_project, rl_gridop_set_rank_hint, rl_gridop_poly_coeffs, rl_slq_log_quadrature,
+ * rl_probes_to_int8 added, round 6; callers built against an older version must be rebuilt).  A binding
  * compares rl_abi_version() with the RL_ABI_VERSION it was written against before its
  * first call (runlmc_amd/_lib.py does) instead of finding out through shifted arguments. */
 #define RL_ABI_VERSION 4
@@ -229,10 +230,18 @@ int rl_solve_batch_lanczos(rl_ski* s, const double* B, double* X, int nrhs, int 
  * tridiagonal T_v of system v (lanczos host [nrhs][cap][2] as rl_solve_batch_lanczos fills
  * it, k = min(iters[v], cap) steps) -- Gauss quadrature of r^T log(K~) r by the implicit QL
  * iteration carrying one row of the eigenvector matrix, O(k^2) per system, systems spread
- * over `nthreads` host threads.  No device work.  (The mean of out over Rademacher probes,
+ * over `nthreads` host threads; out[v] = NaN for a system whose iteration did not settle
+ * (the caller falls back to LAPACK for it).  No device work.  (The mean of out over Rademacher probes,
  * sqnorms = n, estimates log det K~.)                                                      */
 int rl_slq_log_quadrature(const double* lanczos, int nrhs, int cap, const int* iters,
                           const double* sqnorms, double* out, int nthreads);
+/* Host helper: the reference draws its Rademacher probes as an int64 matrix
+ * (lmc/stochastic_deriv.py:35: randint(0, 2, (N, n)) * 2 - 1 -- 1 GB at BASELINE's C5).  One
+ * pass over it on `nthreads` host threads: dst[r][k] = (int8) src[r * row_stride + k] for
+ * nrows rows of n entries, *all_pm1 = 1 iff every entry is +1 or -1 (else the caller sends the
+ * matrix the plain way).  dst may be pinned memory; no device work.                        */
+int rl_probes_to_int8(const long long* src, int nrows, long long row_stride, long long n,
+                      signed char* dst, int nthreads, int* all_pm1);
 
 /* ---- direct solves through the polynomial form ------------------------------
  * The reference's Iterative.solve takes a preconditioner from the operator
@@ -272,6 +281,11 @@ int rl_ski_project(rl_ski* s, const double* X, int nvec, double* out, int* rank,
  * whose derivative rows need a larger basis than the operator's own (Phi is nested: the first
  * r functions of a larger basis are the smaller one).                                       */
 int rl_gridop_project(rl_gridop* g, const double* X, int nvec, int rank, double* out, void* stream);
+/* Where the set-time verification of the polynomial form starts its ladder of basis sizes
+ * (24, 32, 36, 40, 48; 0 = from the bottom): a handle holding the derivative rows of kernels
+ * whose own rows were accepted at rank r elsewhere need not try the smaller ones.  Only speed
+ * depends on it (a rank that is larger than needed costs proportionally more).           */
+int rl_gridop_set_rank_hint(rl_gridop* g, int rank);
 int rl_gridop_poly_coeffs(rl_gridop* g, int q, double* out, int cap, int* rank);
 /* X[v] = K~^-1 B[v]:  x = M b, then  x += M (b - K~ x)  while the reference's rule
  * ||b - K~ x||_2 < tol (iterative.py:36-42,54-58) does not hold, at most max_refine

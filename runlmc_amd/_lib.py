@@ -54,10 +54,12 @@ _SIGNATURES = {
     'rl_solve_batch': [_vp, _vp, _vp, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp],
     'rl_solve_batch_lanczos': [_vp, _vp, _vp, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     'rl_slq_log_quadrature': [_vp, _i, _i, _vp, _vp, _vp, _i],
+    'rl_probes_to_int8': [_vp, _i, ctypes.c_longlong, ctypes.c_longlong, _vp, _i, _c_int_p],
     'rl_ski_factor': [_vp, _c_int_p, _c_dbl_p, _c_dbl_p],
     'rl_ski_project': [_vp, _vp, _i, _vp, _c_int_p, _vp],
     'rl_gridop_poly_coeffs': [_vp, _i, _vp, _i, _c_int_p],
     'rl_gridop_project': [_vp, _vp, _i, _i, _vp, _vp],
+    'rl_gridop_set_rank_hint': [_vp, _i],
     'rl_solve_direct': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp],
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],

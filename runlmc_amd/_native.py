@@ -121,6 +121,10 @@ class GridOp:
                       dev_ptr(out), self.lib.stream_ptr(self.device))
         return out
 
+    def set_rank_hint(self, rank):
+        """First basis size the verification of the polynomial form tries (0: from 24 up)."""
+        self.lib.call('rl_gridop_set_rank_hint', self._h, int(rank))
+
     def set_form_gate(self, min_elements):
         """Smallest batch (nvec*D*m elements) run in the polynomial form;
         0 = every batch, negative = the library default."""
@@ -383,6 +387,9 @@ def slq_quadratic_forms(lanczos, iters, sqnorms, lib=None):
         cores = os.cpu_count() or 1
     lib.call('rl_slq_log_quadrature', host_ptr(lanczos), int(k), int(lanczos.shape[1]),
              host_ptr(its), host_ptr(sq), host_ptr(out), int(max(1, min(cores, 32))))
+    failed = np.flatnonzero(np.isnan(out))
+    if len(failed):          # (an iteration that did not settle: LAPACK takes those systems)
+        out[failed] = slq_quadratic_forms_scipy(lanczos[failed], its[failed], sq[failed])
     return out
 
 
@@ -400,10 +407,17 @@ def slq_quadratic_forms_scipy(lanczos, iters, sqnorms):
         if k == 1:
             theta, tau2 = d[:1], np.ones(1)
         else:
+            if not (np.all(np.isfinite(d)) and np.all(np.isfinite(e))):
+                out[i] = np.nan          # (a recurrence that left the finite numbers)
+                continue
             try:
                 theta, vecs = eigh_tridiagonal(d, e)
             except np.linalg.LinAlgError:
-                theta, vecs = eigh_tridiagonal(d, e, lapack_driver='stev')
+                try:
+                    theta, vecs = eigh_tridiagonal(d, e, lapack_driver='stev')
+                except np.linalg.LinAlgError:
+                    out[i] = np.nan
+                    continue
             tau2 = vecs[0] ** 2
         keep = theta > 0
         out[i] = sqnorms[i] * np.sum(tau2[keep] * np.log(theta[keep]))

@@ -411,6 +411,7 @@ struct rl_gridop {
     std::vector<int> lr_Qi;
     bool lr_bypass = false;     // set while the FFT path is wanted (set-time verification)
     int lr_r = 0;               // basis size in use (24 / 32 / 48)
+    int lr_rank_hint = 0;       // first rank the verification tries (rl_gridop_set_rank_hint)
     size_t lr_min = 0;          // batches below this many elements stay on the FFT path
     double* lr_beta = nullptr;  // dev [RL_LR_RMAX] recurrence coefficients
     double* lr_nu = nullptr;    // dev [RL_LR_RMAX] normalisation
@@ -2193,6 +2194,9 @@ static int lr_verify(rl_gridop* g, const std::vector<char>& want, std::vector<ch
         RL_HIP(hipMemcpy(g->lr_sel, sel.data(), sel.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     for (int r : {24, 32, 36, 40, 48}) {
+        // (a caller who knows where a sibling handle's rows were accepted starts the ladder
+        // there: rl_gridop_set_rank_hint)
+        if (r < g->lr_rank_hint && r < 48) continue;
         g->lr_r = r;
         const int nvr = (r + RL_LR_EXTRA + D - 1) / D, nrows = nvr * D;
         RL_TRY(lr_reserve(g, std::max(nvr, 1)));
@@ -2976,6 +2980,9 @@ struct rl_ski {
     double* dz_Zt = nullptr;            // dev [D r][D r]: the solve map, scalings folded in
     size_t dz_Zt_cap = 0;
     double* dz_inv = nullptr;           // dev [n]: 1 / eps per row
+    std::vector<double> dz_eps;         // host [D]: the noise level of each output ...
+    const char* dz_eps_why = nullptr;   // ... or why there is none (not constant per output, not positive)
+    unsigned long long dz_eps_ver = ~0ull;   // noise_ver those (and dz_inv) were derived from
     bool dz_valid = false;              // ... for the parameters / noise of the versions below
     unsigned long long dz_param_ver = 0, dz_noise_ver = 0;
     int dz_R = 0;
@@ -4772,21 +4779,38 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     hipStream_t st = nullptr;
     RL_TRY(rp_prepare(s, std::max(R, 1)));
     if (s->rp_F == nullptr || s->rp_R != R) { *why = "no table of F"; return RL_OK; }
-    // per-output noise, rows per output
-    std::vector<double> eps(D, 0.0);
+    // per-output noise, rows per output, 1 / eps per row on the device: per NOISE update (a
+    // parameter update alone does not walk the n rows again)
+    if (s->dz_eps_ver != s->noise_ver || (int)s->dz_eps.size() != D) {
+        s->dz_eps.assign(D, 0.0);
+        s->dz_eps_why = nullptr;
+        for (int d = 0, a = 0; d < D && !s->dz_eps_why; ++d) {
+            const int b = s->h_out_end[d];
+            if (b > a) {
+                s->dz_eps[d] = s->h_noise[a];
+                for (int i = a; i < b; ++i)
+                    if (s->h_noise[i] != s->dz_eps[d]) { s->dz_eps_why = "noise is not constant per output"; break; }
+            } else {
+                s->dz_eps[d] = 1.0;
+            }
+            if (!s->dz_eps_why && (!(s->dz_eps[d] > 0.0) || !std::isfinite(s->dz_eps[d])))
+                s->dz_eps_why = "noise is not positive";
+            a = b;
+        }
+        if (!s->dz_eps_why) {
+            std::vector<double> inv((size_t)n);
+            for (int i = 0; i < n; ++i) inv[i] = 1.0 / s->h_noise[i];
+            if (!s->dz_inv) RL_HIP(hipMalloc((void**)&s->dz_inv, (size_t)n * sizeof(double)));
+            RL_HIP(hipMemcpy(s->dz_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        s->dz_eps_ver = s->noise_ver;
+    }
+    if (s->dz_eps_why) { *why = s->dz_eps_why; return RL_OK; }
+    const std::vector<double>& eps = s->dz_eps;
     std::vector<int> rows(D, 0);
     for (int d = 0, a = 0; d < D; ++d) {
-        const int b = s->h_out_end[d];
-        rows[d] = b - a;
-        if (b > a) {
-            eps[d] = s->h_noise[a];
-            for (int i = a; i < b; ++i)
-                if (s->h_noise[i] != eps[d]) { *why = "noise is not constant per output"; return RL_OK; }
-        } else {
-            eps[d] = 1.0;
-        }
-        if (!(eps[d] > 0.0) || !std::isfinite(eps[d])) { *why = "noise is not positive"; return RL_OK; }
-        a = b;
+        rows[d] = s->h_out_end[d] - a;
+        a = s->h_out_end[d];
     }
     // Gram matrices of F on the unnormalised basis, once per (handle, rank): the columns of F
     // ARE a batch of R vectors (degree-major table)
@@ -4921,10 +4945,6 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
         s->dz_Zt_cap = Zs.size();
     }
     RL_HIP(hipMemcpy(s->dz_Zt, Zs.data(), Zs.size() * sizeof(double), hipMemcpyHostToDevice));
-    std::vector<double> inv((size_t)n);
-    for (int i = 0; i < n; ++i) inv[i] = 1.0 / s->h_noise[i];
-    if (!s->dz_inv) RL_HIP(hipMalloc((void**)&s->dz_inv, (size_t)n * sizeof(double)));
-    RL_HIP(hipMemcpy(s->dz_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
     s->dz_logdet = logdet;
     s->dz_cond = (pmax / pmin) * (pmax / pmin);
     s->dz_param_ver = g->param_ver;
@@ -4990,6 +5010,15 @@ extern "C" int rl_ski_project(rl_ski* s, const double* X, int nvec, double* out,
     RL_LAUNCH(k_dz_coeffs, dim3(nvec), dim3(256), 0, st, (const double*)s->rp_part,
               (const int*)s->rp_run_ptr, nvec, g->D, g->lr_r, (const double*)g->lr_nu, out);
     RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+extern "C" int rl_gridop_set_rank_hint(rl_gridop* g, int rank) {
+    if (!g) return fail(RL_EINVAL, "rl_gridop_set_rank_hint: NULL handle");
+    if (rank != 0 && rank != 24 && rank != 32 && rank != 36 && rank != 40 && rank != 48)
+        return fail(RL_EINVAL, "rl_gridop_set_rank_hint: rank must be 0 or one of 24, 32, 36, 40, 48");
+    if (g->wide) return rl_gridop_set_rank_hint(g->child, rank);
+    g->lr_rank_hint = rank;
     return RL_OK;
 }
 
@@ -5164,7 +5193,7 @@ static bool slq_ql_first_row(std::vector<double>& d, std::vector<double>& e, std
                 if (std::fabs(e[m]) <= eps * dd) break;
             }
             if (m == l) break;
-            if (iter++ == 80) return false;
+            if (iter++ == 300) return false;
             double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
             double r = std::hypot(g, 1.0);
             g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
@@ -5200,6 +5229,50 @@ static bool slq_ql_first_row(std::vector<double>& d, std::vector<double>& e, std
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Host helper: +-1 probes drawn as the reference draws them (int64) -> one byte per entry
+// ---------------------------------------------------------------------------
+extern "C" int rl_probes_to_int8(const long long* src, int nrows, long long row_stride, long long n,
+                                 signed char* dst, int nthreads, int* all_pm1) {
+    if (!src || !dst || !all_pm1) return fail(RL_EINVAL, "rl_probes_to_int8: NULL argument");
+    if (nrows < 0 || n < 0) return fail(RL_EINVAL, "rl_probes_to_int8: negative size");
+    const int nt = (int)std::max<long long>(1, std::min<long long>(nthreads, (long long)nrows * n / 65536 + 1));
+    std::vector<int> bad((size_t)nt, 0);
+    // (ONE pass: every entry is read once, checked and narrowed; rows of the matrix are
+    // `row_stride` entries apart -- a rank's share of a round-robin deal is a strided view)
+    auto work = [&](int t) {
+        const long long total = (long long)nrows * n, lo = total * t / nt, hi = total * (t + 1) / nt;
+        int b = 0;
+        long long r = n > 0 ? lo / n : 0, c = n > 0 ? lo - r * n : 0;
+        for (long long e = lo; e < hi;) {
+            const long long* sr = src + r * row_stride;
+            signed char* dr = dst + r * n;
+            const long long cend = std::min(n, c + (hi - e));
+            for (long long k = c; k < cend; ++k) {
+                const long long v = sr[k];
+                b |= (v != 1 && v != -1);
+                dr[k] = (signed char)v;
+            }
+            e += cend - c;
+            c = 0;
+            ++r;
+        }
+        bad[t] = b;
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread& th : pool) th.join();
+    }
+    int any = 0;
+    for (int b : bad) any |= b;
+    *all_pm1 = any ? 0 : 1;
+    return RL_OK;
+}
+
 extern "C" int rl_slq_log_quadrature(const double* lanczos, int nrhs, int cap, const int* iters,
                                      const double* sqnorms, double* out, int nthreads) {
     if (!lanczos || !iters || !sqnorms || !out) return fail(RL_EINVAL, "rl_slq_log_quadrature: NULL argument");
@@ -5217,7 +5290,9 @@ extern "C" int rl_slq_log_quadrature(const double* lanczos, int nrhs, int cap, c
             for (int j = 0; j < k; ++j) d[j] = lz[2 * j];
             for (int j = 0; j + 1 < k; ++j) e[j] = lz[2 * j + 1];
             if (!slq_ql_first_row(d, e, z)) {
+                // (the caller's fallback takes this system: NaN marks it)
                 bad[v] = 1;
+                out[v] = std::nan("");
                 continue;
             }
             double acc = 0.0;
@@ -5234,8 +5309,6 @@ extern "C" int rl_slq_log_quadrature(const double* lanczos, int nrhs, int cap, c
         for (int t = 0; t < nt; ++t) pool.emplace_back(work, t, nt);
         for (std::thread& th : pool) th.join();
     }
-    for (int v = 0; v < nrhs; ++v)
-        if (bad[v]) return fail(RL_EHIP, "rl_slq_log_quadrature: an eigenvalue of a Lanczos tridiagonal did not converge");
     return RL_OK;
 }
 

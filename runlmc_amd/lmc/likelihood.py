@@ -138,6 +138,7 @@ class ApproxLMCLikelihood(LMCLikelihood):
         if dt:
             D = grid.D
             gop = _grad_operator(D, grid.m, len(dt), grid.device_index, sizes=grid.sizes)
+            gop.set_rank_hint(R)       # (derivative rows are no smoother than the rows themselves)
             gop.set_lmc(np.stack(dt), [None] * len(dt), [np.zeros(D)] * len(dt))
             for t in range(len(dt)):
                 r, C = gop.poly_coeffs(t)
@@ -204,6 +205,7 @@ class ApproxLMCLikelihood(LMCLikelihood):
                 blocks.append(Pc)
                 continue
             gop = _grad_operator(D, grid.m, nt, grid.device_index, sizes=grid.sizes)
+            gop.set_rank_hint(0)
             gop.set_lmc(np.stack(tops_t), [None] * nt, [np.zeros(D)] * nt)
             Ut = skiop.apply_wt(U, term)
             Vt = skiop.apply_wt(V, term)

@@ -6,8 +6,12 @@ reference's signature; ``pool`` is accepted and ignored (the solves are one
 batched device call), and an optional torch.distributed ``group`` shards the
 probes over GPUs.
 """
+import ctypes
+
 import numpy as np
 import torch
+
+from .. import _lib
 
 from .derivative import Derivative
 from ..approx.iterative import Iterative
@@ -42,6 +46,7 @@ class StochasticDerivService:
         self._scipy_exits = scipy_exits
         self._maxiter = int(maxiter)
         self._precondition = precondition
+        self._stage = None         # pinned host bytes of the narrowed probes (kept between steps)
 
     def draw_probes(self, n):
         """+-1 probes from NumPy's legacy global RNG exactly as the reference
@@ -104,27 +109,28 @@ class StochasticDerivService:
         if nm and on_device:
             Bfull[first:first + nm] = mine_rows.to(device=dev, dtype=torch.float64)
         elif nm:
-            # (signed integer kinds only: the values are checked BEFORE they are narrowed --
-            # 255 or 257 would wrap to -1 / +1 in one byte and pass a check made afterwards)
-            small = mine_rows.dtype.kind == 'i'
-            # (the two host passes over N x n entries run on all the host's cores whatever
-            # OMP_NUM_THREADS says -- the reference asks for 1, for NumPy's sake, and torch
-            # would then walk the 1 GB of C5's probes on one core: 110 ms of a 160 ms step)
-            threads = torch.get_num_threads()
-            try:
-                torch.set_num_threads(max(threads, min(_host_cores(), 32)))
-                if small:
-                    wide = torch.from_numpy(mine_rows)
-                    lo, hi = torch.aminmax(wide)
-                    small = int(lo) >= -1 and int(hi) <= 1
-                if small:
-                    narrow8 = wide.to(torch.int8)
-            finally:
-                torch.set_num_threads(threads)
-            if small:
-                narrow = narrow8.to(dev)
-                small = bool((narrow != 0).all())                 # (+-1 by contract; anything else:
-            if small:                                             # the plain way)
+            # +-1 probes as the reference draws them are an int64 matrix (1 GB at C5).  ONE
+            # pass over it on the host's cores (the library's helper: every entry checked to be
+            # +-1 BEFORE it is narrowed -- 255 or 257 would wrap to -1 / +1 in one byte) into a
+            # pinned staging buffer kept on the service, one byte per entry across the bus,
+            # widened on the device.  Anything else (another dtype, other values): the plain way.
+            narrow = None
+            if (mine_rows.dtype == np.int64 and mine_rows.ndim == 2 and mine_rows.strides[1] == 8
+                    and mine_rows.strides[0] % 8 == 0 and mine_rows.strides[0] > 0):
+                stage = self._stage
+                if stage is None or stage.numel() < nm * n:
+                    stage = torch.empty(nm * n, dtype=torch.int8)
+                    if dev.type == 'cuda':
+                        stage = stage.pin_memory()
+                    self._stage = stage
+                ok = ctypes.c_int()
+                lib = _lib.get_library()
+                lib.call('rl_probes_to_int8', ctypes.c_void_p(mine_rows.ctypes.data), nm,
+                         mine_rows.strides[0] // 8, n, ctypes.c_void_p(stage.data_ptr()),
+                         max(1, min(_host_cores(), 32)), ctypes.byref(ok))
+                if ok.value:
+                    narrow = stage[:nm * n].view(nm, n).to(dev, non_blocking=True)
+            if narrow is not None:
                 Bfull[first:first + nm] = narrow
             else:
                 Bfull[first:first + nm] = torch.from_numpy(

@@ -2362,3 +2362,40 @@ def check_small_batch_polynomial():
     toeps = [ops.BTTBOracle(tt) for tt in tops]
     _close(g.matmat_host(X), np.array([ops.grid_sum_matvec(Bs, toeps, v) for v in X]), rel=1e-11)
     return out
+
+
+def check_many_rhs_row_polynomial():
+    """More than 1024 systems on a row-polynomial operator (ADVICE, round 5): the expansion with
+    MINRES's P inside keeps 64 bytes of LDS per system, so past 1024 systems (64 KB) the solver
+    keeps P as its own kernel instead of failing the launch.  1100 systems, a few MINRES rounds,
+    against the same solve on the interpolation products (RUNLMC_NO_RP)."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import GridOp, SkiOp, solve_batch, MINRES
+    p = synth.make_problem(2, 1, 1, 2050, eps=1.0)
+    tops = synth.tops(p)
+    rng = np.random.RandomState(3)
+    B = rng.randint(0, 2, (1100, p.n)) * 2.0 - 1
+    knobs = ('RUNLMC_NO_RP',)
+    saved = {k: os.environ.pop(k, None) for k in knobs}
+    res = {}
+    try:
+        for mode, env in (('rp', {}), ('interp', {'RUNLMC_NO_RP': '1'})):
+            for k in knobs:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            g = GridOp(p.D, p.m, p.Q)
+            g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
+            s = SkiOp(g, p.W, p.WT)
+            s.set_noise(p.noise, p.lens)
+            X, it, rs, st = solve_batch(s, torch.from_numpy(B).to(s.device), MINRES, tol=1e-4,
+                                        maxiter=4)[:4]
+            res[mode] = (X.cpu().numpy(), it)
+            if mode == 'rp':
+                assert g.form()[0] > 0
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
+    assert np.all(res['rp'][1] == res['interp'][1])
+    _close(res['rp'][0], res['interp'][0], rel=1e-9)

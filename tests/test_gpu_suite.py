@@ -203,3 +203,7 @@ def test_direct_row_orders():
 
 def test_small_batch_polynomial():
     print(ps.check_small_batch_polynomial())
+
+
+def test_many_rhs_row_polynomial():
+    ps.check_many_rhs_row_polynomial()

@@ -32,7 +32,7 @@ for pdir in sorted(glob.glob(os.path.join(root, 'pass*'))):
 detail, total = {}, 0.0
 for name, c in tot.items():
     if not name.startswith(('k2_', 'k3_', 'k1_') if family == 'fft' else
-                           ('k_lr_project', 'k_lr_mix', 'k_lr_expand', 'k_sf_')):
+                           ('k_lr_project', 'k_lr_mix', 'k_lr_expand', 'k_lr_small', 'k_sf_')):
         continue
     # the product's launches only: the set-time verification also launches k_lr_* kernels
     # (a few dozen rows each) -- per-launch averages over ALL launches would be diluted,
@@ -43,7 +43,7 @@ for name, c in tot.items():
                     'launches_counted': cnt[name].get('FETCH_SIZE', 0)}
     total += rd + wr
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                        'profiles', 'r05', 'traffic.json')
+                        'profiles', os.environ.get('RL_PROFILE_ROUND', 'r05'), 'traffic.json')
 try:
     table = json.load(open(out_path))
 except (OSError, ValueError):
