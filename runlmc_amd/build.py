@@ -15,13 +15,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = [os.path.join(CSRC, 'runlmc_hip.hip')]
+# three translation units (rl_host.h holds what they share); runlmc_hip.hip includes all three
+# (experiment builds that need one code object)
+SOURCES = [os.path.join(CSRC, n) for n in ('rl_gridop.hip', 'rl_ski.hip', 'rl_solve.hip')]
+UNITY = os.path.join(CSRC, 'runlmc_hip.hip')
 import glob
 HEADERS = sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [
     os.path.join(ROOT, 'include', 'runlmc_hip.h')]
 HIP_LIB = os.path.join(CSRC, 'librunlmc_hip.so')
 EMU_DIR = os.path.join(ROOT, 'tests', 'emu')
 EMU_LIB = os.path.join(EMU_DIR, 'librunlmc_emu.so')
+OBJ_DIR = os.path.join(CSRC, 'build')
 
 
 def _stale(target, deps):
@@ -36,6 +40,13 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+def _compile_all(cmds):
+    """The translation units side by side (hipcc / g++ are single-threaded per file)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(cmds)) as pool:
+        list(pool.map(_run, cmds))
+
+
 def find_hipcc():
     for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and os.path.exists(cand):
@@ -43,15 +54,26 @@ def find_hipcc():
     raise RuntimeError('hipcc not found (need ROCm >= 7.0)')
 
 
-def build_hip(force=False, extra=()):
+def build_hip(force=False, extra=(), unity=False, out=None):
     """Compile the gfx950 shared library (cross-compiles without a GPU)."""
-    if not force and not _stale(HIP_LIB, SOURCES + HEADERS + [__file__]):
-        return HIP_LIB
-    cmd = [find_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17',
-           '-fPIC', '-shared', '-Wall', '-Wno-unused-function',
-           '-o', HIP_LIB] + list(extra) + SOURCES
-    _run(cmd)
-    return HIP_LIB
+    lib = out or HIP_LIB
+    if not force and not _stale(lib, SOURCES + HEADERS + [__file__]):
+        return lib
+    hipcc = find_hipcc()
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+    if unity:
+        _run([hipcc] + flags + ['-shared', '-o', lib] + list(extra) + [UNITY])
+        return lib
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = [os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + '.hip.o') for s in SOURCES]
+    # (per object: a file whose source and headers are older than its object is not recompiled --
+    # an edit of the solver costs one translation unit, not three)
+    todo = [(s, o) for s, o in zip(SOURCES, objs)
+            if force or extra or _stale(o, [s] + HEADERS + [__file__])]
+    if todo:
+        _compile_all([[hipcc] + flags + list(extra) + ['-c', s, '-o', o] for s, o in todo])
+    _run([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', lib] + objs)
+    return lib
 
 
 def build_emu(force=False, sanitize=False):
@@ -61,22 +83,28 @@ def build_emu(force=False, sanitize=False):
     lib = EMU_LIB.replace('.so', '_asan.so') if sanitize else EMU_LIB
     if not force and not _stale(lib, SOURCES + HEADERS + [emu_src, emu_hdr, __file__]):
         return lib
-    cmd = ['g++', '-O1' if sanitize else '-O2', '-g', '-std=c++17', '-fPIC',
-           '-shared', '-DRL_EMU', '-ffp-contract=off', '-I', EMU_DIR, '-pthread',
-           '-Wall', '-Wno-unused-function', '-Wno-unknown-pragmas', '-o', lib]
+    flags = ['-O1' if sanitize else '-O2', '-g', '-std=c++17', '-fPIC', '-DRL_EMU',
+             '-ffp-contract=off', '-I', EMU_DIR, '-pthread', '-Wall', '-Wno-unused-function',
+             '-Wno-unknown-pragmas']
     if sanitize:
-        cmd += ['-fsanitize=address,undefined', '-fno-omit-frame-pointer']
-    for s in SOURCES:
-        cmd += ['-x', 'c++', s]
-    cmd += ['-x', 'c++', emu_src]
-    _run(cmd)
+        flags += ['-fsanitize=address,undefined', '-fno-omit-frame-pointer']
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    tag = '.asan.o' if sanitize else '.emu.o'
+    srcs = SOURCES + [emu_src]
+    objs = [os.path.join(OBJ_DIR, os.path.basename(s).rsplit('.', 1)[0] + tag) for s in srcs]
+    todo = [(s, o) for s, o in zip(srcs, objs)
+            if force or _stale(o, [s] + HEADERS + [emu_hdr, __file__])]
+    if todo:
+        _compile_all([['g++'] + flags + ['-c', '-x', 'c++', s, '-o', o] for s, o in todo])
+    _run(['g++', '-shared', '-pthread', '-o', lib] + (['-fsanitize=address,undefined'] if sanitize else [])
+         + objs)
     return lib
 
 
 if __name__ == '__main__':
     if '--timing' in sys.argv:
-        # experiment build with in-kernel phase stamps (rl_device.h: RL_TIMING)
-        print(build_hip(force=True, extra=['-DRL_TIMING']))
+        # experiment build with in-kernel phase stamps (rl_device.h: RL_TIMING): one code object
+        print(build_hip(force=True, extra=['-DRL_TIMING'], unity=True))
     elif '--emu' in sys.argv:
         print(build_emu(force='--force' in sys.argv, sanitize='--asan' in sys.argv))
     else:

@@ -21,7 +21,7 @@
 // The reference's hook for exactly this is its preconditioner argument
 // (iterative.py:47-51: M = getattr(K, 'preconditioner', None)); with M = K~^-1 to roundoff
 // a preconditioned iteration is iterative refinement: x += M (b - K~ x) until the
-// reference's rule ||b - K~ x||_2 < tol holds (host loop: runlmc_hip.hip, rl_solve_direct).
+// reference's rule ||b - K~ x||_2 < tol holds (host loop: rl_solve.hip, rl_solve_direct).
 //
 // Scalings: the streaming kernels work with the UNNORMALISED polynomials q_j (Phi_j = nu_j
 // q_j), so the host folds nu and 1/eps into the map it uploads:
@@ -39,7 +39,7 @@
 // Zt is the map TRANSPOSED (it is symmetric; the layout only says that consecutive
 // threads read consecutive addresses).  A thread owns output coefficients e, e + 256, ...
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_dz_mix(const double* __restrict__ part, const int* __restrict__ run_ptr, int nvec, int D, int r,
          const double* __restrict__ Zt, double* __restrict__ zhat) {
     RL_SMEM(smem);
@@ -78,7 +78,7 @@ k_dz_mix(const double* __restrict__ part, const int* __restrict__ run_ptr, int n
 // k_dz_resid: R[v][i] = B[v][i] - R[v][i]  (R holds K~ x on entry), partial[v][blk] = the
 // block's sum of squares (fixed order).   grid (nblk, nrhs)   block 256
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_dz_resid(const double* __restrict__ B, double* __restrict__ R, int n,
            double* __restrict__ partial) {
     RL_SMEM(smem);
@@ -104,7 +104,7 @@ k_dz_resid(const double* __restrict__ B, double* __restrict__ R, int n,
 }
 
 // resid[v] = sqrt(sum of the system's partials)   grid (ceil(nrhs / 64))   block 64
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 k_dz_norms(const double* __restrict__ partial, int nblk, int nrhs, double* __restrict__ resid) {
     const int v = blockIdx.x * 64 + threadIdx.x;
     if (v >= nrhs) return;
@@ -117,7 +117,7 @@ k_dz_norms(const double* __restrict__ partial, int nblk, int nrhs, double* __res
 // k_dz_axpy: X[v] += T[v] for the systems still being refined (go[v] != 0).
 //   grid (nblk, nrhs)   block 256
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_dz_axpy(double* __restrict__ X, const double* __restrict__ T, int n,
           const int* __restrict__ go) {
     const int rhs = blockIdx.y;
@@ -134,7 +134,7 @@ k_dz_axpy(double* __restrict__ X, const double* __restrict__ T, int n,
 // Phi^T W^T x of a batch on the NORMALISED basis from k_rp_project's partial sums (ascending run
 // order).   grid (nvec)   block 256
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_dz_coeffs(const double* __restrict__ part, const int* __restrict__ run_ptr, int nvec, int D, int r,
             const double* __restrict__ nu, double* __restrict__ out) {
     const int v = blockIdx.x, Dr = D * r;
@@ -147,14 +147,3 @@ k_dz_coeffs(const double* __restrict__ part, const int* __restrict__ run_ptr, in
     }
 }
 
-// out[row][j] = nu_j sum_c part[c][row][j]: the same from k_lr_project's partial sums (grid
-// rows; rl_gridop_project).   grid (ceil(nrows r / 256))   block 256
-__global__ void __launch_bounds__(256)
-k_lr_coeffs(const double* __restrict__ part, int nchunks, int nrows, int r,
-            const double* __restrict__ nu, double* __restrict__ out) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, tot = (size_t)nrows * r;
-    if (e >= tot) return;
-    double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * tot + e];
-    out[e] = nu[e % r] * s;
-}

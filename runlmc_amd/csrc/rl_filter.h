@@ -45,7 +45,7 @@
 // transform kernels: 1e-13).
 //
 // WHICH tops take this form is decided on the host at set time, from the top row
-// itself (runlmc_hip.hip: sf_detect): the parameters are fitted from four
+// itself (rl_gridop.hip: sf_detect): the parameters are fitted from four
 // samples and the fit is accepted only if  sum_i |t_i - model_i| <= 2e-14 sum_i |t_i|
 // over the WHOLE row -- a bound on ||T - T_model||_1, hence on the product's
 // error for every input (no trial vectors involved).
@@ -276,7 +276,7 @@ __device__ __forceinline__ void sf_request_rows2(SfPair (&xa)[2][RB], SfPair (&x
         }
     }
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_sf_carries2(const double* __restrict__ X, int nrows, int m, int NF, const double* __restrict__ pwp,
               int rows_per_wg, double* __restrict__ E) {
     constexpr int RB = 4, NS = 2, NV = RB * 2 * NS, G = RL_SF_G, HG = G / 2;
@@ -968,7 +968,7 @@ __device__ __forceinline__ void sf_stage(const double (&xr)[XR], const double (&
 template <int NS, int D>        // (D at compile time: the row loops, the 2 D registers that
                                 // hold the next tile's rows and their predicates are static --
                                 // with a runtime D the kernel spilled 128 scalar registers)
-__global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
+static __global__ void __launch_bounds__(256) RL_SF_APPLY_ATTR
 k_sf_apply(const double* __restrict__ X, double* __restrict__ Y, int nvec, int m, int NF,
            int nfac, const double* __restrict__ blob, const double* __restrict__ Cin,
            int* __restrict__ next_tile) {

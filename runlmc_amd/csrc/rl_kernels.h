@@ -127,7 +127,7 @@ __device__ __forceinline__ void gather_row(const Gather& gs, int row, const doub
 //         k1 = freq1[r]
 // LDS: tile [N1][C] + twiddle table [N1]
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(RL_THREADS)
+static __global__ void __launch_bounds__(RL_THREADS)
 k_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode, cplx* __restrict__ T,
            int N1, int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1,
            const int* __restrict__ freq1, TwiddleL twl, Gather gs, int* __restrict__ bump) {
@@ -191,7 +191,7 @@ k_cols_fwd(const double* __restrict__ X, int nvec, int D, Geom geo, int mode, cp
 //   grid (N1 / R, npairs)   T [npairs][1][N1][N2]   spec [ntop][N1*N2]
 // LDS: tile [N2][CB] (CB = R | 1) + twiddle table [N2]
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(RL_THREADS)
+static __global__ void __launch_bounds__(RL_THREADS)
 k_rows_spec(const cplx* __restrict__ T, double* __restrict__ spec, int ntop, int N1, int N2,
             int R, FftPlan plan2, const cplx* __restrict__ tw2) {
     RL_SMEM(smem);
@@ -325,7 +325,7 @@ k_rows_mix(cplx* __restrict__ T, int N1, int N2, int R, FftPlan plan2,
 //   grid (ceil(ncols_needed / C), D, npairs)
 //   Y [nvec][D][m];  beta == 0: Y = result, else Y += result
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(RL_THREADS)
+static __global__ void __launch_bounds__(RL_THREADS)
 k_cols_inv(const cplx* __restrict__ T, double* __restrict__ Y, int nvec, int D, Geom geo, int N1,
            int N2, int C, FftPlan plan1, const cplx* __restrict__ tw1) {
     RL_SMEM(smem);
@@ -691,7 +691,7 @@ k_spmv_w_staged(const int* __restrict__ base, const double* __restrict__ w4, int
 // one cache line per 8 useful bytes); callers keep their own order.
 //   grid (ceil(n / RL_THREADS), nvec)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(RL_THREADS)
+static __global__ void __launch_bounds__(RL_THREADS)
 k_permute_rows(const double* __restrict__ X, double* __restrict__ Y,
                const int* __restrict__ perm, int n, int scatter) {
     // Sorting keeps every output's points together, so the random side of the

@@ -99,7 +99,7 @@ __device__ __forceinline__ void apply_twiddle_powers(cplx* v, const TwiddleSeed&
 // spectra (as loops over q and f with the spectrum loads inside, the mix was a
 // chain of Q + nfac dependent memory latencies plus Q D multiply-adds per
 // point: 6.9 of the row kernel's 21 us at C5, profiles/r02).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_mix_tables(MixParams mp, int D, int L, double* __restrict__ dc, double* __restrict__ gs) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= L) return;

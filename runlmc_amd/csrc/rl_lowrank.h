@@ -246,7 +246,7 @@ static inline size_t lr_mix_lds(int D, int r, int Q, int* split3) {
     *split3 = full <= 64 * 1024 ? 1 : 0;
     return *split3 ? full : (1 + q4) * dr * sizeof(double);
 }
-__global__ void __launch_bounds__(RL_LR_MIXT)
+static __global__ void __launch_bounds__(RL_LR_MIXT)
 k_lr_mix(const double* __restrict__ part, int nchunks, int nvec, int D, int r, int Q,
          const double* __restrict__ Cq, const double* __restrict__ Bq,
          const double* __restrict__ nu, double* __restrict__ Zhat,
@@ -806,4 +806,16 @@ k_spmv_w_poly(const int* __restrict__ base, const double* __restrict__ w4, int n
         }
         __syncthreads();
     }
+}
+
+// out[row][j] = nu_j sum_c part[c][row][j]: the coefficients Phi^T x of grid rows on the NORMALISED basis from
+// k_lr_project's partial sums (rl_gridop_project).   grid (ceil(nrows r / 256))   block 256
+static __global__ void __launch_bounds__(256)
+k_lr_coeffs(const double* __restrict__ part, int nchunks, int nrows, int r,
+            const double* __restrict__ nu, double* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, tot = (size_t)nrows * r;
+    if (e >= tot) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * tot + e];
+    out[e] = nu[e % r] * s;
 }

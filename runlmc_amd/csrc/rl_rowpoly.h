@@ -44,7 +44,7 @@
 // normalisation nu rides in k_lr_mix).  One thread per data row, four recurrences.
 //   grid (ceil(n / 256))   block 256
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_rp_build(const int* __restrict__ base, const double* __restrict__ w4, int n, int m, int R,
            const double* __restrict__ beta, double* __restrict__ F) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -106,7 +106,7 @@ struct RpRow {
 };
 
 // scatter of the interpolation entries into the caller's row order (rl_ski_mvm)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_rp_permute_entries(const int* __restrict__ base, const double* __restrict__ w4,
                      const int* __restrict__ perm, int n, int* __restrict__ base_c,
                      double* __restrict__ w4_c) {

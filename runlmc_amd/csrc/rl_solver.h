@@ -165,7 +165,7 @@ __device__ __forceinline__ void block_range(int n, int* lo, int* hi) {
 
 // ---- shared by both methods -------------------------------------------------
 // partial[rhs][blk] = sum_i a[i] * b[i]
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_dot_partial(const double* __restrict__ a, const double* __restrict__ b, int n,
               double* __restrict__ partial) {
     RL_SMEM(smem);
@@ -182,7 +182,7 @@ k_dot_partial(const double* __restrict__ a, const double* __restrict__ b, int n,
 }
 
 // partial[rhs][blk] = sum_i (b[i] - ax[i])^2
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_resid_partial(const double* __restrict__ b, const double* __restrict__ ax, int n,
                 double* __restrict__ partial) {
     RL_SMEM(smem);
@@ -202,7 +202,7 @@ k_resid_partial(const double* __restrict__ b, const double* __restrict__ ax, int
 }
 
 // one thread per rhs: residual norm from partials; optionally freeze
-__global__ void k_resid_finish(const double* __restrict__ partial, int nblk, int nrhs,
+static __global__ void k_resid_finish(const double* __restrict__ partial, int nblk, int nrhs,
                                double* __restrict__ resid, int* __restrict__ I, double tol,
                                int freeze) {
     const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,7 +216,7 @@ __global__ void k_resid_finish(const double* __restrict__ partial, int nblk, int
 }
 
 // *count = number of still-active right-hand sides
-__global__ void k_count_active(const int* __restrict__ I, int nrhs, int* __restrict__ count) {
+static __global__ void k_count_active(const int* __restrict__ I, int nrhs, int* __restrict__ count) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int c = 0;
         for (int r = 0; r < nrhs; ++r) c += I[r * I_NFIELDS + I_ACTIVE] ? 1 : 0;
@@ -248,7 +248,7 @@ struct MinresBufs {
 
 // init: x = 0, r1 = r2 = b, w = 0, v = b / beta1; partial = b.b comes from
 // k_dot_partial(b, b).
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
               MinresBufs mb) {
     const int rhs = blockIdx.y;
@@ -290,7 +290,7 @@ k_minres_init(const double* __restrict__ b, int n, const double* __restrict__ pa
 
 // step A (q = A v already computed): y = q - (beta/oldb) r1 (itn >= 2; y = q
 // on the first iteration); partialA = v . y
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres_a(MinresBufs mb, int n, double* __restrict__ partialA) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
@@ -318,7 +318,7 @@ k_minres_a(MinresBufs mb, int n, double* __restrict__ partialA) {
 }
 
 // step B: alfa = sum partialA; y -= (alfa/beta) r2; partialB = y . y
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres_b(MinresBufs mb, int n, const double* __restrict__ partialA,
            double* __restrict__ partialB) {
     RL_SMEM(smem);
@@ -348,7 +348,7 @@ k_minres_b(MinresBufs mb, int n, const double* __restrict__ partialA,
 // step C: scalar recurrences (every block recomputes them from the current
 // state copy, block 0 publishes to the other copy), new w over w_{k-2},
 // x += phi w, partialC = x . x, v <- y / beta_new.
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres_c(MinresBufs mb, int n, const double* __restrict__ partialA,
            const double* __restrict__ partialB, double* __restrict__ partialC) {
     RL_SMEM(smem);
@@ -442,7 +442,7 @@ k_minres_c(MinresBufs mb, int n, const double* __restrict__ partialA,
 // step D (ONE workgroup): ynorm from partialC, SciPy's stopping tests for every
 // system, then the global iteration counter advances (after every thread of
 // this single workgroup has read it).
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres_test(MinresBufs mb, const double* __restrict__ partialC, int nblk, int nrhs,
               double rtol, int maxiter) {
     const int it0 = *mb.giter;
@@ -635,7 +635,7 @@ __device__ __forceinline__ void block_reduce_rs(const double acc[RL_LR_RS], doub
 
 // projection partials of an arbitrary batch of data-space vectors (the first
 // round's y_0 = b):  part[rhs][blk][j] = sum_{i in block} y_i (W Phi~)[i, j]
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_poly_project_rows(const double* __restrict__ Yv, int n, Minres2Bufs mb) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
@@ -657,7 +657,7 @@ k_poly_project_rows(const double* __restrict__ Yv, int n, Minres2Bufs mb) {
 
 
 // init: x = 0, y_{-1} unused, y_0 = b, w = 0; partial = b.b from k_dot_partial(b, b)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
                Minres2Bufs mb) {
     const int rhs = blockIdx.y;
@@ -704,7 +704,7 @@ k_minres2_init(const double* __restrict__ b, int n, const double* __restrict__ p
 // against 1.56-1.63 ms, B 0.53 against 0.52-0.59 at C5.  Nine and three vector streams at
 // 5.6 TB/s: the kernels are at the rate HBM gives mixed reads and writes, not short of
 // loads in flight.)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_p(Minres2Bufs mb, int n, int par) {
     RL_STAMP(0);
     RL_SMEM(smem);
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ int minres_stop_test(const double* st, double ynorm, 
     return istop;
 }
 
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
     RL_STAMP(40);
     RL_SMEM(smem);
@@ -1314,7 +1314,7 @@ k_minres2_b(Minres2Bufs mb, int n, int par, double rtol, int maxiter) {
 // B's scalar head (Minres2Bufs::fuse_b): the stopping tests of iteration round - 1 and the
 // coefficient of  y_r = y' - (alfa_r / beta_r) y_{r-1};  the vector update itself and
 // ||y_r||^2 are the next round's projection (rl_rowpoly.h, RpFuse).   grid (nrhs)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_bh(Minres2Bufs mb, int nblk, int par, double rtol, int maxiter) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
@@ -1352,7 +1352,7 @@ k_minres2_bh(Minres2Bufs mb, int nblk, int par, double rtol, int maxiter) {
 // k_minres2_b's statements without its scalar head (every workgroup of B re-summed the
 // partial sums of its system: with one partial per W row block that is 2 x 3907 values).
 //   grid (nblk, nrhs)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_bv(Minres2Bufs mb, int n, int par) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
@@ -1395,7 +1395,7 @@ k_minres2_bv(Minres2Bufs mb, int n, int par) {
 // the new scalar state, the Lanczos record -- once per system instead of once per
 // workgroup, and the coefficients of the element work for the expansion (rl_rowpoly.h
 // RpPFuse, which lists pc's fields).  Statement by statement k_minres2_p's.   grid (nrhs)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_minres2_ph(Minres2Bufs mb, int par) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
@@ -1500,7 +1500,7 @@ k_minres2_ph(Minres2Bufs mb, int par) {
 
 // ---- CG ---------------------------------------------------------------------
 // init: x = 0, r = b, p = 0; partial = b.b
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_cg_init(const double* __restrict__ b, int n, const double* __restrict__ partial,
           double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
           double* __restrict__ S, int* __restrict__ I, double rtol) {
@@ -1530,7 +1530,7 @@ k_cg_init(const double* __restrict__ b, int n, const double* __restrict__ partia
 
 // loop head (one thread per rhs): rho = sum partial (r.r) unless first;
 // SciPy tests ||r|| < atol BEFORE the update; maxiter exhaustion
-__global__ void k_cg_head(double* __restrict__ S, int* __restrict__ I,
+static __global__ void k_cg_head(double* __restrict__ S, int* __restrict__ I,
                           const double* __restrict__ partialR, int nblk, int nrhs, int first,
                           int maxiter) {
     const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1552,7 +1552,7 @@ __global__ void k_cg_head(double* __restrict__ S, int* __restrict__ I,
 }
 
 // p = r + (rho/rho_prev) p   (p = r on the first iteration)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_cg_p(double* __restrict__ p, const double* __restrict__ r, int n,
        const double* __restrict__ S, const int* __restrict__ I) {
     const int rhs = blockIdx.y;
@@ -1568,7 +1568,7 @@ k_cg_p(double* __restrict__ p, const double* __restrict__ r, int n,
 }
 
 // alpha = rho / sum partialPQ; x += alpha p; r -= alpha q; partialR = r.r
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_cg_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
             const double* __restrict__ q, int n, const double* __restrict__ S,
             int* __restrict__ I, const double* __restrict__ partialPQ,
@@ -1595,7 +1595,7 @@ k_cg_update(double* __restrict__ x, double* __restrict__ r, const double* __rest
 }
 
 // bump iteration counters of active systems (callback count in the reference)
-__global__ void k_count_iter(int* __restrict__ I, int nrhs) {
+static __global__ void k_count_iter(int* __restrict__ I, int nrhs) {
     const int rhs = blockIdx.x * blockDim.x + threadIdx.x;
     if (rhs >= nrhs) return;
     if (I[rhs * I_NFIELDS + I_ACTIVE]) I[rhs * I_NFIELDS + I_ITN] += 1;
@@ -1604,7 +1604,7 @@ __global__ void k_count_iter(int* __restrict__ I, int nrhs) {
 // ---- gradient partial sums --------------------------------------------------
 // out[v][a][b] = sum_i U[v][a*m + i] * V[v][b*m + i]   (D x D Gram per vector)
 //   grid (D*D, nvec)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_cross_dots(const double* __restrict__ U, const double* __restrict__ V, int D, int m,
              double* __restrict__ out) {
     RL_SMEM(smem);
@@ -1625,7 +1625,7 @@ k_cross_dots(const double* __restrict__ U, const double* __restrict__ V, int D, 
 //   grid (ceil(D / 4) * ceil(D / 8), nvec)
 #define RL_XD_A 4
 #define RL_XD_B 8
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_cross_dots_tiled(const double* __restrict__ U, const double* __restrict__ V, int D, int m,
                    double* __restrict__ out) {
     RL_SMEM(smem);
@@ -1664,7 +1664,7 @@ k_cross_dots_tiled(const double* __restrict__ U, const double* __restrict__ V, i
 
 // out[v][d] = sum_{i in segment d} U[v][i] * V[v][i];  segments given by
 // offsets[D+1] (per-output slices of a data-space vector)   grid (D, nvec)
-__global__ void __launch_bounds__(RL_SOLVER_THREADS)
+static __global__ void __launch_bounds__(RL_SOLVER_THREADS)
 k_segment_dots(const double* __restrict__ U, const double* __restrict__ V,
                const int* __restrict__ offsets, int n, int D, double* __restrict__ out) {
     RL_SMEM(smem);

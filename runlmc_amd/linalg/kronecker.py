@@ -22,7 +22,7 @@ def _is_lmc_term(K):
 def fuse_kronecker_sum(terms):
     """One GridOp for sum_q B_q (x) T_q, or None if `terms` is not of that
     form (symmetric dense B_q of one size, 1-D BTTB of one size; any D -- above 16
-    outputs the handle is the 'wide' operator of csrc/runlmc_hip.hip)."""
+    outputs the handle is the 'wide' operator of csrc/rl_gridop.hip)."""
     if not all(_is_lmc_term(K) for K in terms):
         return None
     D = terms[0].A.shape[0]

@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # The tests force kernel paths through the library's A/B hooks (RUNLMC_NO_RP, RUNLMC_STAGED_WT,
-# ...), which the library reads only under this switch (runlmc_hip.hip: read_knobs).  Child
+# ...), which the library reads only under this switch (csrc/rl_gridop.hip: read_knobs).  Child
 # processes (multi-rank tests, the C ABI demo) inherit it.
 os.environ.setdefault('RUNLMC_DEBUG', '1')
 if ROOT not in sys.path:

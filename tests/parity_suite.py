@@ -899,7 +899,7 @@ def check_polynomial_form():
 
 def _verification_trial_vector(n):
     """The fixed trial vector of the polynomial form's set-time verification
-    (runlmc_hip.hip: lr_verify -- a 64-bit LCG, entries in [-1, 1))."""
+    (csrc/rl_gridop.hip: lr_verify -- a 64-bit LCG, entries in [-1, 1))."""
     st, mask = 0x9E3779B97F4A7C15, (1 << 64) - 1
     x = np.empty(n)
     for i in range(n):

@@ -1,5 +1,5 @@
 #!/bin/bash
-export RUNLMC_DEBUG=1   # the switches below are debug hooks (runlmc_hip.hip: read_knobs)
+export RUNLMC_DEBUG=1   # the switches below are debug hooks (csrc/rl_gridop.hip: read_knobs)
 # GPU box: HBM-side bytes of the transform kernels at C2, 1024 vectors, old order vs pair-affine
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04; mkdir -p $O
 cd $R

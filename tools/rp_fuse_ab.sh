@@ -1,5 +1,5 @@
 #!/bin/bash
-export RUNLMC_DEBUG=1   # the switches below are debug hooks (runlmc_hip.hip: read_knobs)
+export RUNLMC_DEBUG=1   # the switches below are debug hooks (csrc/rl_gridop.hip: read_knobs)
 # GPU box: MINRES's B inside the row-polynomial projection against B as its own kernel
 # (RUNLMC_NO_RP_FUSE=1), same box: round timelines (tools/r04_rounds.sh) and the NLL + gradient step
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04; mkdir -p $O   # (run as: bash tools/rp_fuse_ab.sh 2>&1 | tee gpurun_out/rp_fuse_ab.txt)
