@@ -88,6 +88,75 @@ def test_two_rank_probe_sharding():
     assert np.abs(got[0][1] - ref).max() < 1e-4 * scale
 
 
+def _grads_smooth(world_group=None):
+    """The step on the golden case whose top rows are all smooth: solves through the operator's
+    factorisation (csrc/rl_direct.h), Gram terms in coefficient space, exact log det."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import parity_suite as ps
+    from cases import Case
+    from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+    from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
+    c = Case('lmc_smooth')
+    fk, K, gk = ps.build_operator(c)
+    ad = (0,)
+    svc = StochasticDerivService(None, None, len(c.rs), 1e-9, group=world_group)
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)},
+                              c.Ys, svc, probes=c.rs)
+    assert lik.deriv.logdet_exact is not None          # the direct path answered
+    flat = np.concatenate([np.ravel(g) for g in lik.coreg_vec_gradients()] +
+                          [np.ravel(g) for g in lik.coreg_diags_gradients()] +
+                          [np.ravel(g) for g in lik.kernel_gradients()] +
+                          [lik.noise_gradient()])
+    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy(), lik.log_likelihood(), c
+
+
+def _worker_smooth(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.EMU_LIB)
+    flat, nloc, alpha, ll, _ = _grads_smooth()
+    q.put((rank, flat, nloc, alpha, ll))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_direct_path():
+    """Probe sharding when the solves go through the operator's factorisation (round 6): every
+    rank factors its replica, solves alpha and its share of the probes, rank 0's alpha is
+    broadcast, ONE all-reduce carries the Gram terms -- the same bits on both ranks, the
+    one-rank step's gradient to 1e-9 (the solves are converged: no solver-level noise), the
+    reference's dense values (golden lmc_smooth) to 1e-8, the same exact log likelihood."""
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.build_emu())
+    try:
+        ref, nall, alpha_ref, ll_ref, c = _grads_smooth()
+    finally:
+        _lib.use_library(None)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_smooth, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert got[0][2] + got[1][2] == nall
+    assert np.array_equal(got[0][3], got[1][3])            # alpha: rank 0's, broadcast
+    assert np.array_equal(got[0][1], got[1][1])            # the assembled gradient
+    assert got[0][4] == got[1][4]
+    scale = np.abs(ref).max()
+    assert np.abs(got[0][1] - ref).max() < 1e-9 * scale
+    assert np.abs(got[0][3] - c.g['alpha_dense']).max() < 1e-8 * np.abs(c.g['alpha_dense']).max()
+    assert abs(got[0][4] - ll_ref) <= 1e-12 * abs(ll_ref)
+
+
 def _grads_n(n_probes):
     """The step on `lmc_small` with a seeded matrix of n_probes probes (every rank draws the
     same matrix and keeps its own rows: rank, rank + world, ...)."""
