@@ -260,7 +260,9 @@ int rl_probes_to_int8(const long long* src, int nrows, long long row_stride, lon
  * the polynomial form whatever the batch gate).  *available = 0 when the operator has
  * no such form (a top row on the transform or filter kernels, several grids, a 2-D
  * grid, D > 16, noise not constant per output, an output with fewer rows than the
- * basis) -- rl_last_error() then says which; that is not an error.  *logdet receives
+ * basis, D r > 576 on a system of fewer than 10^5 (D r / 576)^3 rows: there the host's
+ * ~1.5 (D r)^3 multiply-adds cost more than the Krylov solve) -- rl_last_error() then says
+ * which; that is not an error.  *logdet receives
  * log det K~ of the handle's operator -- the quantity the reference computes by a dense
  * Cholesky (models/interpolated_llgp.py:262-276) -- and *cond an estimate of the condition
  * number of the D r x D r system (squared ratio of its Cholesky pivots).  Any pointer may

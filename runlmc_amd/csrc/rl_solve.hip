@@ -889,6 +889,15 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     const int R = g->lr_r, D = g->D, n = s->n, Dr = D * R, Q = g->Q;
     if (s->dz_valid && s->dz_param_ver == g->param_ver && s->dz_noise_ver == s->noise_ver && s->dz_R == R)
         return RL_OK;
+    // The host's part is ~1.5 (D r)^3 multiply-adds per parameter update (2.5 ms at D r = 240, 8 ms at
+    // 360, ~0.1 s at 768): past D r = 576 a SMALL system's Krylov solve is cheaper than its
+    // factorisation (a round of a 10^4-row system is 20 us), so such operators keep the Krylov path
+    if (Dr > 576 && (double)n < 1e5 * ((double)Dr / 576.0) * ((double)Dr / 576.0) * ((double)Dr / 576.0)) {
+        s->dz_valid = false;
+        *ok = false;
+        *why = "D * rank is large for this few rows: the factorisation would cost more than the Krylov solve";
+        return RL_OK;
+    }
     s->dz_valid = false;
     *ok = false;
     hipStream_t st = nullptr;

@@ -34,7 +34,7 @@ class StochasticDerivService:
     LANCZOS_MAX = 4096
 
     def __init__(self, metrics, pool, n_it, tol, group=None, scipy_exits=None, maxiter=0,
-                 precondition=None):
+                 precondition=None, device_probes=None):
         # (the first four arguments are the reference's; scipy_exits / maxiter / precondition go
         # to Iterative.solve_device unchanged: None = Iterative.SCIPY_EXITS, 0 = n iterations,
         # None = Iterative.PRECONDITION)
@@ -46,6 +46,13 @@ class StochasticDerivService:
         self._scipy_exits = scipy_exits
         self._maxiter = int(maxiter)
         self._precondition = precondition
+        # device_probes: None -- probes come from NumPy's global legacy RNG exactly as the
+        # reference draws them (stochastic_deriv.py:35; 0.6 s of host time for C5's 128 x 10^6
+        # int64 matrix, twenty times the step that uses them); an int -- a seed: every call of
+        # generate() without explicit probes draws them ON the device (torch's generator, seed +
+        # call count, the same on every rank): the same estimator, another stream of draws
+        self._device_probes = device_probes
+        self._draws = 0
         self._stage = None         # pinned host bytes of the narrowed probes (kept between steps)
 
     def draw_probes(self, n):
@@ -67,6 +74,9 @@ class StochasticDerivService:
         """Solve K alpha = y and K s_i = r_i for this rank's probes.  `rs`
         (n_it x n, entries +-1) may be passed explicitly (parity tests)."""
         n = K.shape[0]
+        if rs is None and self._device_probes is not None:
+            rs = self.draw_probes_device(n, K.device, seed=int(self._device_probes) + self._draws)
+            self._draws += 1
         if rs is None:
             rs = self.draw_probes(n)
         # (a torch tensor on the operator's device is taken as it is -- +-1 entries of any

@@ -59,7 +59,7 @@ class InterpolatedLLGP:
     def __init__(self, Xs, Ys, normalize=True, lo=None, hi=None, m=None,
                  name='lmc', metrics=False, prediction='on-the-fly',
                  max_procs=None, trace_iterations=15, tolerance=1e-4,
-                 functional_kernel=None, group=None, device_index=0):
+                 functional_kernel=None, group=None, device_index=0, device_probes=None):
         self.name = name
         self.input_dim, self.output_dim = self._validate_io(Xs, Ys)
         self.normalizer = None
@@ -88,8 +88,11 @@ class InterpolatedLLGP:
         self._generate_grids(lo, hi, m)
         self.metrics = Metrics() if metrics else None
         self._device_index = device_index
+        # (device_probes: a seed -- the Hutchinson probes are drawn on the device instead of by
+        # NumPy's global RNG, StochasticDerivService; None keeps the reference's stream)
         self._deriv_service = StochasticDerivService(
-            self.metrics, None, trace_iterations, tolerance, group=group)
+            self.metrics, None, trace_iterations, tolerance, group=group,
+            device_probes=device_probes)
         self._K = None
         self._grid_kernels = None
         self._caches = {}

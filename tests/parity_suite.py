@@ -2399,3 +2399,106 @@ def check_many_rhs_row_polynomial():
                 os.environ[k] = saved[k]
     assert np.all(res['rp'][1] == res['interp'][1])
     _close(res['rp'][0], res['interp'][0], rel=1e-9)
+
+
+def check_round6_abi_errors():
+    """Argument and state errors of the round-6 entry points (RL_EINVAL -> ValueError, RL_ELIMIT ->
+    NotImplementedError), and the host helpers against NumPy."""
+    import ctypes
+    from runlmc_amd import _lib
+    from runlmc_amd._lib import host_ptr, dev_ptr
+    from runlmc_amd._native import GridOp, SkiOp
+    from runlmc_amd.util import synth
+    lib = _lib.get_library()
+    p = synth.make_problem(2, 1, 1, 300, kern='rbf')
+    tops = synth.tops(p)
+    g = GridOp(p.D, p.m, p.Q)
+    g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
+    s = SkiOp(g, p.W, p.WT)
+    # no noise yet: the factorisation says so, the solve refuses
+    ok, _, _ = s.factor()
+    assert not ok and 'noise' in s.factor_reason
+    s.set_noise(p.noise, p.lens)
+    ok, ld, cond = s.factor()
+    assert ok and np.isfinite(ld) and cond >= 1.0
+    rank = g.form()[0]
+    # rl_gridop_poly_coeffs
+    r, C = g.poly_coeffs(0)
+    assert r == rank and C.shape == (rank, rank) and np.array_equal(C, C.T)
+    rr = ctypes.c_int()
+    for call in (lambda: lib.call('rl_gridop_poly_coeffs', g.handle, 5, None, 0, ctypes.byref(rr)),
+                 lambda: lib.call('rl_gridop_poly_coeffs', g.handle, 0, host_ptr(np.zeros(4)), 4,
+                                  ctypes.byref(rr)),
+                 lambda: lib.call('rl_gridop_set_rank_hint', g.handle, 25),
+                 lambda: g.project(torch.zeros(1, p.D * p.m, dtype=torch.float64, device=g.device), 30)):
+        try:
+            call()
+            raise AssertionError('accepted a bad argument')
+        except ValueError:
+            pass
+    # C_q really is Phi^T T Phi: the form's product of a vector in the subspace
+    x = torch.randn(3, p.n, dtype=torch.float64).to(s.device)
+    cx = s.project(x)                                   # (3, D, r)
+    assert cx.shape == (3, p.D, rank)
+    gx = s.apply_wt(x)
+    cg = g.project(gx, rank)
+    _close(cx.cpu().numpy(), cg.cpu().numpy(), rel=1e-11)
+    if rank < 48:
+        c48 = g.project(gx, 48)                          # nested basis: the leading block agrees
+        _close(c48[:, :, :rank].cpu().numpy(), cg.cpu().numpy(), rel=1e-11)
+    quad = torch.einsum('vai,ij,vaj->va', cx, torch.from_numpy(C).to(s.device), cx).cpu().numpy()
+    Tg = g.mvm(gx, top=0)
+    ref = (gx.view(3, p.D, p.m) * Tg.view(3, p.D, p.m)).sum(dim=2).cpu().numpy()
+    _close(quad, ref, rel=1e-10)
+    # rl_probes_to_int8: strided rows, bad values
+    rs = np.random.RandomState(0).randint(0, 2, (6, 1000)).astype(np.int64) * 2 - 1
+    view = rs[1::2]
+    out = np.zeros((3, 1000), dtype=np.int8)
+    okf = ctypes.c_int()
+    lib.call('rl_probes_to_int8', ctypes.c_void_p(view.ctypes.data), 3, view.strides[0] // 8, 1000,
+             host_ptr(out), 4, ctypes.byref(okf))
+    assert okf.value == 1 and np.array_equal(out, view.astype(np.int8))
+    bad = rs.copy()
+    bad[3, 77] = 257                                     # would wrap to +1 in one byte
+    out6 = np.zeros((6, 1000), dtype=np.int8)            # (kept alive across the call)
+    lib.call('rl_probes_to_int8', ctypes.c_void_p(bad.ctypes.data), 6, 1000, 1000,
+             host_ptr(out6), 4, ctypes.byref(okf))
+    assert okf.value == 0
+    # rl_slq_log_quadrature on a known tridiagonal: e_1^T log(T) e_1 by dense eigenpairs
+    k = 40
+    rng = np.random.RandomState(1)
+    d, e = 2.0 + rng.rand(k), 0.3 * rng.rand(k - 1)
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    w, V = np.linalg.eigh(T)
+    exact = 7.0 * np.sum(V[0] ** 2 * np.log(w))
+    lz = np.zeros((1, 64, 2))
+    lz[0, :k, 0] = d
+    lz[0, :k - 1, 1] = e
+    from runlmc_amd._native import slq_quadratic_forms
+    got = slq_quadratic_forms(lz, np.array([k]), np.array([7.0]))
+    assert abs(got[0] - exact) <= 1e-12 * abs(exact), (got, exact)
+
+
+def check_device_probes():
+    """StochasticDerivService(device_probes=seed): probes drawn on the device are +-1 int8, the
+    same matrix for the same (seed, call), another one at the next call; a step with them gives
+    the gradient the same probes give when handed over as a host int64 matrix."""
+    c = Case('lmc_small')
+    fk, K, gk = build_operator(c)
+    ad = c.ad
+    svc = StochasticDerivService(None, None, 6, 1e-6, device_probes=123)
+    p0 = svc.draw_probes_device(c.n, K.device, seed=123)
+    assert p0.dtype == torch.int8 and p0.shape == (6, c.n) and bool((p0.abs() == 1).all())
+    assert torch.equal(p0, svc.draw_probes_device(c.n, K.device, seed=123))
+    assert not torch.equal(p0, svc.draw_probes_device(c.n, K.device, seed=124))
+    lik = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)}, c.Ys, svc)
+    assert torch.equal(lik.deriv.rs_dev.to(torch.int8), p0)          # first call: seed + 0
+    g_dev = lik.noise_gradient()
+    svc2 = StochasticDerivService(None, None, 6, 1e-6)
+    lik2 = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)}, c.Ys, svc2,
+                               probes=p0.cpu().numpy().astype(np.int64))
+    assert np.array_equal(g_dev, lik2.noise_gradient())
+    for a, b in zip(lik.coreg_vec_gradients(), lik2.coreg_vec_gradients()):
+        assert np.array_equal(a, b)
+    lik3 = ApproxLMCLikelihood(fk, K, {ad: c.grid_dists}, {ad: (c.W, c.WT)}, c.Ys, svc)
+    assert not torch.equal(lik3.deriv.rs_dev.to(torch.int8), p0)      # second call: seed + 1

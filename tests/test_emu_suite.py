@@ -225,3 +225,11 @@ def test_direct_row_orders():
 
 def test_small_batch_polynomial():
     print(ps.check_small_batch_polynomial())
+
+
+def test_round6_abi_errors():
+    ps.check_round6_abi_errors()
+
+
+def test_device_probes():
+    ps.check_device_probes()

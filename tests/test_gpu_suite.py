@@ -207,3 +207,11 @@ def test_small_batch_polynomial():
 
 def test_many_rhs_row_polynomial():
     ps.check_many_rhs_row_polynomial()
+
+
+def test_round6_abi_errors():
+    ps.check_round6_abi_errors()
+
+
+def test_device_probes():
+    ps.check_device_probes()
