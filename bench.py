@@ -458,8 +458,14 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
              lik.kernel_gradients(), lik.noise_gradient())
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        logdet = lik.log_det_K()
-        ll = lik.log_likelihood()
+        try:
+            logdet = lik.log_det_K()
+            ll = lik.log_likelihood()
+        except ValueError:
+            # (solves preconditioned by an INEXACT factorisation -- conjugate gradients, the Matern
+            # and mix families: no Lanczos recurrence of K~ ran and the factorisation's log det is
+            # not the operator's; the Krylov entry beside this one carries the quadrature)
+            logdet = ll = float('nan')
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if info is None:
@@ -468,6 +474,7 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
         if best is None or el < best:
             best = el
             direct = lik.deriv.logdet_exact is not None
+            pcg = (not direct) and lik.deriv.lanczos is None
             info = dict(iterations_mean=float(np.mean(lik.deriv.iterations)),
                         iterations_max=int(np.max(lik.deriv.iterations)),
                         residual_max=float(np.max(lik.deriv.residuals)),
@@ -477,17 +484,22 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
                         solver=('direct: K~ = F M F^T + E through the Woodbury identity + '
                                 'refinement to the reference\'s residual rule (csrc/rl_direct.h); '
                                 'iterations = applications of K~^-1') if direct else
+                               ('pcg: conjugate gradients preconditioned by the Woodbury inverse of the '
+                                'operator\'s projection on the polynomial subspace (rl_solve_pcg; the '
+                                'reference\'s M of iterative.py:47-51), ended by the reference\'s residual rule')
+                               if pcg else
                                ('krylov: batched MINRES, ' +
                                 ('SciPy 1.15 exits' if scipy_exits else 'reference residual rule only')),
                         nll=float(-ll), logdet=float(logdet),
                         logdet_kind=('exact: determinant lemma on the factorisation' if direct else
+                                     'none on this path (see nll_grad_krylov)' if pcg else
                                      'stochastic Lanczos quadrature from the probe solves'),
                         grad_norm=float(np.linalg.norm(flat_gradient(g))),
                         # a few entries, so that runs can be compared with each other
                         grad_sample=[float(v) for v in np.concatenate(
                             [np.ravel(g[3]), np.ravel(g[1][0]), np.ravel(g[0][0])])[:12]])
             info['seconds_loglik'] = el - (t1 - t0)
-            if not direct:
+            if not direct and not pcg:
                 est = lik.deriv.logdet_probe_estimates()
                 if len(est) > 1:
                     info['logdet_sem'] = float(est.std(ddof=1) / np.sqrt(len(est)))
@@ -750,7 +762,7 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
                         probes_per_rank=-(-n_probes // world),
                         probes='int64 host matrix as the reference draws it, checked and '
                                'narrowed inside the timed step')
-            direct = info['solver'].startswith('direct')
+            direct = info['solver'].startswith(('direct', 'pcg'))
             if world > 1 and key == 'nll_grad':
                 # the SAME step on one rank alone (every rank runs it, no collective): what the
                 # probe sharding of this run is a speed-up of (reference axis:
@@ -804,8 +816,9 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
                        gradient_rel_distance_to_default_step=rel_dist(grad_kry, grad_default),
                        logdet_exact=info['logdet'],
                        logdet_slq_minus_exact=(kry['logdet'] - info['logdet']
-                                               if kry['logdet'] is not None else None))
-            if kry.get('logdet_sem') and kry['logdet'] is not None:
+                                               if kry['logdet'] is not None and info['logdet'] is not None
+                                               else None))
+            if kry.get('logdet_sem') and kry['logdet'] is not None and info['logdet'] is not None:
                 kry['logdet_slq_minus_exact_in_sem'] = (kry['logdet'] - info['logdet']) / kry['logdet_sem']
             if world == 1 and n_probes >= 16 and not args.no_extra:
                 share = n_probes // 8

@@ -37,7 +37,7 @@ typedef struct rl_ski rl_ski;
 
 /* Version of this ABI: bumped whenever a declared signature changes (2: rl_solve_batch_lanczos
  * gained `method`, round 4; 3: rl_gridop_form_stats added, round 5; 4: rl_ski_factor,
- * rl_solve_direct, rl_ski_project,
+ * rl_solve_direct, rl_solve_pcg, rl_ski_project,
  * rl_gridop_project, rl_gridop_set_rank_hint, rl_gridop_poly_coeffs, rl_slq_log_quadrature,
  * rl_probes_to_int8 added, round 6; callers built against an older version must be rebuilt).  A binding
  * compares rl_abi_version() with the RL_ABI_VERSION it was written against before its
@@ -268,6 +268,20 @@ int rl_probes_to_int8(const long long* src, int nrows, long long row_stride, lon
  * number of the D r x D r system (squared ratio of its Cholesky pivots).  Any pointer may
  * be NULL.                                                                              */
 int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond);
+/* *available = 2: NOT every top row is in the polynomial form (a Matern row, say, on the filter
+ * kernels), but the polynomial subspace still holds at least 0.8 of every row's spectrum: the
+ * factorisation then inverts the operator's PROJECTION on the subspace,  F M_r F^T + E  with
+ * C_q = Phi^T T_q Phi of every row -- not K~^-1 (no log det), but the symmetric positive definite
+ * M of the reference's  sla.cg(op, y, M=M)  (iterative.py:47-51).  rl_solve_pcg runs SciPy's
+ * statements of preconditioned conjugate gradients with it, all systems in lockstep, each ended
+ * by the reference's rule ||b - K~ x||_2 < tol (the recurrence's residual norm every iteration,
+ * the explicit residual before a system is let go), at most maxiter iterations (<= 0: n).
+ * BASELINE's 'mix' family (four smooth rows and a Matern row) ends in 4-5 iterations where
+ * MINRES runs 590 without meeting the rule; Matern rows alone take ~100.  Also valid with
+ * *available = 1 (then M is K~^-1 and one iteration suffices: rl_solve_direct is the shorter way).
+ *   iters_out / resid_out / istop_out as rl_solve_direct (istop 6: maxiter reached).       */
+int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
+                 int* iters_out, double* resid_out, int* istop_out, void* stream);
 /* The pieces of that form, for callers that work in its coefficient space (the gradient's
  * Gram terms: with T = Phi C Phi^T,  u~_a . T v~_b = c_u[a]^T C c_v[b],  c_u = Phi^T W^T u
  * -- runlmc_amd/lmc/likelihood.py; reference loops: lmc/likelihood.py:48-96):

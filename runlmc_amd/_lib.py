@@ -61,6 +61,7 @@ _SIGNATURES = {
     'rl_gridop_project': [_vp, _vp, _i, _i, _vp, _vp],
     'rl_gridop_set_rank_hint': [_vp, _i],
     'rl_solve_direct': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp],
+    'rl_solve_pcg': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp],
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 }

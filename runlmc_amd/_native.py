@@ -277,6 +277,9 @@ class SkiOp:
                       ctypes.byref(cond))
         self.factor_reason = ('' if av.value else
                               self.lib.cdll.rl_last_error().decode())
+        # 1: the factorisation is K~^-1 (every top row in the polynomial form); 2: it inverts the
+        # operator's projection on the polynomial subspace -- a preconditioner (solve_pcg)
+        self.factor_mode = int(av.value)
         return bool(av.value), float(ld.value), float(cond.value)
 
     def project(self, X):
@@ -362,6 +365,22 @@ def solve_direct(ski, B, tol=1e-4, max_refine=4):
     ski.lib.call('rl_solve_direct', ski.handle, dev_ptr(B), dev_ptr(X), k, float(tol),
                  int(max_refine), host_ptr(iters), host_ptr(resid), host_ptr(istop),
                  ski.lib.stream_ptr(ski.device))
+    return X, iters, resid, istop
+
+
+def solve_pcg(ski, B, tol=1e-4, maxiter=0):
+    """Device batched solve K~ X = B by conjugate gradients preconditioned with the Woodbury
+    inverse of the operator's projection on the polynomial subspace (include/runlmc_hip.h:
+    rl_solve_pcg).  Returns (X, iterations, residuals, istop)."""
+    k = B.shape[0]
+    X = torch.empty_like(B)
+    iters = np.zeros(k, dtype=np.int32)
+    istop = np.zeros(k, dtype=np.int32)
+    resid = np.zeros(k, dtype=np.float64)
+    if k == 0:
+        return X, iters, resid, istop
+    ski.lib.call('rl_solve_pcg', ski.handle, dev_ptr(B), dev_ptr(X), k, float(tol), int(maxiter),
+                 host_ptr(iters), host_ptr(resid), host_ptr(istop), ski.lib.stream_ptr(ski.device))
     return X, iters, resid, istop
 
 

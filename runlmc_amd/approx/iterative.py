@@ -60,7 +60,7 @@ class Iterative:
         if precondition:
             M = getattr(K, 'preconditioner', None)          # reference iterative.py:47
             if M is not None:
-                out = M.solve(B.contiguous(), tol=tol)
+                out = M.solve(B.contiguous(), tol=tol, maxiter=maxiter)
                 return out + (None,) if lanczos_cap > 0 else out
         if scipy_exits is None:
             scipy_exits = Iterative.SCIPY_EXITS

@@ -147,3 +147,68 @@ k_dz_coeffs(const double* __restrict__ part, const int* __restrict__ run_ptr, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// Preconditioned conjugate gradients with M = (F M_r F^T + E)^-1, the Woodbury inverse of the
+// operator's projection on the polynomial subspace (round 6): for operators that are NOT wholly
+// in the polynomial form (a Matern row next to smooth ones, Matern rows alone) the factorisation
+// of rl_solve.hip is no longer K~^-1 but still the reference's preconditioner argument
+// (approx/iterative.py:47-51, sla.cg(op, y, M=M)): SciPy's statements of preconditioned CG --
+//   z = M r;  rho = r.z;  p = z + (rho / rho_prev) p;  q = K~ p;  alpha = rho / p.q;
+//   x += alpha p;  r -= alpha q
+// -- all systems in lockstep, each with its own scalars scal[v] = (rho, rho_prev); go[v] = 0
+// freezes a system that met the reference's residual rule.  Dot products: k_dot_partial
+// (rl_solver.h) into per-block partial sums, summed in a fixed order here.
+//   grid (nblk, nrhs) block 256 for the vector kernels; k_pcg_head: grid (ceil(nrhs / 64)) block 64
+// ---------------------------------------------------------------------------
+static __global__ void __launch_bounds__(64)
+k_pcg_head(const double* __restrict__ partRZ, int nblk, int nrhs, double* __restrict__ scal,
+           const int* __restrict__ go) {
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= nrhs || !go[v]) return;
+    double s = 0.0;
+    for (int c = 0; c < nblk; ++c) s += partRZ[(size_t)v * nblk + c];
+    scal[2 * v + 1] = scal[2 * v];
+    scal[2 * v] = s;
+}
+static __global__ void __launch_bounds__(256)
+k_pcg_p(double* __restrict__ p, const double* __restrict__ z, int n, const double* __restrict__ scal,
+        const int* __restrict__ go, int first) {
+    const int rhs = blockIdx.y;
+    if (!go[rhs]) return;
+    const double beta = first ? 0.0 : scal[2 * rhs] / scal[2 * rhs + 1];
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const size_t off = (size_t)rhs * n;
+    for (int i = lo + threadIdx.x; i < hi; i += 256)
+        p[off + i] = first ? z[off + i] : fma(beta, p[off + i], z[off + i]);
+}
+static __global__ void __launch_bounds__(256)
+k_pcg_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+             const double* __restrict__ q, int n, const double* __restrict__ scal,
+             const double* __restrict__ partPQ, double* __restrict__ partRR,
+             const int* __restrict__ go) {
+    RL_SMEM(smem);
+    double* red = reinterpret_cast<double*>(smem);
+    const int rhs = blockIdx.y, nblk = gridDim.x;
+    if (!go[rhs]) return;
+    double pq = 0.0;
+    for (int c = 0; c < nblk; ++c) pq += partPQ[(size_t)rhs * nblk + c];
+    const double alpha = scal[2 * rhs] / pq;
+    const int per = (n + nblk - 1) / nblk;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const size_t off = (size_t)rhs * n;
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        x[off + i] = fma(alpha, p[off + i], x[off + i]);
+        const double ri = fma(-alpha, q[off + i], r[off + i]);
+        r[off + i] = ri;
+        acc = fma(ri, ri, acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partRR[(size_t)rhs * nblk + blockIdx.x] = red[0];
+}

@@ -98,6 +98,7 @@ RlKnobs read_knobs() {
     k.no_rp = flag("RUNLMC_NO_RP");
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
     k.no_lr_small = flag("RUNLMC_NO_LR_SMALL");
+    k.no_precond_approx = flag("RUNLMC_NO_PRECOND_APPROX");
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");
@@ -615,7 +616,7 @@ extern "C" int rl_gridop_destroy(rl_gridop* g) {
     void* ptrs[] = {g->tw1, g->tw2, g->twlo, g->twhi, g->freq1, g->tops, g->spec,
                     g->facA, g->facW, g->facQ, g->kappa, g->ones, g->T,
                     g->T2[0], g->T2[1], g->T2[2], g->twL, g->spec1, g->mixtab, g->lr_beta, g->lr_nu, g->lr_phiJ, g->lr_stat, g->lr_M,
-                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_sel, g->lr_Cc, g->lr_Bc, g->lr_Mf, g->lr_spart,
+                    g->lr_B, g->lr_eye, g->lr_part, g->lr_zhat, g->lr_scr, g->lr_pw, g->lr_sel, g->lr_Cc, g->lr_Bc, g->lr_Mf, g->lr_spart, g->lr_Cx,
                     g->sf_tops, g->sf_blob, g->sf_blob_top, g->sf_pwp, g->sf_pw, g->sf_kappa, g->sf_facA, g->sf_facAW, g->sf_facJ,
                     g->sf_E, g->sf_Cin, g->sf_next};
     for (void* p : ptrs)
@@ -2088,6 +2089,16 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
     g->sf_nfac = 0;
     g->lr_np = 0;
     if (!g->lr_try && !g->sf_try) return RL_OK;
+    // dense couplings B_q = sum_{f of q} w_f a_f a_f^T + diag(kappa_q): the polynomial form's
+    // products and the factorisations of rl_solve.hip (exact or as a preconditioner) use them
+    std::vector<double> B((size_t)Q * D * D, 0.0);
+    for (size_t f = 0; f < W.size(); ++f)
+        for (int a = 0; a < D; ++a)
+            for (int b = 0; b < D; ++b)
+                B[((size_t)Qi[f] * D + a) * D + b] += W[f] * A[f * D + a] * A[f * D + b];
+    for (int q = 0; q < Q; ++q)
+        for (int a = 0; a < D; ++a) B[((size_t)q * D + a) * D + a] += kap[(size_t)q * D + a];
+    g->lr_hB = B;
     // 1. exponential-polynomial tops (host, from the rows themselves)
     std::vector<SfFit> fits(Q);
     int nfilt = 0;
@@ -2210,19 +2221,10 @@ static int forms_setup(rl_gridop* g, const std::vector<double>& A, const std::ve
         }
     }
     if (nfft > 0) return RL_OK;          // some top needs the transforms: so does the operator
-    // dense couplings B_q = sum_{f of q} w_f a_f a_f^T + diag(kappa_q) of the polynomial tops
     if (npoly) {
-        std::vector<double> B((size_t)Q * D * D, 0.0);
-        for (size_t f = 0; f < W.size(); ++f)
-            for (int a = 0; a < D; ++a)
-                for (int b = 0; b < D; ++b)
-                    B[((size_t)Qi[f] * D + a) * D + b] += W[f] * A[f * D + a] * A[f * D + b];
-        for (int q = 0; q < Q; ++q)
-            for (int a = 0; a < D; ++a) B[((size_t)q * D + a) * D + a] += kap[(size_t)q * D + a];
         const int r = g->lr_r;
         if (nfilt == 0) {
             RL_HIP(hipMemcpy(g->lr_B, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
-            g->lr_hB = B;
             g->lr_ok = true;
             g->lr_Mf_ok = false;
             if ((size_t)D * m <= RL_LR_SMALL_MAX && !g->kn.no_lr_small && (int)g->lr_hnu.size() >= r) {
@@ -2313,6 +2315,74 @@ int lr_ensure(rl_gridop* g) {
     g->lr_dirty = false;
     RL_HIP(hipSetDevice(g->device));
     return forms_setup(g, g->lr_A, g->lr_W, g->lr_Qi, g->lr_kap);
+}
+
+// C_q = Phi_R^T T_q Phi_R of EVERY top row on the first R orthonormal polynomials, host out
+// [Q][R][R] (symmetrised), for the factorisations of rl_solve.hip: exact[q] = 1 when the row is IN the
+// polynomial form at that rank (C from the accepted form), else the row's projection computed here
+// through the transform kernels -- what a preconditioner built on the polynomial subspace
+// takes for a Matern row; captured[q] = trace(C_q) / trace(T_q): the share of the row's
+// spectrum the subspace holds.
+int lr_all_coeffs(rl_gridop* g, int R, std::vector<double>* hC, std::vector<char>* exact,
+                  std::vector<double>* captured) {
+    const int D = g->D, m = g->m, Q = g->Q;
+    if (g->wide || !g->lr_try || Q < 1) return fail(RL_ELIMIT, "no polynomial basis on this grid");
+    if (R != 24 && R != 32 && R != 36 && R != 40 && R != 48) return fail(RL_EINVAL, "bad basis size");
+    RL_HIP(hipSetDevice(g->device));
+    RL_TRY(lr_ensure(g));
+    if (!g->lr_phiJ) {
+        // (a handle none of whose rows was ever a candidate has no basis yet: the verification's
+        // set-up, with nothing to verify; the basis size it leaves behind is nobody's)
+        std::vector<char> none((size_t)Q, 0), pass;
+        RL_TRY(lr_verify(g, none, &pass));
+    }
+    if (g->lr_np == 0) g->lr_r = R;
+    if (!g->lr_Cx) RL_HIP(hipMalloc((void**)&g->lr_Cx, (size_t)RL_LR_RMAX * RL_LR_RMAX * sizeof(double)));
+    hC->assign((size_t)Q * R * R, 0.0);
+    exact->assign(Q, 0);
+    captured->assign(Q, 0.0);
+    const size_t vec = (size_t)D * m;
+    double* tphi = g->lr_scr + 3 * vec;
+    hipStream_t st = nullptr;
+    std::vector<double> one((size_t)R * R);
+    for (int q = 0; q < Q; ++q) {
+        double* dst = hC->data() + (size_t)q * R * R;
+        if ((int)g->top_form.size() > q && g->top_form[q] == 1 && g->lr_r == R &&
+            g->lr_hC.size() >= (size_t)(q + 1) * R * R) {
+            std::memcpy(one.data(), g->lr_hC.data() + (size_t)q * R * R, one.size() * sizeof(double));
+            (*exact)[q] = 1;
+        } else {
+            const int nvr = (R + D - 1) / D, nrows = nvr * D;
+            RL_TRY(lr_reserve(g, std::max(nvr, 1)));
+            MixParams mp{1, 0, g->spec + (size_t)q * g->L, nullptr, nullptr, nullptr, g->ones, nullptr, nullptr};
+            g->lr_bypass = true;
+            const int rc = mvm_with_mix(g, mp, g->lr_phiJ, tphi, nvr, st);
+            g->lr_bypass = false;
+            if (rc != RL_OK) return rc;
+            int nparts = 0;
+            switch (R) {
+                case 24: nparts = lr_project<24>(g, tphi, nrows, st); break;
+                case 32: nparts = lr_project<32>(g, tphi, nrows, st); break;
+                case 36: nparts = lr_project<36>(g, tphi, nrows, st); break;
+                case 40: nparts = lr_project<40>(g, tphi, nrows, st); break;
+                default: nparts = lr_project<48>(g, tphi, nrows, st); break;
+            }
+            RL_LAUNCH(k_lr_finish_C, dim3(R), dim3(256), 512 * sizeof(double), st,
+                      (const double*)g->lr_part, nparts, nrows, R, (const double*)g->lr_nu, g->lr_Cx);
+            RL_HIP(hipGetLastError());
+            RL_HIP(hipMemcpy(one.data(), g->lr_Cx, one.size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        double tr = 0.0;
+        for (int i = 0; i < R; ++i) {
+            tr += one[(size_t)i * R + i];
+            for (int j = 0; j < R; ++j) dst[(size_t)i * R + j] = 0.5 * (one[(size_t)i * R + j] + one[(size_t)j * R + i]);
+        }
+        const double t0 = g->h_tops.size() > (size_t)q * m ? g->h_tops[(size_t)q * m] : 0.0;
+        (*captured)[q] = t0 > 0.0 ? tr / (t0 * m) : 0.0;
+        for (size_t e = 0; e < (size_t)R * R; ++e)
+            if (!std::isfinite(dst[e])) return fail(RL_EINVAL, "a top row's projection is not finite");
+    }
+    return RL_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -91,6 +91,7 @@ struct RlKnobs {
                                  // C5 matern round 3.71 ms against 4.18, mix 3.98 against 4.41
     bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
     bool no_lr_small = false;    // RUNLMC_NO_LR_SMALL: small batches never take k_lr_small_*
+    bool no_precond_approx = false;   // RUNLMC_NO_PRECOND_APPROX: no preconditioner for operators outside the polynomial form
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
                                  // expansion 257 -> 236 us at 129 vectors, 61 -> 42 at 17; projection level at rank
@@ -176,6 +177,7 @@ struct rl_gridop {
     std::vector<double> lr_hC;  // host copy of lr_C for it
     double* lr_spart = nullptr; // dev [nvec][D][nseg][r]: partial sums of k_lr_small_project
     size_t lr_spart_cap = 0;
+    double* lr_Cx = nullptr;    // dev [RMAX][RMAX]: scratch of lr_all_coeffs
     double* lr_Mf = nullptr;    // dev [D][r][D][r]: the coefficient map for k_lr_small_expand (any rank)
     size_t lr_Mf_cap = 0;
     bool lr_Mf_ok = false;      // ... built for the current parameters
@@ -396,6 +398,14 @@ struct rl_ski {
     const char* dz_eps_why = nullptr;   // ... or why there is none (not constant per output, not positive)
     unsigned long long dz_eps_ver = ~0ull;   // noise_ver those (and dz_inv) were derived from
     bool dz_valid = false;              // ... for the parameters / noise of the versions below
+    bool dz_exact = false;              // every top row in the polynomial form: the factorisation IS K~^-1;
+                                        // else it inverts the operator's projection on the subspace: a preconditioner
+    const char* dz_fail_why = nullptr;  // "not available" decided for the versions below (not recomputed per solve)
+    unsigned long long dz_fail_param_ver = 0, dz_fail_noise_ver = 0;
+    int dz_fail_streak = 0, dz_fail_skip = 0;   // back-off of the attempts after failures in a row
+    double *dz_p = nullptr, *dz_q = nullptr;       // dev [cap][n]: PCG's direction and operator product
+    size_t dz_pq_cap = 0;
+    double* dz_scal = nullptr;          // dev [cap][2]: PCG's (rho, rho_prev)
     unsigned long long dz_param_ver = 0, dz_noise_ver = 0;
     int dz_R = 0;
     double dz_logdet = 0.0;             // log det K~ of that factorisation
@@ -425,6 +435,8 @@ int lr_ensure(rl_gridop* g);
 int lr_prepare(rl_gridop* g, int nvec);
 int lr_reserve(rl_gridop* g, int nvec);
 int gridop_prepare(rl_gridop* g, int nvec);
+int lr_all_coeffs(rl_gridop* g, int R, std::vector<double>* hC, std::vector<char>* exact,
+                  std::vector<double>* captured);
 // (one chunk of a batched product on the transform kernels, optionally gathering W^T x itself:
 // the solver's fused rounds call them directly)
 int mvm_chunk_v2(rl_gridop* g, const MixParams& mp, const double* Xc, double* Yc, int nv, size_t pairs,

@@ -873,9 +873,9 @@ static int dz_available(rl_ski* s, bool* ok, const char** why) {
     if (!s->has_noise || (int)s->h_noise.size() != s->n) { *why = "no noise set"; return RL_OK; }
     RL_HIP(hipSetDevice(g->device));
     RL_TRY(lr_ensure(g));
-    if (!g->lr_ok) { *why = "not every top row is in the polynomial form"; return RL_OK; }
-    if ((int)g->lr_hC.size() < g->Q * g->lr_r * g->lr_r || (int)g->lr_hB.size() < g->Q * g->D * g->D ||
-        (int)g->lr_hnu.size() < g->lr_r) { *why = "no host copy of the coefficient maps"; return RL_OK; }
+    // (a row outside the polynomial form -- filter or transform kernels -- does not end it here: its
+    // projection on the subspace still makes a preconditioner, dz_ensure decides)
+    if ((int)g->lr_hB.size() < g->Q * g->D * g->D) { *why = "no host copy of the couplings"; return RL_OK; }
     *ok = true;
     return RL_OK;
 }
@@ -886,9 +886,46 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     rl_gridop* g = s->g;
     RL_TRY(dz_available(s, ok, why));
     if (!*ok) { s->dz_valid = false; return RL_OK; }
-    const int R = g->lr_r, D = g->D, n = s->n, Dr = D * R, Q = g->Q;
+    // basis size: the operator's own when some row is in the polynomial form, else the largest
+    const bool exact = g->lr_ok;
+    const int R = exact || g->lr_np > 0 ? g->lr_r : RL_LR_RMAX;
+    const int D = g->D, n = s->n, Dr = D * R, Q = g->Q;
     if (s->dz_valid && s->dz_param_ver == g->param_ver && s->dz_noise_ver == s->noise_ver && s->dz_R == R)
         return RL_OK;
+    if (s->dz_fail_why != nullptr && s->dz_fail_param_ver == g->param_ver && s->dz_fail_noise_ver == s->noise_ver) {
+        *ok = false;                       // (decided for these parameters already)
+        *why = s->dz_fail_why;
+        return RL_OK;
+    }
+    // an operator that had no factorisation at its last parameter sets sits out a growing number
+    // of updates before the next attempt (1, 3, 7 ... 31: the projections of its rows cost a
+    // millisecond an update, and a fit's kernels do not become smooth from one step to the next)
+    if (!exact && s->dz_fail_streak > 0 && s->dz_fail_why != nullptr) {
+        if (s->dz_fail_skip > 0) {
+            --s->dz_fail_skip;
+            *ok = false;
+            *why = s->dz_fail_why;
+            s->dz_fail_param_ver = g->param_ver;
+            s->dz_fail_noise_ver = s->noise_ver;
+            return RL_OK;
+        }
+    }
+    struct FailNote {                      // every "not available" below is remembered with its versions
+        rl_ski* s; bool* ok; const char** why;
+        ~FailNote() {
+            if (!*ok) {
+                s->dz_fail_why = *why;
+                s->dz_fail_param_ver = s->g->param_ver;
+                s->dz_fail_noise_ver = s->noise_ver;
+                s->dz_fail_streak = std::min(s->dz_fail_streak + 1, 5);
+                s->dz_fail_skip = (1 << s->dz_fail_streak) - 1;
+            } else {
+                s->dz_fail_why = nullptr;
+                s->dz_fail_streak = 0;
+                s->dz_fail_skip = 0;
+            }
+        }
+    } note{s, ok, why};
     // The host's part is ~1.5 (D r)^3 multiply-adds per parameter update (2.5 ms at D r = 240, 8 ms at
     // 360, ~0.1 s at 768): past D r = 576 a SMALL system's Krylov solve is cheaper than its
     // factorisation (a round of a 10^4-row system is 20 us), so such operators keep the Krylov path
@@ -901,6 +938,27 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     s->dz_valid = false;
     *ok = false;
     hipStream_t st = nullptr;
+    // C_q of every top row at this basis size: the accepted form's, or (rows on the filter /
+    // transform kernels) the row's projection on the subspace -- then the factorisation is the
+    // inverse of F M_r F^T + E, a PRECONDITIONER for K~ (rl_solve_pcg), not K~^-1.  (First of all:
+    // on a handle without polynomial rows this is what creates the basis and sets its size.)
+    std::vector<double> hCx;
+    const double* hC = g->lr_hC.data();
+    if (!exact) {
+        if (s->kn.no_precond_approx) { *why = "not every top row is in the polynomial form"; return RL_OK; }
+        std::vector<char> ex;
+        std::vector<double> cap;
+        RL_TRY(lr_all_coeffs(g, R, &hCx, &ex, &cap));
+        for (int q = 0; q < Q; ++q)
+            if (!(cap[q] >= 0.8)) {
+                *why = "not every top row is in the polynomial form, and the subspace holds less than 0.8 of a row's spectrum (no preconditioner either)";
+                return RL_OK;
+            }
+        hC = hCx.data();
+    } else if ((int)g->lr_hC.size() < Q * R * R) {
+        *why = "no host copy of the coefficient maps";
+        return RL_OK;
+    }
     RL_TRY(rp_prepare(s, std::max(R, 1)));
     if (s->rp_F == nullptr || s->rp_R != R) { *why = "no table of F"; return RL_OK; }
     // per-output noise, rows per output, 1 / eps per row on the device: per NOISE update (a
@@ -952,6 +1010,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
                     s->dz_U[(size_t)d * R * R + e] += part[(size_t)c * R * R + e];
         s->dz_U_R = R;
     }
+    if ((int)g->lr_hnu.size() < R) { *why = "no host copy of the basis normalisation"; return RL_OK; }
     const double* nu = g->lr_hnu.data();
     // G_d = nu nu^T (.) U_d / eps_d = L_d L_d^T; Li_d = L_d^-1
     std::vector<std::vector<double>> L(D), Li(D);
@@ -979,7 +1038,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
                 const double bq = 0.5 * (g->lr_hB[((size_t)q * D + a) * D + b] + g->lr_hB[((size_t)q * D + b) * D + a]);
                 if (bq == 0.0) continue;
                 any = true;
-                const double* C = g->lr_hC.data() + (size_t)q * R * R;
+                const double* C = hC + (size_t)q * R * R;
                 for (int i = 0; i < R; ++i)
                     for (int j = 0; j < R; ++j)
                         Mab[(size_t)i * R + j] += bq * 0.5 * (C[(size_t)i * R + j] + C[(size_t)j * R + i]);
@@ -1074,6 +1133,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     s->dz_param_ver = g->param_ver;
     s->dz_noise_ver = s->noise_ver;
     s->dz_R = R;
+    s->dz_exact = exact;
     s->dz_valid = true;
     *ok = true;
     return RL_OK;
@@ -1101,8 +1161,10 @@ extern "C" int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* 
     bool ok = false;
     const char* why = "";
     RL_TRY(dz_ensure(s, &ok, &why));
-    if (available) *available = ok ? 1 : 0;
-    if (logdet) *logdet = ok ? s->dz_logdet : 0.0;
+    // (2: the factorisation inverts the operator's projection on the polynomial subspace -- a
+    // preconditioner for rl_solve_pcg; its log det is not the operator's)
+    if (available) *available = ok ? (s->dz_exact ? 1 : 2) : 0;
+    if (logdet) *logdet = ok && s->dz_exact ? s->dz_logdet : 0.0;
     if (cond) *cond = ok ? s->dz_cond : 0.0;
     if (!ok) (void)fail(RL_OK, std::string("direct solve not available: ") + why);
     return RL_OK;
@@ -1117,6 +1179,7 @@ extern "C" int rl_ski_project(rl_ski* s, const double* X, int nvec, double* out,
     const char* why = "";
     RL_TRY(dz_ensure(s, &ok, &why));
     if (!ok) return fail(RL_ELIMIT, std::string("rl_ski_project: not available for this operator: ") + why);
+    if (!s->dz_exact) return fail(RL_ELIMIT, "rl_ski_project: not every top row is in the polynomial form");
     if (rank) *rank = g->lr_r;
     if (nvec == 0) return RL_OK;
     RL_HIP(hipSetDevice(g->device));
@@ -1152,6 +1215,9 @@ extern "C" int rl_solve_direct(rl_ski* s, const double* B, double* X, int nrhs, 
     const char* why = "";
     RL_TRY(dz_ensure(s, &ok, &why));
     if (!ok) return fail(RL_ELIMIT, std::string("rl_solve_direct: not available for this operator: ") + why);
+    if (!s->dz_exact)
+        return fail(RL_ELIMIT, "rl_solve_direct: not every top row is in the polynomial form -- the "
+                               "factorisation is a preconditioner here (rl_solve_pcg)");
     const int n = s->n, R = g->lr_r;
     // everything the kernels below allocate lazily
     RL_TRY(rp_prepare(s, std::max(nrhs, R)));
@@ -1175,7 +1241,7 @@ extern "C" int rl_solve_direct(rl_ski* s, const double* B, double* X, int nrhs, 
         s->dz_part = nullptr;
         s->dz_go = nullptr;
         s->dz_rhs_cap = 0;
-        RL_HIP(hipMalloc((void**)&s->dz_part, (size_t)nrhs * (RL_DZ_NBLK + 1) * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&s->dz_part, (size_t)nrhs * (2 * RL_DZ_NBLK + 1) * sizeof(double)));
         RL_HIP(hipMalloc((void**)&s->dz_go, (size_t)nrhs * sizeof(int)));
         s->dz_rhs_cap = (size_t)nrhs;
     }
@@ -1291,6 +1357,154 @@ static bool slq_ql_first_row(std::vector<double>& d, std::vector<double>& e, std
         } while (m != l);
     }
     return true;
+}
+
+extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
+                            int* iters_out, double* resid_out, int* istop_out, void* stream) {
+    if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_pcg: NULL argument");
+    if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_pcg: nrhs < 0");
+    if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_pcg: tol must be > 0");
+    if (nrhs == 0) return RL_OK;
+    rl_gridop* g = s->g;
+    RL_HIP(hipSetDevice(g->device));
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+    const char* why = "";
+    RL_TRY(dz_ensure(s, &ok, &why));
+    if (!ok) return fail(RL_ELIMIT, std::string("rl_solve_pcg: no preconditioner for this operator: ") + why);
+    const int n = s->n, R = g->lr_r;
+    if (maxiter <= 0) maxiter = n;
+    RL_TRY(rp_prepare(s, std::max(nrhs, R)));
+    RL_TRY(ski_reserve(s, nrhs));
+    RL_TRY(gridop_prepare(g, nrhs));
+    if (rp_ok(s, nrhs)) RL_TRY(rp_prepare(s, nrhs));
+    RL_TRY(ski_reserve_perm(s, nrhs));
+    const size_t ve = (size_t)nrhs * n;
+    if (s->dz_vec_cap < ve) {
+        if (s->dz_res) RL_HIP(hipFree(s->dz_res));
+        if (s->dz_cor) RL_HIP(hipFree(s->dz_cor));
+        s->dz_res = s->dz_cor = nullptr;
+        s->dz_vec_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->dz_res, ve * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&s->dz_cor, ve * sizeof(double)));
+        s->dz_vec_cap = ve;
+    }
+    if (s->dz_pq_cap < ve) {
+        if (s->dz_p) RL_HIP(hipFree(s->dz_p));
+        if (s->dz_q) RL_HIP(hipFree(s->dz_q));
+        s->dz_p = s->dz_q = nullptr;
+        s->dz_pq_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->dz_p, ve * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&s->dz_q, ve * sizeof(double)));
+        s->dz_pq_cap = ve;
+    }
+    if (s->dz_rhs_cap < (size_t)nrhs || s->dz_scal == nullptr) {
+        if (s->dz_part) RL_HIP(hipFree(s->dz_part));
+        if (s->dz_go) RL_HIP(hipFree(s->dz_go));
+        if (s->dz_scal) RL_HIP(hipFree(s->dz_scal));
+        s->dz_part = nullptr;
+        s->dz_go = nullptr;
+        s->dz_scal = nullptr;
+        s->dz_rhs_cap = 0;
+        RL_HIP(hipMalloc((void**)&s->dz_part, (size_t)nrhs * (2 * RL_DZ_NBLK + 1) * sizeof(double)));
+        RL_HIP(hipMalloc((void**)&s->dz_go, (size_t)nrhs * sizeof(int)));
+        RL_HIP(hipMalloc((void**)&s->dz_scal, (size_t)nrhs * 2 * sizeof(double)));
+        s->dz_rhs_cap = (size_t)nrhs;
+    }
+    const double* Bi = B;
+    double* Xi = X;
+    if (s->permuted) {
+        permute_rows(s, B, s->P1, nrhs, 0, st);
+        Bi = s->P1;
+        Xi = s->P2;
+    }
+    const int nblk = std::max(1, std::min(RL_DZ_NBLK, (n + 1023) / 1024));
+    const dim3 vgrid(nblk, nrhs), vblk(256), hgrid((nrhs + 63) / 64), hblk(64);
+    const size_t red = 256 * sizeof(double);
+    double* part2 = s->dz_part + (size_t)nrhs * RL_DZ_NBLK;           // (r.r while p.q is still read)
+    double* norms = s->dz_part + (size_t)2 * nrhs * RL_DZ_NBLK;
+    double *r = s->dz_res, *z = s->dz_cor, *p = s->dz_p, *q = s->dz_q;
+    std::vector<double> res((size_t)nrhs, 0.0);
+    std::vector<int> go((size_t)nrhs, 1), its((size_t)nrhs, 0), stop((size_t)nrhs, 0);
+    trace_once("solve: conjugate gradients preconditioned by the polynomial subspace's Woodbury inverse (rl_solve_pcg)");
+    RL_HIP(hipMemsetAsync(Xi, 0, ve * sizeof(double), st));
+    RL_HIP(hipMemcpyAsync(r, Bi, ve * sizeof(double), hipMemcpyDeviceToDevice, st));
+    RL_HIP(hipMemsetAsync(s->dz_scal, 0, (size_t)nrhs * 2 * sizeof(double), st));
+    // zero right-hand sides end at once
+    RL_LAUNCH(k_dot_partial, vgrid, vblk, red, st, (const double*)r, (const double*)r, n, s->dz_part);
+    RL_LAUNCH(k_dz_norms, hgrid, hblk, 0, st, (const double*)s->dz_part, nblk, nrhs, norms);
+    RL_HIP(hipMemcpyAsync(res.data(), norms, (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, st));
+    RL_HIP(hipStreamSynchronize(st));
+    int active = 0;
+    for (int v = 0; v < nrhs; ++v) {
+        if (res[v] == 0.0) { go[v] = 0; stop[v] = RL_ISTOP_ZERO_RHS; }
+        else if (res[v] < tol) { go[v] = 0; stop[v] = RL_ISTOP_RESIDUAL; }
+        else ++active;
+    }
+    int restarts = 0;
+    for (int k = 0; active > 0; ++k) {
+        RL_HIP(hipMemcpyAsync(s->dz_go, go.data(), (size_t)nrhs * sizeof(int), hipMemcpyHostToDevice, st));
+        RL_TRY(dz_apply(s, r, z, nrhs, st));                              // z = M r
+        RL_LAUNCH(k_dot_partial, vgrid, vblk, red, st, (const double*)r, (const double*)z, n, s->dz_part);
+        RL_LAUNCH(k_pcg_head, hgrid, hblk, 0, st, (const double*)s->dz_part, nblk, nrhs, s->dz_scal,
+                  (const int*)s->dz_go);
+        RL_LAUNCH(k_pcg_p, vgrid, vblk, 0, st, p, (const double*)z, n, (const double*)s->dz_scal,
+                  (const int*)s->dz_go, k == 0 ? 1 : 0);
+        RL_TRY(ski_mvm_int(s, p, q, nrhs, st));                            // q = K~ p
+        RL_LAUNCH(k_dot_partial, vgrid, vblk, red, st, (const double*)p, (const double*)q, n, s->dz_part);
+        RL_LAUNCH(k_pcg_update, vgrid, vblk, red, st, Xi, r, (const double*)p, (const double*)q, n,
+                  (const double*)s->dz_scal, (const double*)s->dz_part, part2, (const int*)s->dz_go);
+        RL_LAUNCH(k_dz_norms, hgrid, hblk, 0, st, (const double*)part2, nblk, nrhs, norms);
+        RL_HIP(hipGetLastError());
+        RL_HIP(hipMemcpyAsync(res.data(), norms, (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, st));
+        RL_HIP(hipStreamSynchronize(st));
+        active = 0;
+        for (int v = 0; v < nrhs; ++v) {
+            if (!go[v]) continue;
+            ++its[v];
+            if (!std::isfinite(res[v])) { go[v] = 0; stop[v] = RL_ISTOP_DIRECT_STALL; }
+            else if (res[v] < tol) { go[v] = 0; stop[v] = RL_ISTOP_RESIDUAL; }
+            else if (its[v] >= maxiter) { go[v] = 0; stop[v] = 6; }
+            else ++active;
+        }
+        if (active == 0 && restarts < 3) {
+            // the recurrence's residuals met the rule: the EXPLICIT residuals decide (the
+            // reference's own final check, iterative.py:54); a system whose explicit residual is
+            // still above the tolerance goes on from it
+            RL_TRY(ski_mvm_int(s, Xi, q, nrhs, st));
+            RL_LAUNCH(k_dz_resid, vgrid, vblk, red, st, Bi, q, n, s->dz_part);
+            RL_LAUNCH(k_dz_norms, hgrid, hblk, 0, st, (const double*)s->dz_part, nblk, nrhs, norms);
+            RL_HIP(hipMemcpyAsync(res.data(), norms, (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, st));
+            RL_HIP(hipStreamSynchronize(st));
+            for (int v = 0; v < nrhs; ++v)
+                if (stop[v] == RL_ISTOP_RESIDUAL && res[v] >= tol && its[v] < maxiter) {
+                    go[v] = 1;
+                    stop[v] = 0;
+                    ++active;
+                }
+            if (active > 0) {
+                // restart from the explicit residuals (q holds b - K~ x of every system; frozen
+                // systems' vectors are not touched again)
+                RL_HIP(hipMemcpyAsync(r, q, ve * sizeof(double), hipMemcpyDeviceToDevice, st));
+                ++restarts;
+                k = -1;                       // (the next pass is a first iteration: p = z)
+            }
+        }
+    }
+    // final explicit residuals of every system (what resid_out reports)
+    RL_TRY(ski_mvm_int(s, Xi, q, nrhs, st));
+    RL_LAUNCH(k_dz_resid, vgrid, vblk, red, st, Bi, q, n, s->dz_part);
+    RL_LAUNCH(k_dz_norms, hgrid, hblk, 0, st, (const double*)s->dz_part, nblk, nrhs, norms);
+    RL_HIP(hipMemcpyAsync(res.data(), norms, (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (s->permuted) permute_rows(s, Xi, X, nrhs, 1, st);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipStreamSynchronize(st));
+    for (int v = 0; v < nrhs; ++v) {
+        if (iters_out) iters_out[v] = its[v];
+        if (resid_out) resid_out[v] = res[v];
+        if (istop_out) istop_out[v] = stop[v];
+    }
+    return RL_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -22,7 +22,7 @@ import torch
 from ..linalg.matrix import Matrix, check_vector, check_block
 from ..linalg.diag import Diag
 from ..linalg.sum_matrix import SumMatrix
-from .._native import GridOp, SkiOp, solve_direct
+from .._native import GridOp, SkiOp, solve_direct, solve_pcg
 from .._lib import as_f64
 
 
@@ -176,12 +176,20 @@ class FactoredInverse(Matrix):
 
     MAX_REFINE = 4
 
-    def __init__(self, skiop):
+    def __init__(self, skiop, exact=True):
         super().__init__(skiop.n, skiop.n)
         self._skiop = skiop
+        # exact: every top row is in the polynomial form and the factorisation IS K~^-1.  Not
+        # exact (a Matern row next to smooth ones, Matern rows alone): it inverts the
+        # operator's projection on the polynomial subspace -- the M of preconditioned conjugate
+        # gradients (rl_solve_pcg), no log det
+        self.exact = bool(exact)
 
-    def solve(self, B, tol=1e-4, max_refine=None):
-        """B: (k, n) tensor on the device.  (X, applications of K~^-1, residuals, istop)."""
+    def solve(self, B, tol=1e-4, max_refine=None, maxiter=0):
+        """B: (k, n) tensor on the device.  (X, applications of the factorisation, residuals,
+        istop): refinement when it is K~^-1, preconditioned CG when it is a preconditioner."""
+        if not self.exact:
+            return solve_pcg(self._skiop, B, tol=tol, maxiter=maxiter)
         return solve_direct(self._skiop, B, tol=tol,
                             max_refine=self.MAX_REFINE if max_refine is None else max_refine)
 
@@ -189,11 +197,14 @@ class FactoredInverse(Matrix):
         """log det K~, exactly (determinant lemma) -- the reference's dense
         ``log_det_K`` (models/interpolated_llgp.py:262-276) without the Cholesky."""
         ok, ld, _ = self._skiop.factor()
-        if not ok:
-            raise ValueError(self._skiop.factor_reason)
+        if not ok or self._skiop.factor_mode != 1:
+            raise ValueError(self._skiop.factor_reason or
+                             'the factorisation is a preconditioner here, not K~^-1: no exact log det')
         return ld
 
     def matmat_device(self, X):
+        if not self.exact:
+            raise NotImplementedError('this preconditioner is applied inside rl_solve_pcg only')
         return solve_direct(self._skiop, X.contiguous(), tol=np.finfo(np.float64).max,
                             max_refine=0)[0]
 
@@ -237,7 +248,7 @@ class LMCOperator(SumMatrix):
         polynomial form (the factorisation is rebuilt on the device handle whenever
         parameters or noise changed), else None -- the Krylov path as before."""
         ok = self._skiop.factor()[0]
-        return FactoredInverse(self._skiop) if ok else None
+        return FactoredInverse(self._skiop, exact=self._skiop.factor_mode == 1) if ok else None
 
     @property
     def device(self):

@@ -120,7 +120,7 @@ class ApproxLMCLikelihood(LMCLikelihood):
         if term != 0 or len(skiop.grids) != 1 or grid.sizes is not None and len(grid.sizes) > 1:
             return None
         try:
-            if not skiop.factor()[0]:
+            if not skiop.factor()[0] or skiop.factor_mode != 1:
                 return None
         except NotImplementedError:
             return None

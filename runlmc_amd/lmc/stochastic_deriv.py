@@ -157,7 +157,11 @@ class StochasticDerivService:
         # factorisation holds log det K~ exactly instead)
         logdet_exact = None
         if lanczos is None:
-            logdet_exact = K.preconditioner.logdet()
+            M = K.preconditioner
+            if M is not None and M.exact:
+                logdet_exact = M.logdet()
+            # (preconditioned CG through an INEXACT factorisation: no Lanczos recurrence of K~ ran
+            # and the factorisation's log det is not the operator's -- logdet_K() says so)
         else:
             lanczos = lanczos[order]
         if self.metrics is not None:
@@ -225,7 +229,8 @@ class StochasticDeriv(Derivative):
         THIS rank's probes, from the Lanczos tridiagonals the probe solves
         built (no extra operator products)."""
         if self.lanczos is None:
-            raise ValueError('no Lanczos coefficients were recorded')
+            raise ValueError('no Lanczos coefficients were recorded (the solves ran preconditioned: '
+                             'pass precondition=False for a Lanczos-quadrature log det)')
         from .._native import slq_quadratic_forms
         n = self.alpha_dev.shape[0]
         its = np.asarray(self.iterations)[1:]
