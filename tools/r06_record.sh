@@ -33,6 +33,33 @@ rm -rf /tmp/prof_bench
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $root/bench.py --no-cpu > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err < /dev/null
 f=$(find /tmp/prof_bench -name "*kernel_stats.csv" 2>/dev/null | head -1)
 if [ -n "$f" ] && [ -f "$f" ]; then cp "$f" $out/bench_default_kernel_stats.csv; fi
+# per-launch durations of the headline's three kernels (full-size launches only: the set-time verification
+# launches the same kernels on a few dozen rows)
+rm -rf /tmp/prof_c5; mkdir -p /tmp/prof_c5
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu --no-nll --no-sweep --no-full --no-extra --no-families > /tmp/prof_c5/bench.json 2> /tmp/prof_c5/err.txt < /dev/null
+f=$(find /tmp/prof_c5 -name "*kernel_stats.csv" 2>/dev/null | head -1)
+if [ -n "$f" ] && [ -f "$f" ]; then cp "$f" $out/c5_products_kernel_stats.csv; fi
+python3 - <<PY > $out/c5_k129_poly_launch_durations.txt
+import csv,glob,collections
+fs=glob.glob('/tmp/prof_c5/**/*kernel_trace.csv',recursive=True)
+d=collections.defaultdict(list)
+if fs:
+    for r in csv.DictReader(open(fs[0])):
+        n=r['Kernel_Name'].split('(')[0].replace('void ','')
+        if n.startswith(('k_lr_project','k_lr_mix','k_lr_expand')):
+            d[n].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+print('# headline product (C5, 129 vectors, polynomial form, rank 24): per-launch durations in us of the launches of')
+print('# the timed region (bench.py --steps 50 --warmup 5 under rocprofv3 --kernel-trace); set-time launches (a few')
+print('# dozen rows, < 60 us for the projection / expansion) listed apart')
+for n,v in sorted(d.items()):
+    big=sorted(x for x in v if x >= (60 if 'mix' not in n else 0))
+    small=[x for x in v if x < (60 if 'mix' not in n else 0)]
+    if big:
+        print('%-24s full-size launches %3d  min %.1f  median %.1f  mean %.1f  max %.1f'%(n,len(big),big[0],big[len(big)//2],sum(big)/len(big),big[-1]))
+    if small:
+        print('%-24s set-time launches  %3d  mean %.1f'%(n,len(small),sum(small)/len(small)))
+PY
+cat $out/c5_k129_poly_launch_durations.txt
 if [ "${1:-}" != quick ]; then
   cd $root
   for k in periodic matern mix; do
@@ -44,6 +71,9 @@ if [ "${1:-}" != quick ]; then
   python3 tools/r06_direct_probe.py c5 rbf 2>/dev/null | tail -1 > $out/direct_probe_c5_rbf.txt < /dev/null
   python3 tools/r06_direct_probe.py c5 periodic 2>/dev/null | tail -1 > $out/direct_probe_c5_periodic.txt < /dev/null
   python3 tools/r06_direct_probe.py c2 rbf 2>/dev/null | tail -1 > $out/direct_probe_c2_rbf.txt < /dev/null
+  for a in "c5 mix" "c5 matern" "c2 mix" "c2 matern"; do
+    python3 tools/r06_pcg_probe.py $a 2>/dev/null | tail -1 > $out/pcg_probe_$(echo $a | tr " " _).txt < /dev/null
+  done
   python3 tools/r06_generate_stages.py 2>/dev/null > $out/generate_stages_c5.txt < /dev/null
   python3 tools/nll_breakdown.py c5 128 rbf 2>/dev/null > $out/nll_breakdown_c5_rbf.txt < /dev/null
   python3 tools/nll_breakdown.py c5 16 rbf 2>/dev/null >> $out/nll_breakdown_c5_rbf.txt < /dev/null
