@@ -486,7 +486,10 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
                                 'iterations = applications of K~^-1') if direct else
                                ('pcg: conjugate gradients preconditioned by the Woodbury inverse of the '
                                 'operator\'s projection on the polynomial subspace (rl_solve_pcg; the '
-                                'reference\'s M of iterative.py:47-51), ended by the reference\'s residual rule')
+                                'reference\'s M of iterative.py:47-51), ended by the reference\'s residual rule' +
+                                ('; no row of this operator is in the polynomial form: a basis of its own, up '
+                                 'to 192 polynomials per output (csrc/rl_solve.hip hz_*)'
+                                 if K.device_operator().factor_mode == 3 else ''))
                                if pcg else
                                ('krylov: batched MINRES, ' +
                                 ('SciPy 1.15 exits' if scipy_exits else 'reference residual rule only')),

@@ -212,3 +212,54 @@ k_pcg_update(double* __restrict__ x, double* __restrict__ r, const double* __res
     }
     if (threadIdx.x == 0) partRR[(size_t)rhs * nblk + blockIdx.x] = red[0];
 }
+
+// ---------------------------------------------------------------------------
+// k_dz_mix_blocks: the dense map of a factorisation whose basis is NB blocks of RL_HZ_BLK functions
+// (the high-rank preconditioner of operators without a polynomial row, rl_solve.hip: hz_*): the
+// projection ran block by block (k_rp_project<48> on 48 columns of F at a time), so
+//   S[v][(b, 48 k + j)] = sum_{runs c of output b} part[k][c][v][j]
+//   zhat[k][v][a][i]    = sum_f Zt[f][(a, 48 k + i)] S[v][f]        (each block's coefficients a
+//                         standalone [nvec][D][48] array for its expansion)
+//   grid (ceil(nvec / RL_DZ_VB), RL_HZ_SPLIT)   block 256   LDS: S [RL_DZ_VB][D NB 48]
+// ---------------------------------------------------------------------------
+#define RL_HZ_BLK 48
+#define RL_HZ_SPLIT 4          // workgroups per group of vectors: each a quarter of the output coefficients
+static __global__ void __launch_bounds__(256)
+k_dz_mix_blocks(const double* __restrict__ part, const int* __restrict__ run_ptr, int nruns, int nvec,
+                int D, int NB, const double* __restrict__ Zt, double* __restrict__ zhat) {
+    RL_SMEM(smem);
+    double* S = reinterpret_cast<double*>(smem);          // [RL_DZ_VB][Dr]
+    const int tid = threadIdx.x, R = NB * RL_HZ_BLK, Dr = D * R;
+    const int v0 = blockIdx.x * RL_DZ_VB;
+    for (int e = tid; e < Dr; e += 256) {
+        const int b = e / R, jg = e - b * R, k = jg / RL_HZ_BLK, j = jg - k * RL_HZ_BLK;
+        const int c0 = run_ptr[b], c1 = run_ptr[b + 1];
+        const double* pk = part + (size_t)k * nruns * nvec * RL_HZ_BLK;
+#pragma unroll
+        for (int q = 0; q < RL_DZ_VB; ++q) {
+            const int v = v0 + q < nvec ? v0 + q : nvec - 1;
+            const double* src = pk + (size_t)v * RL_HZ_BLK + j;
+            double s = 0.0;
+            for (int c = c0; c < c1; ++c) s += src[(size_t)c * nvec * RL_HZ_BLK];
+            S[q * Dr + e] = s;
+        }
+    }
+    __syncthreads();
+    const int per = (Dr + gridDim.y - 1) / gridDim.y;
+    const int e_lo = blockIdx.y * per, e_hi = e_lo + per < Dr ? e_lo + per : Dr;
+    for (int e = e_lo + tid; e < e_hi; e += 256) {
+        double acc[RL_DZ_VB];
+#pragma unroll
+        for (int q = 0; q < RL_DZ_VB; ++q) acc[q] = 0.0;
+        for (int f = 0; f < Dr; ++f) {
+            const double z = Zt[(size_t)f * Dr + e];
+#pragma unroll
+            for (int q = 0; q < RL_DZ_VB; ++q) acc[q] = fma(z, S[q * Dr + f], acc[q]);
+        }
+        const int a = e / R, ig = e - a * R, k = ig / RL_HZ_BLK, i = ig - k * RL_HZ_BLK;
+#pragma unroll
+        for (int q = 0; q < RL_DZ_VB; ++q)
+            if (v0 + q < nvec)
+                zhat[(((size_t)k * nvec + v0 + q) * D + a) * RL_HZ_BLK + i] = acc[q];
+    }
+}

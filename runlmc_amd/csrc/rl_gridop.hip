@@ -99,6 +99,9 @@ RlKnobs read_knobs() {
     k.rp_stagger = (int)num("RUNLMC_RP_STAGGER", 7);
     k.no_lr_small = flag("RUNLMC_NO_LR_SMALL");
     k.no_precond_approx = flag("RUNLMC_NO_PRECOND_APPROX");
+    k.no_precond_hi = flag("RUNLMC_NO_PRECOND_HI");
+    k.precond_hi_min = num("RUNLMC_PRECOND_HI_MIN", 100000);
+    k.precond_hi_rank = (int)num("RUNLMC_PRECOND_HI_RANK", 192);
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");

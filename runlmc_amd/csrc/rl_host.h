@@ -92,6 +92,11 @@ struct RlKnobs {
     bool no_rp_fuse = false;     // RUNLMC_NO_RP_FUSE: MINRES's B as its own kernel in row-polynomial rounds
     bool no_lr_small = false;    // RUNLMC_NO_LR_SMALL: small batches never take k_lr_small_*
     bool no_precond_approx = false;   // RUNLMC_NO_PRECOND_APPROX: no preconditioner for operators outside the polynomial form
+    long long precond_hi_min = 100000;   // RUNLMC_PRECOND_HI_MIN: rows from which an operator without a polynomial row
+                                      // gets the 96-function preconditioner
+    int precond_hi_rank = 192;         // RUNLMC_PRECOND_HI_RANK: its basis size (whole blocks of 48)
+    bool no_precond_hi = false;       // RUNLMC_NO_PRECOND_HI: operators without a polynomial row keep the 48-function
+                                      // preconditioner (not the 96-function one of rl_solve.hip: hz_*)
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
                                  // bit 1: k_rp_project too (otherwise from the table).  Measured (C5, per round):
                                  // expansion 257 -> 236 us at 129 vectors, 61 -> 42 at 17; projection level at rank
@@ -408,6 +413,23 @@ struct rl_ski {
     double* dz_scal = nullptr;          // dev [cap][2]: PCG's (rho, rho_prev)
     unsigned long long dz_param_ver = 0, dz_noise_ver = 0;
     int dz_R = 0;
+    // the 96-function preconditioner of an operator without a polynomial row (rl_solve.hip: hz_*)
+    bool dz_hz = false;                 // the valid factorisation is THAT one (dz_Zt: [D 96][D 96])
+    int hz_R = 0;                       // its basis size (blocks of 48; "96" below stands for it)
+    bool hz_basis_tried = false;        // basis generated (or found unusable) once per handle
+    const char* hz_why = nullptr;       // why the handle has none (decided once)
+    std::vector<double> hz_hnu;         // host [96]: normalisation of the basis
+    double* hz_beta = nullptr;          // dev [96]: recurrence coefficients
+    double* hz_phi = nullptr;           // dev [96 rounded up to D][m]: the functions on the grid
+    double* hz_tphi = nullptr;          // dev, same size: a top row applied to them
+    double* hz_C = nullptr;             // dev [96][96]
+    double* hz_F = nullptr;             // dev [96][n]: F = W Phi, unnormalised, degree-major
+    double* hz_ones = nullptr;          // dev [n]
+    std::vector<double> hz_U;           // host [D][96][96]: F_d^T F_d, once per handle
+    double* hz_part = nullptr;          // dev [2][runs][cap][48]
+    double* hz_zhat = nullptr;          // dev [2][cap][D][48]
+    double* hz_tmp = nullptr;           // dev [cap][n]: the first half's expansion
+    size_t hz_vec_cap = 0;
     double dz_logdet = 0.0;             // log det K~ of that factorisation
     double dz_cond = 0.0;               // ratio of the largest to the smallest pivot of chol(S), squared
     double *dz_res = nullptr, *dz_cor = nullptr;   // dev [cap][n]: residuals, corrections

@@ -750,8 +750,10 @@ static inline double dz_dot(const double* a, const double* b, int n) {
 static int dz_threads() {
     static int n = 0;
     if (n == 0) {
+        // (up to 8 on a small host, a quarter of a large one's logical processors up to 32: the
+        // MI355X box has 256 of them and eight ranks to share them)
         unsigned hc = std::thread::hardware_concurrency();
-        n = (int)std::max(1u, std::min(hc ? hc : 1u, 8u));
+        n = (int)std::max(1u, hc <= 32u ? std::min(hc ? hc : 1u, 8u) : std::min(hc / 4u, 32u));
     }
     return n;
 }
@@ -768,20 +770,37 @@ static void dz_parallel(int count, int min_per_thread, F body) {
     for (std::thread& th : pool) th.join();
 }
 // in-place Cholesky factor (lower, row-major n x n; the strict upper part is left alone);
-// false when a pivot is not positive
+// false when a pivot is not positive.  Row by row, every entry ONE dot product of two finished
+// row prefixes -- in panels of 64 columns: a panel's diagonal rows on the calling thread, then its
+// columns of all rows below spread over threads (the same dot products in the same order
+// whatever the thread count; 2.4 GFLOP at n = 1920, most of a parameter update's host time
+// when done on one thread).
 static bool dz_chol(std::vector<double>& a, int n) {
-    for (int i = 0; i < n; ++i) {
-        double* ai = a.data() + (size_t)i * n;
-        for (int j = 0; j <= i; ++j) {
-            const double* aj = a.data() + (size_t)j * n;
-            const double s = ai[j] - dz_dot(ai, aj, j);
-            if (j < i) {
-                ai[j] = s / aj[j];
-            } else {
-                if (!(s > 0.0) || !std::isfinite(s)) return false;
-                ai[i] = std::sqrt(s);
+    const int PW = 64;
+    for (int k0 = 0; k0 < n; k0 += PW) {
+        const int k1 = std::min(n, k0 + PW);
+        for (int i = k0; i < k1; ++i) {
+            double* ai = a.data() + (size_t)i * n;
+            for (int j = k0; j <= i; ++j) {
+                const double* aj = a.data() + (size_t)j * n;
+                const double s = ai[j] - dz_dot(ai, aj, j);
+                if (j < i) {
+                    ai[j] = s / aj[j];
+                } else {
+                    if (!(s > 0.0) || !std::isfinite(s)) return false;
+                    ai[i] = std::sqrt(s);
+                }
             }
         }
+        dz_parallel(n - k1, 16, [&](int first, int step) {
+            for (int i = k1 + first; i < n; i += step) {
+                double* ai = a.data() + (size_t)i * n;
+                for (int j = k0; j < k1; ++j) {
+                    const double* aj = a.data() + (size_t)j * n;
+                    ai[j] = (ai[j] - dz_dot(ai, aj, j)) / aj[j];
+                }
+            }
+        });
     }
     return true;
 }
@@ -809,31 +828,46 @@ static void dz_tri_inverse(const std::vector<double>& L, int n, std::vector<doub
         for (int i = c; i < n; ++i) x[(size_t)i * n + c] = xt[(size_t)c * n + i];
 }
 
+// (F / part: another table and another partial-sum buffer than the handle's own -- the
+// high-rank preconditioner projects on 48 columns of ITS table at a time)
 template <int R>
-static void rp_project_plain(rl_ski* s, const double* Xp, int nvec, hipStream_t st) {
+static void rp_project_plain(rl_ski* s, const double* Xp, int nvec, hipStream_t st,
+                             const double* Ftab = nullptr, double* partbuf = nullptr) {
     rl_gridop* g = s->g;
+    const double* F_ = Ftab ? Ftab : (const double*)s->rp_F;
+    double* part_ = partbuf ? partbuf : s->rp_part;
+    const double* beta_ = (const double*)g->lr_beta;       // (read by the table-free variants only)
     constexpr int NT = (R + 15) / 16;
     const RpFuse nofz{nullptr, nullptr, nullptr};
     if (nvec <= RL_RP_VG + 1 && (nvec <= RL_RP_VG || nvec % RL_RP_VG == 1) && !s->kn.no_rp_small) {
         const size_t lds1 = (((size_t)16 * NT + RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
         RL_LAUNCH((k_rp_project1<R, false>), dim3(s->rp_nruns), dim3(256), lds1, st, Xp, s->n, nvec,
-                  (const double*)s->rp_F, (const int*)s->rp_runs, s->rp_part, (int*)nullptr,
-                  (const int*)s->W4_base, (const double*)s->W4_w, g->m, (const double*)g->lr_beta, nofz);
+                  F_, (const int*)s->rp_runs, part_, (int*)nullptr,
+                  (const int*)s->W4_base, (const double*)s->W4_w, g->m, beta_, nofz);
         return;
     }
     const size_t lds = (((size_t)16 * NT + 2 * RL_RP_VG) * RL_RP_LD + RL_RP_TILE) * sizeof(double);
     const int vblk = RL_RP_NG(R) * RL_RP_VG;
     RL_LAUNCH((k_rp_project<R, false>), dim3(8 * ((s->rp_nruns + 7) / 8) * ((nvec + vblk - 1) / vblk)),
-              dim3(256), lds, st, Xp, s->n, nvec, (const double*)s->rp_F, (const int*)s->rp_runs,
-              s->rp_nruns, s->rp_part, (int*)nullptr, (const int*)s->W4_base, (const double*)s->W4_w,
-              g->m, (const double*)g->lr_beta, nofz);
+              dim3(256), lds, st, Xp, s->n, nvec, F_, (const int*)s->rp_runs,
+              s->rp_nruns, part_, (int*)nullptr, (const int*)s->W4_base, (const double*)s->W4_w,
+              g->m, beta_, nofz);
 }
 // Yp = F zhat + diag (.) X2
+// (Ftab: expand from THAT table -- a block of the high-rank preconditioner's -- instead of the
+// handle's own / the rows computed on the fly)
 template <int R>
 static void rp_expand_plain(rl_ski* s, const double* zhat, double* Yp, int nvec, const double* diag,
-                            const double* X2, hipStream_t st) {
+                            const double* X2, hipStream_t st, const double* Ftab = nullptr) {
     rl_gridop* g = s->g;
     const RpPFuse nopf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (Ftab != nullptr) {
+        RL_LAUNCH((k_rp_expand<R, false, false, true>), dim3((s->n + 255) / 256), dim3(256), 0, st, zhat,
+                  Ftab, s->n, nvec, g->D, (const int*)s->rp_out_end, Yp, diag, X2,
+                  s->kn.rp_stagger, (const int*)s->W4_base, (const double*)s->W4_w, g->m,
+                  (const double*)g->lr_beta, nopf);
+        return;
+    }
     if (s->kn.rp_fly & 1)
         RL_LAUNCH((k_rp_expand<R, true, false, true>), dim3((s->n + 255) / 256), dim3(256), 0, st, zhat,
                   (const double*)s->rp_F, s->n, nvec, g->D, (const int*)s->rp_out_end, Yp, diag, X2,
@@ -854,6 +888,354 @@ static void rp_expand_plain(rl_ski* s, const double* zhat, double* Yp, int nvec,
         case 48: CALL(48); break;                                                        \
         default: return fail(RL_EINVAL, "direct solve: bad basis size");                 \
     }
+
+// The host's part of a factorisation (rl_direct.h): from the per-output Gram matrices U_d = F_d^T F_d on
+// the unnormalised basis, the normalisation nu, the noise levels, the couplings B_q and the rows'
+// coefficient matrices C_q at basis size R -- the scaled solve map Zs (D R x D R, symmetric), log det of
+// F M F^T + E and the extreme Cholesky pivots of S.  false (with a reason) when a factor breaks down.
+static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, const std::vector<double>& eps,
+                        const std::vector<int>& rows, const double* hB, const double* hC,
+                        std::vector<double>& Zs, double* logdet_out, double* pmin_out, double* pmax_out,
+                        const char** why) {
+    const int Dr = D * R;
+    // G_d = nu nu^T (.) U_d / eps_d = L_d L_d^T; Li_d = L_d^-1
+    std::vector<std::vector<double>> L(D), Li(D);
+    for (int d = 0; d < D; ++d) {
+        L[d].assign((size_t)R * R, 0.0);
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < R; ++j) {
+                const double u = 0.5 * (U[((size_t)d * R + i) * R + j] + U[((size_t)d * R + j) * R + i]);
+                L[d][(size_t)i * R + j] = nu[i] * nu[j] * u / eps[d];
+            }
+        if (!dz_chol(L[d], R)) { *why = "an output has too few (or degenerate) rows for the basis"; return false; }
+        for (int i = 0; i < R; ++i)
+            for (int j = i + 1; j < R; ++j) L[d][(size_t)i * R + j] = 0.0;
+        dz_tri_inverse(L[d], R, Li[d]);
+    }
+    // S = I + L^T M L, M_ab = sum_q B_q[a][b] C_q  (C symmetrised)
+    std::vector<double> S((size_t)Dr * Dr, 0.0);
+    dz_parallel(D, 1, [&](int first, int step) {
+      std::vector<double> Mab((size_t)R * R), T1((size_t)R * R);
+      for (int a = first; a < D; a += step)
+        for (int b = 0; b <= a; ++b) {
+            std::fill(Mab.begin(), Mab.end(), 0.0);
+            bool any = false;
+            for (int q = 0; q < Q; ++q) {
+                const double bq = 0.5 * (hB[((size_t)q * D + a) * D + b] + hB[((size_t)q * D + b) * D + a]);
+                if (bq == 0.0) continue;
+                any = true;
+                const double* C = hC + (size_t)q * R * R;
+                for (int i = 0; i < R; ++i)
+                    for (int j = 0; j < R; ++j)
+                        Mab[(size_t)i * R + j] += bq * 0.5 * (C[(size_t)i * R + j] + C[(size_t)j * R + i]);
+            }
+            if (!any) continue;
+            // T1 = M_ab L_b   (L_b lower: column j of L_b has rows >= j)
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = j; k < R; ++k) acc += Mab[(size_t)i * R + k] * L[b][(size_t)k * R + j];
+                    T1[(size_t)i * R + j] = acc;
+                }
+            // A_ab = L_a^T T1
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = i; k < R; ++k) acc += L[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
+                    S[((size_t)a * R + i) * Dr + (size_t)b * R + j] = acc;
+                    S[((size_t)b * R + j) * Dr + (size_t)a * R + i] = acc;
+                }
+        }
+    });
+    for (int i = 0; i < Dr; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double v = 0.5 * (S[(size_t)i * Dr + j] + S[(size_t)j * Dr + i]);
+            S[(size_t)i * Dr + j] = v;
+            S[(size_t)j * Dr + i] = v;
+        }
+    for (int i = 0; i < Dr; ++i) S[(size_t)i * Dr + i] += 1.0;
+    if (!dz_chol(S, Dr)) { *why = "I + L^T M L is not positive definite (M is not positive semi-definite to roundoff)"; return false; }
+    double logdet = 0.0, pmin = 1e300, pmax = 0.0;
+    for (int i = 0; i < Dr; ++i) {
+        const double p = S[(size_t)i * Dr + i];
+        logdet += 2.0 * std::log(p);
+        pmin = std::min(pmin, p);
+        pmax = std::max(pmax, p);
+    }
+    for (int d = 0; d < D; ++d) logdet += rows[d] * std::log(eps[d]);
+    // Y = I - S^-1 = I - X^T X, X = chol(S)^-1: with Xt = X^T stored by rows (row c = column c
+    // of X, zero before position c), S^-1[i][j] = Xt[i] . Xt[j] over positions >= max(i, j)
+    std::vector<double> Xt;
+    dz_tri_inverse_t(S, Dr, Xt);
+    std::vector<double> Y((size_t)Dr * Dr, 0.0);
+    dz_parallel(Dr, 32, [&](int first, int step) {
+        for (int i = first; i < Dr; i += step) {
+            const double* xi = Xt.data() + (size_t)i * Dr;
+            for (int j = 0; j <= i; ++j) {
+                const double* xj = Xt.data() + (size_t)j * Dr;
+                const double v = (i == j ? 1.0 : 0.0) - dz_dot(xi + i, xj + i, Dr - i);
+                Y[(size_t)i * Dr + j] = v;
+            }
+        }
+    });
+    for (int i = 0; i < Dr; ++i)
+        for (int j = 0; j < i; ++j) Y[(size_t)j * Dr + i] = Y[(size_t)i * Dr + j];
+    // Z_ab = Li_a^T Y_ab Li_b, scaled:  Zs = -(nu_i / eps_a) Z (nu_j / eps_b)
+    Zs.assign((size_t)Dr * Dr, 0.0);
+    dz_parallel(D, 1, [&](int first, int step) {
+      std::vector<double> T1((size_t)R * R);
+      for (int a = first; a < D; a += step)
+        for (int b = 0; b <= a; ++b) {
+            // T1 = Y_ab Li_b  (Li_b lower)
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = j; k < R; ++k)
+                        acc += Y[((size_t)a * R + i) * Dr + (size_t)b * R + k] * Li[b][(size_t)k * R + j];
+                    T1[(size_t)i * R + j] = acc;
+                }
+            for (int i = 0; i < R; ++i)
+                for (int j = 0; j < R; ++j) {
+                    double acc = 0.0;
+                    for (int k = i; k < R; ++k) acc += Li[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
+                    const double v = -(nu[i] / eps[a]) * acc * (nu[j] / eps[b]);
+                    Zs[((size_t)a * R + i) * Dr + (size_t)b * R + j] = v;
+                    Zs[((size_t)b * R + j) * Dr + (size_t)a * R + i] = v;
+                }
+        }
+    });
+    *logdet_out = logdet;
+    *pmin_out = pmin;
+    *pmax_out = pmax;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// The larger preconditioner.  An operator NONE of whose rows is in the polynomial form (filter and
+// transform kernels only: Matern) has no basis size of its own, and its rows' spectra fall off
+// slowly: the 48 functions every handle generates leave conjugate gradients 1358 iterations at
+// C5 (8 s; profiles/r06/pcg_probe_c5_matern.txt).  More functions cut that several times over --
+// 220 iterations with 96, 77 with 144, 38 with 192 (0.39 s; profiles/r06/pcg_probe_c5_matern_hi*.txt)
+// -- so such an operator of enough rows gets a basis of its own, of hz_rank() functions:
+//   * orthonormal polynomials by the same recurrence as lr_make_basis, F = W Phi as an [R][n]
+//     table (k_rp_build), the Gram matrices of its columns per output: once per handle;
+//   * per parameter update C_q = Phi^T T_q Phi from ONE product of the row with the functions
+//     (rl_gridop_mvm_top) and an R x R block of dot products, then dz_host_map at size D * R;
+//   * per application the 48-function kernels on one block of 48 columns of the table at a time
+//     (rp_project_plain<48> / rp_expand_plain<48> with a table argument) around k_dz_mix_blocks.
+// The factorisation is a PRECONDITIONER (rl_solve_pcg): nothing here is exact, and nothing else in
+// the library reads this basis.  ("96" in names and comments below: the smallest such basis.)
+// ---------------------------------------------------------------------------
+static_assert(RL_HZ_BLK == RL_RP_RMAX, "the blocks run the rank-48 kernels");
+// basis size of this handle: the largest number of whole blocks of 48, at most RUNLMC_PRECOND_HI_RANK
+// (default RL_HZ_RDEF) and at least two, that
+//   * k_dz_mix_blocks' coefficient rows leave room for in 64 KB of LDS (D * R <= 2048),
+//   * the grid carries (the recurrence keeps its functions orthonormal well past m = 8 R; hz_basis
+//     checks), and
+//   * pays: the host's part of a parameter update grows as (D R)^3 -- measured on the MI355X box's
+//     host at C5 (D = 10): 47 ms at R = 96, 90 ms at 144, 0.24 s at 192 on 8 threads -- against
+//     conjugate-gradient iterations of ~7 us per thousand rows saved (C5: 1358 iterations with the
+//     48 functions, 220 with 96, 77 with 144, 38 with 192).
+// 0: none.
+#define RL_HZ_RDEF 192
+static int hz_rank(const rl_ski* s) {
+    const int D = s->g->D;
+    const int lim = (int)(65536 / sizeof(double) / RL_DZ_VB / D) / RL_HZ_BLK * RL_HZ_BLK;
+    for (int R = std::min(s->kn.precond_hi_rank / RL_HZ_BLK * RL_HZ_BLK, lim); R >= 2 * RL_HZ_BLK; R -= RL_HZ_BLK) {
+        const double f = (double)D * R / 960.0;
+        if (s->g->m >= 8 * R && (double)s->n >= 1e5 * f * f * f) return R;
+    }
+    return 0;
+}
+template <class T>
+static int hz_grow(T** p, size_t count) {
+    if (*p) RL_HIP(hipFree(*p));
+    *p = nullptr;
+    RL_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return RL_OK;
+}
+
+// buffers of an application to nvec vectors (never inside a capture: rl_solve_pcg calls it first)
+static int hz_reserve(rl_ski* s, int nvec) {
+    const size_t cap = (size_t)std::max(nvec, RL_HZ_BLK);
+    if (s->hz_vec_cap >= cap && s->hz_part != nullptr) return RL_OK;
+    s->hz_vec_cap = 0;
+    const size_t nb = (size_t)s->hz_R / RL_HZ_BLK;
+    RL_TRY(hz_grow(&s->hz_part, nb * s->rp_nruns * cap * RL_HZ_BLK));
+    RL_TRY(hz_grow(&s->hz_zhat, nb * cap * s->g->D * RL_HZ_BLK));
+    RL_TRY(hz_grow(&s->hz_tmp, cap * s->n));
+    s->hz_vec_cap = cap;
+    return RL_OK;
+}
+
+// once per handle: the basis on the grid, its recurrence, F and the Gram matrices of F's columns
+// per output.  hz_why != nullptr afterwards: the handle has no such basis.
+static int hz_basis(rl_ski* s) {
+    rl_gridop* g = s->g;
+    if (s->hz_basis_tried) return RL_OK;
+    s->hz_basis_tried = true;
+    s->hz_why = "basis not built";
+    const int m = g->m, n = s->n, D = g->D, R = hz_rank(s), NB = R / RL_HZ_BLK;
+    if (R == 0) { s->hz_why = "no room for a larger basis at this many outputs"; return RL_OK; }
+    s->hz_R = R;
+    const int rows = (R + D - 1) / D * D;               // (products take whole vectors of D blocks)
+    std::vector<double> phi((size_t)rows * m, 0.0), beta(R), nu(R);
+    {
+        std::vector<long double> prev(m, 0.0L), cur(m), nxt(m);
+        const long double p0 = 1.0L / sqrtl((long double)m);
+        for (int i = 0; i < m; ++i) cur[i] = p0;
+        long double bj = 0.0L, nuj = p0;
+        for (int j = 0; j < R; ++j) {
+            for (int i = 0; i < m; ++i) phi[(size_t)j * m + i] = (double)cur[i];
+            beta[j] = (double)(bj * bj);
+            nu[j] = (double)nuj;
+            long double nrm = 0.0L;
+            for (int i = 0; i < m; ++i) {
+                const long double si = -1.0L + 2.0L * i / (m - 1);
+                nxt[i] = si * cur[i] - bj * prev[i];
+                nrm += nxt[i] * nxt[i];
+            }
+            bj = sqrtl(nrm);
+            if (!(bj > 0.0L)) { s->hz_why = "the larger basis is degenerate on this grid"; return RL_OK; }
+            nuj /= bj;
+            for (int i = 0; i < m; ++i) {
+                prev[i] = cur[i];
+                cur[i] = nxt[i] / bj;
+            }
+        }
+    }
+    // (the recurrence loses orthogonality when the degree nears 2 sqrt(m): the last function
+    // against a few of the others says whether it did)
+    {
+        const int probe[] = {0, 1, R / 4, R / 2 - 1, R / 2, R - 3, R - 2};
+        const double* last = phi.data() + (size_t)(R - 1) * m;
+        double worst = std::fabs(dz_dot(last, last, m) - 1.0);
+        for (int j : probe) worst = std::max(worst, std::fabs(dz_dot(last, phi.data() + (size_t)j * m, m)));
+        if (!(worst < 1e-9)) { s->hz_why = "the larger basis is not orthonormal on this grid (too few points)"; return RL_OK; }
+    }
+    RL_TRY(upload(&s->hz_phi, phi));
+    RL_TRY(upload(&s->hz_beta, beta));
+    s->hz_hnu = nu;
+    RL_TRY(hz_grow(&s->hz_tphi, (size_t)rows * m));
+    RL_TRY(hz_grow(&s->hz_C, (size_t)R * R));
+    RL_TRY(hz_grow(&s->hz_F, (size_t)R * n));
+    {
+        std::vector<double> ones((size_t)n, 1.0);
+        RL_TRY(upload(&s->hz_ones, ones));
+    }
+    hipStream_t st = nullptr;
+    RL_LAUNCH(k_rp_build, dim3((n + 255) / 256), dim3(256), 0, st, (const int*)s->W4_base,
+              (const double*)s->W4_w, n, m, R, (const double*)s->hz_beta, s->hz_F);
+    RL_HIP(hipGetLastError());
+    RL_TRY(hz_reserve(s, RL_HZ_BLK));
+    // U_d[(rb, j)][(cb, v)] = sum over the runs c of output d of part[c][v][j]: half cb of the
+    // table's columns as a batch of 48 vectors, projected on half rb
+    s->hz_U.assign((size_t)D * R * R, 0.0);
+    std::vector<double> part((size_t)s->rp_nruns * RL_HZ_BLK * RL_HZ_BLK);
+    for (int cb = 0; cb < NB; ++cb)
+        for (int rb = 0; rb < NB; ++rb) {
+            rp_project_plain<RL_HZ_BLK>(s, s->hz_F + (size_t)cb * RL_HZ_BLK * n, RL_HZ_BLK, st,
+                                        s->hz_F + (size_t)rb * RL_HZ_BLK * n, s->hz_part);
+            RL_HIP(hipGetLastError());
+            RL_HIP(hipMemcpy(part.data(), s->hz_part, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int d = 0; d < D; ++d)
+                for (int c = s->h_run_ptr[d]; c < s->h_run_ptr[d + 1]; ++c)
+                    for (int v = 0; v < RL_HZ_BLK; ++v)
+                        for (int j = 0; j < RL_HZ_BLK; ++j)
+                            s->hz_U[((size_t)d * R + rb * RL_HZ_BLK + j) * R + cb * RL_HZ_BLK + v] +=
+                                part[((size_t)c * RL_HZ_BLK + v) * RL_HZ_BLK + j];
+        }
+    s->hz_why = nullptr;
+    return RL_OK;
+}
+
+// Is the 96-function preconditioner this operator's?  (No polynomial row, a 1-D grid long enough
+// for the basis, rows enough that the factorisation at D * 96 pays: a conjugate-gradient
+// iteration of a 10^5-row system costs tens of microseconds, the host's part here grows as
+// (D * 96)^3 -- 10 ms at D = 4, 0.25 s at D = 10.)
+static bool hz_wanted(const rl_ski* s) {
+    const rl_gridop* g = s->g;
+    if (s->kn.no_precond_hi || g->lr_ok || g->lr_np > 0) return false;
+    return hz_rank(s) > 0 && (double)s->n >= (double)s->kn.precond_hi_min;
+}
+
+// the factorisation at the current parameters: *ok = false with a reason leaves the handle to the
+// 48-function one
+static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<int>& rows, bool* ok,
+                  const char** why) {
+    rl_gridop* g = s->g;
+    *ok = false;
+    RL_TRY(hz_basis(s));
+    if (s->hz_why != nullptr) { *why = s->hz_why; return RL_OK; }
+    const int D = g->D, m = g->m, Q = g->Q, R = s->hz_R;
+    const int nv = (R + D - 1) / D;
+    hipStream_t st = nullptr;
+    std::vector<double> hC((size_t)Q * R * R), one((size_t)R * R);
+    const unsigned nb = ((R + RL_XD_A - 1) / RL_XD_A) * ((R + RL_XD_B - 1) / RL_XD_B);
+    for (int q = 0; q < Q; ++q) {
+        RL_TRY(rl_gridop_mvm_top(g, q, s->hz_phi, s->hz_tphi, nv, st));
+        RL_LAUNCH(k_cross_dots_tiled, dim3(nb, 1), dim3(RL_SOLVER_THREADS), RL_SOLVER_THREADS * sizeof(double),
+                  st, (const double*)s->hz_phi, (const double*)s->hz_tphi, R, m, s->hz_C);
+        RL_HIP(hipGetLastError());
+        RL_HIP(hipMemcpy(one.data(), s->hz_C, one.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double tr = 0.0;
+        double* dst = hC.data() + (size_t)q * R * R;
+        for (int i = 0; i < R; ++i) {
+            tr += one[(size_t)i * R + i];
+            for (int j = 0; j < R; ++j) {
+                dst[(size_t)i * R + j] = 0.5 * (one[(size_t)i * R + j] + one[(size_t)j * R + i]);
+                if (!std::isfinite(dst[(size_t)i * R + j])) { *why = "a top row's projection is not finite"; return RL_OK; }
+            }
+        }
+        const double t0 = g->h_tops.size() > (size_t)q * m ? g->h_tops[(size_t)q * m] : 0.0;
+        if (!(t0 > 0.0 && tr / (t0 * m) >= 0.8)) {
+            *why = "the larger subspace holds less than 0.8 of a row's spectrum either";
+            return RL_OK;
+        }
+    }
+    std::vector<double> Zs;
+    double logdet = 0.0, pmin = 1.0, pmax = 1.0;
+    if (!dz_host_map(D, R, Q, s->hz_U.data(), s->hz_hnu.data(), eps, rows, g->lr_hB.data(), hC.data(), Zs,
+                     &logdet, &pmin, &pmax, why))
+        return RL_OK;
+    for (double v : Zs)
+        if (!std::isfinite(v)) { *why = "the solve map is not finite"; return RL_OK; }
+    if (s->dz_Zt_cap < Zs.size()) {
+        s->dz_Zt_cap = 0;
+        RL_TRY(hz_grow(&s->dz_Zt, Zs.size()));
+        s->dz_Zt_cap = Zs.size();
+    }
+    RL_HIP(hipMemcpy(s->dz_Zt, Zs.data(), Zs.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->dz_logdet = logdet;
+    s->dz_cond = (pmax / pmin) * (pmax / pmin);
+    *ok = true;
+    return RL_OK;
+}
+
+// out = P^-1 in through the 96-function factorisation (dz_apply's other branch)
+static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st) {
+    rl_gridop* g = s->g;
+    const int D = g->D, n = s->n, Dr = D * s->hz_R, NB = s->hz_R / RL_HZ_BLK;
+    RL_TRY(hz_reserve(s, nvec));
+    for (int k = 0; k < NB; ++k)
+        rp_project_plain<RL_HZ_BLK>(s, in, nvec, st, s->hz_F + (size_t)k * RL_HZ_BLK * n,
+                                    s->hz_part + (size_t)k * s->rp_nruns * nvec * RL_HZ_BLK);
+    RL_LAUNCH(k_dz_mix_blocks, dim3((nvec + RL_DZ_VB - 1) / RL_DZ_VB, RL_HZ_SPLIT), dim3(256),
+              (size_t)RL_DZ_VB * Dr * sizeof(double), st, (const double*)s->hz_part,
+              (const int*)s->rp_run_ptr, s->rp_nruns, nvec, D, NB, (const double*)s->dz_Zt, s->hz_zhat);
+    // (a pass over the rows per block, each adding to the one before through the noise term's
+    // operand with a diagonal of ones: not in place -- the kernel's pointers are declared not
+    // to alias -- but alternating between `out` and one more buffer so that the last lands in out)
+    const double* src = in;
+    for (int k = 0; k < NB; ++k) {
+        double* dst = (NB - 1 - k) % 2 == 0 ? out : s->hz_tmp;
+        rp_expand_plain<RL_HZ_BLK>(s, s->hz_zhat + (size_t)k * nvec * D * RL_HZ_BLK, dst, nvec,
+                                   k == 0 ? s->dz_inv : s->hz_ones, src, st, s->hz_F + (size_t)k * RL_HZ_BLK * n);
+        src = dst;
+    }
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
 
 // May this handle's operator be inverted through its polynomial form?  Runs the pending
 // verification of the forms (whatever the batch gate says: the decision is the operator's,
@@ -890,7 +1272,8 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     const bool exact = g->lr_ok;
     const int R = exact || g->lr_np > 0 ? g->lr_r : RL_LR_RMAX;
     const int D = g->D, n = s->n, Dr = D * R, Q = g->Q;
-    if (s->dz_valid && s->dz_param_ver == g->param_ver && s->dz_noise_ver == s->noise_ver && s->dz_R == R)
+    if (s->dz_valid && s->dz_param_ver == g->param_ver && s->dz_noise_ver == s->noise_ver &&
+        (s->dz_R == R || s->dz_hz))
         return RL_OK;
     if (s->dz_fail_why != nullptr && s->dz_fail_param_ver == g->param_ver && s->dz_fail_noise_ver == s->noise_ver) {
         *ok = false;                       // (decided for these parameters already)
@@ -929,6 +1312,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     // The host's part is ~1.5 (D r)^3 multiply-adds per parameter update (2.5 ms at D r = 240, 8 ms at
     // 360, ~0.1 s at 768): past D r = 576 a SMALL system's Krylov solve is cheaper than its
     // factorisation (a round of a 10^4-row system is 20 us), so such operators keep the Krylov path
+    s->dz_hz = false;
     if (Dr > 576 && (double)n < 1e5 * ((double)Dr / 576.0) * ((double)Dr / 576.0) * ((double)Dr / 576.0)) {
         s->dz_valid = false;
         *ok = false;
@@ -944,16 +1328,17 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     // on a handle without polynomial rows this is what creates the basis and sets its size.)
     std::vector<double> hCx;
     const double* hC = g->lr_hC.data();
+    const char* cap_why = nullptr;
     if (!exact) {
         if (s->kn.no_precond_approx) { *why = "not every top row is in the polynomial form"; return RL_OK; }
         std::vector<char> ex;
         std::vector<double> cap;
         RL_TRY(lr_all_coeffs(g, R, &hCx, &ex, &cap));
         for (int q = 0; q < Q; ++q)
-            if (!(cap[q] >= 0.8)) {
-                *why = "not every top row is in the polynomial form, and the subspace holds less than 0.8 of a row's spectrum (no preconditioner either)";
-                return RL_OK;
-            }
+            if (!(cap[q] >= 0.8))
+                cap_why = "not every top row is in the polynomial form, and the subspace holds less than 0.8 of a row's spectrum (no preconditioner either)";
+        // (... which the 96-function basis below may still hold)
+        if (cap_why != nullptr && !hz_wanted(s)) { *why = cap_why; return RL_OK; }
         hC = hCx.data();
     } else if ((int)g->lr_hC.size() < Q * R * R) {
         *why = "no host copy of the coefficient maps";
@@ -994,6 +1379,24 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
         rows[d] = s->h_out_end[d] - a;
         a = s->h_out_end[d];
     }
+    // an operator without a polynomial row, of enough rows: the 96-function preconditioner (hz_*
+    // above); whatever it declines falls back to the 48 functions
+    if (!exact && hz_wanted(s)) {
+        bool hz_ok = false;
+        const char* hz_why = "";
+        RL_TRY(hz_try(s, eps, rows, &hz_ok, &hz_why));
+        if (hz_ok) {
+            s->dz_param_ver = g->param_ver;
+            s->dz_noise_ver = s->noise_ver;
+            s->dz_R = s->hz_R;
+            s->dz_exact = false;
+            s->dz_hz = true;
+            s->dz_valid = true;
+            *ok = true;
+            return RL_OK;
+        }
+        if (cap_why != nullptr) { *why = cap_why; return RL_OK; }
+    }
     // Gram matrices of F on the unnormalised basis, once per (handle, rank): the columns of F
     // ARE a batch of R vectors (degree-major table)
     if (s->dz_U_R != R) {
@@ -1011,113 +1414,11 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
         s->dz_U_R = R;
     }
     if ((int)g->lr_hnu.size() < R) { *why = "no host copy of the basis normalisation"; return RL_OK; }
-    const double* nu = g->lr_hnu.data();
-    // G_d = nu nu^T (.) U_d / eps_d = L_d L_d^T; Li_d = L_d^-1
-    std::vector<std::vector<double>> L(D), Li(D);
-    for (int d = 0; d < D; ++d) {
-        L[d].assign((size_t)R * R, 0.0);
-        for (int i = 0; i < R; ++i)
-            for (int j = 0; j < R; ++j) {
-                const double u = 0.5 * (s->dz_U[((size_t)d * R + i) * R + j] + s->dz_U[((size_t)d * R + j) * R + i]);
-                L[d][(size_t)i * R + j] = nu[i] * nu[j] * u / eps[d];
-            }
-        if (!dz_chol(L[d], R)) { *why = "an output has too few (or degenerate) rows for the basis"; return RL_OK; }
-        for (int i = 0; i < R; ++i)
-            for (int j = i + 1; j < R; ++j) L[d][(size_t)i * R + j] = 0.0;
-        dz_tri_inverse(L[d], R, Li[d]);
-    }
-    // S = I + L^T M L, M_ab = sum_q B_q[a][b] C_q  (C symmetrised)
-    std::vector<double> S((size_t)Dr * Dr, 0.0);
-    dz_parallel(D, 1, [&](int first, int step) {
-      std::vector<double> Mab((size_t)R * R), T1((size_t)R * R);
-      for (int a = first; a < D; a += step)
-        for (int b = 0; b <= a; ++b) {
-            std::fill(Mab.begin(), Mab.end(), 0.0);
-            bool any = false;
-            for (int q = 0; q < Q; ++q) {
-                const double bq = 0.5 * (g->lr_hB[((size_t)q * D + a) * D + b] + g->lr_hB[((size_t)q * D + b) * D + a]);
-                if (bq == 0.0) continue;
-                any = true;
-                const double* C = hC + (size_t)q * R * R;
-                for (int i = 0; i < R; ++i)
-                    for (int j = 0; j < R; ++j)
-                        Mab[(size_t)i * R + j] += bq * 0.5 * (C[(size_t)i * R + j] + C[(size_t)j * R + i]);
-            }
-            if (!any) continue;
-            // T1 = M_ab L_b   (L_b lower: column j of L_b has rows >= j)
-            for (int i = 0; i < R; ++i)
-                for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = j; k < R; ++k) acc += Mab[(size_t)i * R + k] * L[b][(size_t)k * R + j];
-                    T1[(size_t)i * R + j] = acc;
-                }
-            // A_ab = L_a^T T1
-            for (int i = 0; i < R; ++i)
-                for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = i; k < R; ++k) acc += L[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
-                    S[((size_t)a * R + i) * Dr + (size_t)b * R + j] = acc;
-                    S[((size_t)b * R + j) * Dr + (size_t)a * R + i] = acc;
-                }
-        }
-    });
-    for (int i = 0; i < Dr; ++i)
-        for (int j = 0; j < i; ++j) {
-            const double v = 0.5 * (S[(size_t)i * Dr + j] + S[(size_t)j * Dr + i]);
-            S[(size_t)i * Dr + j] = v;
-            S[(size_t)j * Dr + i] = v;
-        }
-    for (int i = 0; i < Dr; ++i) S[(size_t)i * Dr + i] += 1.0;
-    if (!dz_chol(S, Dr)) { *why = "I + L^T M L is not positive definite (M is not positive semi-definite to roundoff)"; return RL_OK; }
-    double logdet = 0.0, pmin = 1e300, pmax = 0.0;
-    for (int i = 0; i < Dr; ++i) {
-        const double p = S[(size_t)i * Dr + i];
-        logdet += 2.0 * std::log(p);
-        pmin = std::min(pmin, p);
-        pmax = std::max(pmax, p);
-    }
-    for (int d = 0; d < D; ++d) logdet += rows[d] * std::log(eps[d]);
-    // Y = I - S^-1 = I - X^T X, X = chol(S)^-1: with Xt = X^T stored by rows (row c = column c
-    // of X, zero before position c), S^-1[i][j] = Xt[i] . Xt[j] over positions >= max(i, j)
-    std::vector<double> Xt;
-    dz_tri_inverse_t(S, Dr, Xt);
-    std::vector<double> Y((size_t)Dr * Dr, 0.0);
-    dz_parallel(Dr, 32, [&](int first, int step) {
-        for (int i = first; i < Dr; i += step) {
-            const double* xi = Xt.data() + (size_t)i * Dr;
-            for (int j = 0; j <= i; ++j) {
-                const double* xj = Xt.data() + (size_t)j * Dr;
-                const double v = (i == j ? 1.0 : 0.0) - dz_dot(xi + i, xj + i, Dr - i);
-                Y[(size_t)i * Dr + j] = v;
-            }
-        }
-    });
-    for (int i = 0; i < Dr; ++i)
-        for (int j = 0; j < i; ++j) Y[(size_t)j * Dr + i] = Y[(size_t)i * Dr + j];
-    // Z_ab = Li_a^T Y_ab Li_b, scaled:  Zs = -(nu_i / eps_a) Z (nu_j / eps_b)
-    std::vector<double> Zs((size_t)Dr * Dr, 0.0);
-    dz_parallel(D, 1, [&](int first, int step) {
-      std::vector<double> T1((size_t)R * R);
-      for (int a = first; a < D; a += step)
-        for (int b = 0; b <= a; ++b) {
-            // T1 = Y_ab Li_b  (Li_b lower)
-            for (int i = 0; i < R; ++i)
-                for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = j; k < R; ++k)
-                        acc += Y[((size_t)a * R + i) * Dr + (size_t)b * R + k] * Li[b][(size_t)k * R + j];
-                    T1[(size_t)i * R + j] = acc;
-                }
-            for (int i = 0; i < R; ++i)
-                for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = i; k < R; ++k) acc += Li[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
-                    const double v = -(nu[i] / eps[a]) * acc * (nu[j] / eps[b]);
-                    Zs[((size_t)a * R + i) * Dr + (size_t)b * R + j] = v;
-                    Zs[((size_t)b * R + j) * Dr + (size_t)a * R + i] = v;
-                }
-        }
-    });
+    std::vector<double> Zs;
+    double logdet = 0.0, pmin = 1.0, pmax = 1.0;
+    if (!dz_host_map(D, R, Q, s->dz_U.data(), g->lr_hnu.data(), eps, rows, g->lr_hB.data(), hC, Zs, &logdet,
+                     &pmin, &pmax, why))
+        return RL_OK;
     for (double v : Zs)
         if (!std::isfinite(v)) { *why = "the solve map is not finite"; return RL_OK; }
     if (s->dz_Zt_cap < Zs.size()) {
@@ -1142,6 +1443,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
 // out = K~^-1 in (to roundoff), both in internal row order; in and out may not alias
 static int dz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st) {
     rl_gridop* g = s->g;
+    if (s->dz_hz) return hz_apply(s, in, out, nvec, st);
     const int R = g->lr_r, D = g->D;
 #define RL_DZ_PROJ(R_) rp_project_plain<R_>(s, in, nvec, st)
     RL_DZ_RANKS(RL_DZ_PROJ);
@@ -1163,7 +1465,8 @@ extern "C" int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* 
     RL_TRY(dz_ensure(s, &ok, &why));
     // (2: the factorisation inverts the operator's projection on the polynomial subspace -- a
     // preconditioner for rl_solve_pcg; its log det is not the operator's)
-    if (available) *available = ok ? (s->dz_exact ? 1 : 2) : 0;
+    // (3: the same on the 96-function basis of an operator without a polynomial row, hz_* above)
+    if (available) *available = ok ? (s->dz_exact ? 1 : s->dz_hz ? 3 : 2) : 0;
     if (logdet) *logdet = ok && s->dz_exact ? s->dz_logdet : 0.0;
     if (cond) *cond = ok ? s->dz_cond : 0.0;
     if (!ok) (void)fail(RL_OK, std::string("direct solve not available: ") + why);
@@ -1379,6 +1682,7 @@ extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, dou
     RL_TRY(gridop_prepare(g, nrhs));
     if (rp_ok(s, nrhs)) RL_TRY(rp_prepare(s, nrhs));
     RL_TRY(ski_reserve_perm(s, nrhs));
+    if (s->dz_hz) RL_TRY(hz_reserve(s, nrhs));
     const size_t ve = (size_t)nrhs * n;
     if (s->dz_vec_cap < ve) {
         if (s->dz_res) RL_HIP(hipFree(s->dz_res));
@@ -1426,7 +1730,8 @@ extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, dou
     double *r = s->dz_res, *z = s->dz_cor, *p = s->dz_p, *q = s->dz_q;
     std::vector<double> res((size_t)nrhs, 0.0);
     std::vector<int> go((size_t)nrhs, 1), its((size_t)nrhs, 0), stop((size_t)nrhs, 0);
-    trace_once("solve: conjugate gradients preconditioned by the polynomial subspace's Woodbury inverse (rl_solve_pcg)");
+    if (s->dz_hz) trace_once("solve: conjugate gradients preconditioned by the Woodbury inverse on 96 polynomials per output (rl_solve_pcg)");
+    else trace_once("solve: conjugate gradients preconditioned by the polynomial subspace's Woodbury inverse (rl_solve_pcg)");
     RL_HIP(hipMemsetAsync(Xi, 0, ve * sizeof(double), st));
     RL_HIP(hipMemcpyAsync(r, Bi, ve * sizeof(double), hipMemcpyDeviceToDevice, st));
     RL_HIP(hipMemsetAsync(s->dz_scal, 0, (size_t)nrhs * 2 * sizeof(double), st));

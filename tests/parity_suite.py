@@ -2210,6 +2210,73 @@ def functional_kernel_for_synth(p, scale=1.0):
     return fk
 
 
+def _env_set(**kw):
+    """Context manager: debug switches for handles created inside (read at creation)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        saved = {k: os.environ.get(k) for k in kw}
+        os.environ.update({k: str(v) for k, v in kw.items()})
+        try:
+            yield
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+    return cm()
+
+
+def check_precond_hi(m_data=1000):
+    """An operator with NO row in the polynomial form (Matern rows only): from 10^5 rows on (here:
+    RUNLMC_PRECOND_HI_MIN lowered) its preconditioner is the Woodbury inverse on a basis of 96
+    polynomials per output (rl_ski_factor: *available = 3; csrc/rl_solve.hip hz_*), applied by the
+    rank-48 kernels on one half of the table at a time.  Against the dense solve of the oracle's K~:
+    the same solutions, the reference's residual rule met on the explicit residual, in fewer
+    iterations than with the 48 functions (RUNLMC_NO_PRECOND_HI) -- and both far below the Krylov
+    solve's count.  Batches on either side of the small-batch projection (<= 17 vectors) and a
+    parameter update (the map is rebuilt, the basis and the table are not)."""
+    import scipy.linalg as la
+    from runlmc_amd._native import solve_pcg
+    out = {}
+    rng = np.random.RandomState(5)
+    for tag, env in (('hi', dict(RUNLMC_PRECOND_HI_MIN=0)), ('lo', dict(RUNLMC_PRECOND_HI_MIN=0, RUNLMC_NO_PRECOND_HI=1))):
+        with _env_set(**env):
+            p, fk, K, gk, spec, op = _synth_problem_and_oracle(2, 2, m_data, 'matern')
+            ski = K.device_operator()
+            ok, _, cond = ski.factor()
+            assert ok and ski.factor_mode == (3 if tag == 'hi' else 2), (ski.factor_mode, ski.factor_reason)
+            M = K.preconditioner
+            assert M is not None and not M.exact
+            Kd = _dense_spd(op, p.n)
+            cf = la.cho_factor(Kd)
+            for nb in (3, 20):
+                B = np.vstack([p.y] + [rng.randint(0, 2, p.n) * 2.0 - 1 for _ in range(nb - 1)])
+                Xref = la.cho_solve(cf, B.T).T
+                X, it, rs, st = solve_pcg(ski, torch.from_numpy(B).to(ski.device), tol=1e-8)
+                assert np.all(st == 10) and np.all(rs < 1e-8), (st, rs)
+                X = X.cpu().numpy()
+                _close(X, Xref, rel=1e-8)
+                for i in range(0, nb, 7):
+                    assert np.linalg.norm(B[i] - op.matvec(X[i])) < 2e-8
+                out[tag, nb] = int(np.max(it))
+            if tag == 'hi':
+                # a parameter update: new couplings, same rows
+                gk.update(functional_kernel_for_synth(p, scale=1.7), p.grid_dists)
+                spec.coreg_vecs = [np.sqrt(1.7) * a for a in spec.coreg_vecs]
+                spec.coreg_diags = [1.7 * k for k in spec.coreg_diags]
+                op2 = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+                ok, _, _ = ski.factor()
+                assert ok and ski.factor_mode == 3
+                x, it2, rs2 = Iterative.solve(K, p.y, verbose=True, tol=1e-8)
+                assert rs2 < 1e-8 and np.linalg.norm(p.y - op2.matvec(x)) < 2e-8
+                _close(x, la.solve(_dense_spd(op2, p.n), p.y, assume_a='pos'), rel=1e-8)
+                out['hi', 'updated'] = int(it2)
+    assert out['hi', 3] < out['lo', 3] and out['hi', 20] < out['lo', 20], out
+    return out
+
+
 def check_direct_unavailable():
     """Operators outside the polynomial form.  Matern rows (filter form): the factorisation is no
     longer K~^-1 -- rl_solve_direct refuses with RL_ELIMIT, there is no exact log det -- but it

@@ -701,3 +701,53 @@ def test_c5_mix_preconditioned_cg_reaches_the_reference_tolerance(native):
     spec.set_input_dim(1)
     oop = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
     assert np.linalg.norm(B[0] - oop.matvec(X[0].cpu().numpy())) < 1.5e-4
+
+
+def test_c5_matern_larger_basis_preconditioner(native):
+    """C5, Matern rows only (no row in the polynomial form): the preconditioner is the Woodbury
+    inverse on a basis of 192 polynomials per output (rl_ski_factor: *available = 3;
+    csrc/rl_solve.hip hz_*), applied 48 columns at a time by the rank-48 kernels.  All 129 systems
+    end on the reference's residual rule in < 100 iterations (1358 with the handle's 48 functions;
+    MINRES exits at 1194 with a residual of 188), the residuals hold through an independent handle
+    on the transform kernels and, for y, through the oracle's FFT operator; a parameter update
+    rebuilds the map and the solve still converges."""
+    from runlmc_amd.util import synth
+    from runlmc_amd._native import GridOp, SkiOp, solve_pcg
+    from oracle.kernels import StdPeriodicSpec, Matern32Spec
+    D, Q, R, m0, N = synth.CONFIGS['c5']
+    p = synth.make_problem(D, Q, R, m0, kern='matern')
+    tops = synth.tops(p)
+    g = GridOp(p.D, p.m, p.Q)
+    g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
+    s = SkiOp(g, p.W, p.WT)
+    s.set_noise(p.noise, p.lens)
+    ok, _, _ = s.factor()
+    assert ok and s.factor_mode == 3, (s.factor_mode, s.factor_reason)
+    assert sorted(set(g.top_forms()[0])) == [2]
+    rng = np.random.RandomState(4321)
+    B = np.vstack([p.y] + [rng.randint(0, 2, p.n) * 2.0 - 1 for _ in range(N)])
+    Bd = torch.from_numpy(B).to(s.device)
+    X, it, res, st = solve_pcg(s, Bd, tol=1e-4)
+    assert np.all(st == 10) and np.all(res < 1e-4), (res.max(), sorted(set(st)))
+    assert it.max() < 100, it.max()
+    g2 = GridOp(p.D, p.m, p.Q)
+    g2.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
+    g2.set_form_gate(1 << 60)
+    s2 = SkiOp(g2, p.W, p.WT)
+    s2.set_noise(p.noise, p.lens)
+    r2 = (Bd - s2.mvm(X)).norm(dim=1).cpu().numpy()
+    assert np.all(r2 < 1.5e-4), r2.max()
+    spec = KernelSpec(p.D, synth.kernel_objects(p.kern_desc, rbf=RBFSpec, periodic=StdPeriodicSpec,
+                                                matern=Matern32Spec),
+                      list(p.coreg_vecs), list(p.coreg_diags), p.noise)
+    spec.set_input_dim(1)
+    oop = olik.LMCOperatorOracle(spec, p.grid_dists, p.W, p.WT, p.lens)
+    assert np.linalg.norm(B[0] - oop.matvec(X[0].cpu().numpy())) < 1.5e-4
+    # parameter update: couplings scaled; 17 systems (the small-batch projection)
+    g.set_lmc(tops, [np.sqrt(1.5) * a for a in p.coreg_vecs], [1.5 * k for k in p.coreg_diags])
+    g2.set_lmc(tops, [np.sqrt(1.5) * a for a in p.coreg_vecs], [1.5 * k for k in p.coreg_diags])
+    X17, it17, res17, st17 = solve_pcg(s, Bd[:17].contiguous(), tol=1e-4)
+    assert s.factor_mode == 3 or s.factor()[0] and s.factor_mode == 3
+    assert np.all(st17 == 10) and it17.max() < 100, (it17.max(), sorted(set(st17)))
+    r17 = (Bd[:17] - s2.mvm(X17)).norm(dim=1).cpu().numpy()
+    assert np.all(r17 < 1.5e-4), r17.max()

@@ -193,6 +193,10 @@ def test_direct_unavailable():
     ps.check_direct_unavailable()
 
 
+def test_precond_hi():
+    ps.check_precond_hi()
+
+
 def test_direct_golden():
     print(ps.check_direct_golden())
 
