@@ -95,6 +95,7 @@ struct RlKnobs {
     long long precond_hi_min = 100000;   // RUNLMC_PRECOND_HI_MIN: rows from which an operator without a polynomial row
                                       // gets the 96-function preconditioner
     int precond_hi_rank = 192;         // RUNLMC_PRECOND_HI_RANK: its basis size (whole blocks of 48)
+    bool no_precond_hi_mixed = false; // RUNLMC_NO_PRECOND_HI_MIXED: ... but not operators with SOME rows in the polynomial form
     bool no_precond_hi = false;       // RUNLMC_NO_PRECOND_HI: operators without a polynomial row keep the 48-function
                                       // preconditioner (not the 96-function one of rl_solve.hip: hz_*)
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,
@@ -416,6 +417,7 @@ struct rl_ski {
     // the 96-function preconditioner of an operator without a polynomial row (rl_solve.hip: hz_*)
     bool dz_hz = false;                 // the valid factorisation is THAT one (dz_Zt: [D 96][D 96])
     int hz_R = 0;                       // its basis size (blocks of 48; "96" below stands for it)
+    int hz_Ruse = 0;                    // ... of which the current factorisation uses the first hz_Ruse
     bool hz_basis_tried = false;        // basis generated (or found unusable) once per handle
     const char* hz_why = nullptr;       // why the handle has none (decided once)
     std::vector<double> hz_hnu;         // host [96]: normalisation of the basis

@@ -912,12 +912,18 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
             for (int j = i + 1; j < R; ++j) L[d][(size_t)i * R + j] = 0.0;
         dz_tri_inverse(L[d], R, Li[d]);
     }
-    // S = I + L^T M L, M_ab = sum_q B_q[a][b] C_q  (C symmetrised)
+    // S = I + L^T M L, M_ab = sum_q B_q[a][b] C_q  (C symmetrised).  The D (D + 1) / 2 blocks
+    // (a, b <= a) are independent: dealt to the threads in turn (not a thread per a: output D - 1
+    // has D blocks, output 0 one); the inner loops run along rows (k ascending per entry, as a
+    // dot product over k would).
     std::vector<double> S((size_t)Dr * Dr, 0.0);
-    dz_parallel(D, 1, [&](int first, int step) {
-      std::vector<double> Mab((size_t)R * R), T1((size_t)R * R);
-      for (int a = first; a < D; a += step)
-        for (int b = 0; b <= a; ++b) {
+    std::vector<std::pair<int, int>> blocks;
+    for (int a = 0; a < D; ++a)
+        for (int b = 0; b <= a; ++b) blocks.emplace_back(a, b);
+    dz_parallel((int)blocks.size(), 1, [&](int first, int step) {
+      std::vector<double> Mab((size_t)R * R), T1((size_t)R * R), A((size_t)R * R);
+      for (size_t pb = first; pb < blocks.size(); pb += step) {
+            const int a = blocks[pb].first, b = blocks[pb].second;
             std::fill(Mab.begin(), Mab.end(), 0.0);
             bool any = false;
             for (int q = 0; q < Q; ++q) {
@@ -930,22 +936,33 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
                         Mab[(size_t)i * R + j] += bq * 0.5 * (C[(size_t)i * R + j] + C[(size_t)j * R + i]);
             }
             if (!any) continue;
-            // T1 = M_ab L_b   (L_b lower: column j of L_b has rows >= j)
-            for (int i = 0; i < R; ++i)
-                for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = j; k < R; ++k) acc += Mab[(size_t)i * R + k] * L[b][(size_t)k * R + j];
-                    T1[(size_t)i * R + j] = acc;
+            // T1 = M_ab L_b   (L_b lower: row k of L_b has columns <= k)
+            std::fill(T1.begin(), T1.end(), 0.0);
+            for (int i = 0; i < R; ++i) {
+                double* t = T1.data() + (size_t)i * R;
+                for (int k = 0; k < R; ++k) {
+                    const double mk = Mab[(size_t)i * R + k];
+                    const double* l = L[b].data() + (size_t)k * R;
+                    for (int j = 0; j <= k; ++j) t[j] += mk * l[j];
                 }
+            }
             // A_ab = L_a^T T1
+            std::fill(A.begin(), A.end(), 0.0);
+            for (int k = 0; k < R; ++k) {
+                const double* t = T1.data() + (size_t)k * R;
+                for (int i = 0; i <= k; ++i) {
+                    const double lk = L[a][(size_t)k * R + i];
+                    double* o = A.data() + (size_t)i * R;
+                    for (int j = 0; j < R; ++j) o[j] += lk * t[j];
+                }
+            }
             for (int i = 0; i < R; ++i)
                 for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = i; k < R; ++k) acc += L[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
+                    const double acc = A[(size_t)i * R + j];
                     S[((size_t)a * R + i) * Dr + (size_t)b * R + j] = acc;
                     S[((size_t)b * R + j) * Dr + (size_t)a * R + i] = acc;
                 }
-        }
+      }
     });
     for (int i = 0; i < Dr; ++i)
         for (int j = 0; j < i; ++j) {
@@ -982,27 +999,37 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
         for (int j = 0; j < i; ++j) Y[(size_t)j * Dr + i] = Y[(size_t)i * Dr + j];
     // Z_ab = Li_a^T Y_ab Li_b, scaled:  Zs = -(nu_i / eps_a) Z (nu_j / eps_b)
     Zs.assign((size_t)Dr * Dr, 0.0);
-    dz_parallel(D, 1, [&](int first, int step) {
-      std::vector<double> T1((size_t)R * R);
-      for (int a = first; a < D; a += step)
-        for (int b = 0; b <= a; ++b) {
+    dz_parallel((int)blocks.size(), 1, [&](int first, int step) {
+      std::vector<double> T1((size_t)R * R), A((size_t)R * R);
+      for (size_t pb = first; pb < blocks.size(); pb += step) {
+            const int a = blocks[pb].first, b = blocks[pb].second;
             // T1 = Y_ab Li_b  (Li_b lower)
-            for (int i = 0; i < R; ++i)
-                for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = j; k < R; ++k)
-                        acc += Y[((size_t)a * R + i) * Dr + (size_t)b * R + k] * Li[b][(size_t)k * R + j];
-                    T1[(size_t)i * R + j] = acc;
+            std::fill(T1.begin(), T1.end(), 0.0);
+            for (int i = 0; i < R; ++i) {
+                double* t = T1.data() + (size_t)i * R;
+                const double* y = Y.data() + ((size_t)a * R + i) * Dr + (size_t)b * R;
+                for (int k = 0; k < R; ++k) {
+                    const double yk = y[k];
+                    const double* l = Li[b].data() + (size_t)k * R;
+                    for (int j = 0; j <= k; ++j) t[j] += yk * l[j];
                 }
+            }
+            std::fill(A.begin(), A.end(), 0.0);
+            for (int k = 0; k < R; ++k) {
+                const double* t = T1.data() + (size_t)k * R;
+                for (int i = 0; i <= k; ++i) {
+                    const double lk = Li[a][(size_t)k * R + i];
+                    double* o = A.data() + (size_t)i * R;
+                    for (int j = 0; j < R; ++j) o[j] += lk * t[j];
+                }
+            }
             for (int i = 0; i < R; ++i)
                 for (int j = 0; j < R; ++j) {
-                    double acc = 0.0;
-                    for (int k = i; k < R; ++k) acc += Li[a][(size_t)k * R + i] * T1[(size_t)k * R + j];
-                    const double v = -(nu[i] / eps[a]) * acc * (nu[j] / eps[b]);
+                    const double v = -(nu[i] / eps[a]) * A[(size_t)i * R + j] * (nu[j] / eps[b]);
                     Zs[((size_t)a * R + i) * Dr + (size_t)b * R + j] = v;
                     Zs[((size_t)b * R + j) * Dr + (size_t)a * R + i] = v;
                 }
-        }
+      }
     });
     *logdet_out = logdet;
     *pmin_out = pmin;
@@ -1025,6 +1052,7 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
 //     (rp_project_plain<48> / rp_expand_plain<48> with a table argument) around k_dz_mix_blocks.
 // The factorisation is a PRECONDITIONER (rl_solve_pcg): nothing here is exact, and nothing else in
 // the library reads this basis.  ("96" in names and comments below: the smallest such basis.)
+// An operator with SOME rows in the polynomial form (C5 'mix') takes the first 96 of them: hz_try.
 // ---------------------------------------------------------------------------
 static_assert(RL_HZ_BLK == RL_RP_RMAX, "the blocks run the rank-48 kernels");
 // basis size of this handle: the largest number of whole blocks of 48, at most RUNLMC_PRECOND_HI_RANK
@@ -1149,13 +1177,12 @@ static int hz_basis(rl_ski* s) {
     return RL_OK;
 }
 
-// Is the 96-function preconditioner this operator's?  (No polynomial row, a 1-D grid long enough
-// for the basis, rows enough that the factorisation at D * 96 pays: a conjugate-gradient
-// iteration of a 10^5-row system costs tens of microseconds, the host's part here grows as
-// (D * 96)^3 -- 10 ms at D = 4, 0.25 s at D = 10.)
+// Is the larger preconditioner this operator's?  (Not every row in the polynomial form, rows
+// enough -- RUNLMC_PRECOND_HI_MIN, 10^5: below, a conjugate-gradient iteration costs tens of
+// microseconds and the 48 functions' cheaper update wins -- and a basis size that pays, hz_rank.)
 static bool hz_wanted(const rl_ski* s) {
     const rl_gridop* g = s->g;
-    if (s->kn.no_precond_hi || g->lr_ok || g->lr_np > 0) return false;
+    if (s->kn.no_precond_hi || g->lr_ok || (g->lr_np > 0 && s->kn.no_precond_hi_mixed)) return false;
     return hz_rank(s) > 0 && (double)s->n >= (double)s->kn.precond_hi_min;
 }
 
@@ -1167,7 +1194,12 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
     *ok = false;
     RL_TRY(hz_basis(s));
     if (s->hz_why != nullptr) { *why = s->hz_why; return RL_OK; }
-    const int D = g->D, m = g->m, Q = g->Q, R = s->hz_R;
+    // (an operator with SOME rows in the polynomial form is close to its projection already --
+    // C5 'mix': 59 iterations with the operator's own 36 functions, 11 with 96, 4 with 192, and
+    // the update's host time decides: 0.13 s a step with 96 against 0.16 with 192 -- so it uses
+    // the table's first two blocks; the others all of it)
+    const int D = g->D, m = g->m, Q = g->Q, RT = s->hz_R;
+    const int R = g->lr_np > 0 ? std::min(RT, 2 * RL_HZ_BLK) : RT;
     const int nv = (R + D - 1) / D;
     hipStream_t st = nullptr;
     std::vector<double> hC((size_t)Q * R * R), one((size_t)R * R);
@@ -1195,7 +1227,17 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
     }
     std::vector<double> Zs;
     double logdet = 0.0, pmin = 1.0, pmax = 1.0;
-    if (!dz_host_map(D, R, Q, s->hz_U.data(), s->hz_hnu.data(), eps, rows, g->lr_hB.data(), hC.data(), Zs,
+    std::vector<double> Usub;
+    const double* U = s->hz_U.data();
+    if (R != RT) {                              // the leading R x R corner of every output's block
+        Usub.resize((size_t)D * R * R);
+        for (int d = 0; d < D; ++d)
+            for (int i = 0; i < R; ++i)
+                std::memcpy(Usub.data() + ((size_t)d * R + i) * R, s->hz_U.data() + ((size_t)d * RT + i) * RT,
+                            (size_t)R * sizeof(double));
+        U = Usub.data();
+    }
+    if (!dz_host_map(D, R, Q, U, s->hz_hnu.data(), eps, rows, g->lr_hB.data(), hC.data(), Zs,
                      &logdet, &pmin, &pmax, why))
         return RL_OK;
     for (double v : Zs)
@@ -1208,6 +1250,7 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
     RL_HIP(hipMemcpy(s->dz_Zt, Zs.data(), Zs.size() * sizeof(double), hipMemcpyHostToDevice));
     s->dz_logdet = logdet;
     s->dz_cond = (pmax / pmin) * (pmax / pmin);
+    s->hz_Ruse = R;
     *ok = true;
     return RL_OK;
 }
@@ -1215,7 +1258,7 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
 // out = P^-1 in through the 96-function factorisation (dz_apply's other branch)
 static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st) {
     rl_gridop* g = s->g;
-    const int D = g->D, n = s->n, Dr = D * s->hz_R, NB = s->hz_R / RL_HZ_BLK;
+    const int D = g->D, n = s->n, Dr = D * s->hz_Ruse, NB = s->hz_Ruse / RL_HZ_BLK;
     RL_TRY(hz_reserve(s, nvec));
     for (int k = 0; k < NB; ++k)
         rp_project_plain<RL_HZ_BLK>(s, in, nvec, st, s->hz_F + (size_t)k * RL_HZ_BLK * n,
@@ -1388,7 +1431,7 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
         if (hz_ok) {
             s->dz_param_ver = g->param_ver;
             s->dz_noise_ver = s->noise_ver;
-            s->dz_R = s->hz_R;
+            s->dz_R = s->hz_Ruse;
             s->dz_exact = false;
             s->dz_hz = true;
             s->dz_valid = true;

@@ -2228,7 +2228,7 @@ def _env_set(**kw):
     return cm()
 
 
-def check_precond_hi(m_data=1000):
+def check_precond_hi(m_data=1000, kern='matern', Q=2):
     """An operator with NO row in the polynomial form (Matern rows only): from 10^5 rows on (here:
     RUNLMC_PRECOND_HI_MIN lowered) its preconditioner is the Woodbury inverse on a basis of 96
     polynomials per output (rl_ski_factor: *available = 3; csrc/rl_solve.hip hz_*), applied by the
@@ -2236,17 +2236,19 @@ def check_precond_hi(m_data=1000):
     the same solutions, the reference's residual rule met on the explicit residual, in fewer
     iterations than with the 48 functions (RUNLMC_NO_PRECOND_HI) -- and both far below the Krylov
     solve's count.  Batches on either side of the small-batch projection (<= 17 vectors) and a
-    parameter update (the map is rebuilt, the basis and the table are not)."""
+    parameter update (the map is rebuilt, the basis and the table are not).  kern='mix': smooth rows
+    in the polynomial form next to a Matern row -- the first 96 functions of the same basis."""
     import scipy.linalg as la
     from runlmc_amd._native import solve_pcg
     out = {}
     rng = np.random.RandomState(5)
     for tag, env in (('hi', dict(RUNLMC_PRECOND_HI_MIN=0)), ('lo', dict(RUNLMC_PRECOND_HI_MIN=0, RUNLMC_NO_PRECOND_HI=1))):
         with _env_set(**env):
-            p, fk, K, gk, spec, op = _synth_problem_and_oracle(2, 2, m_data, 'matern')
+            p, fk, K, gk, spec, op = _synth_problem_and_oracle(2, Q, m_data, kern)
             ski = K.device_operator()
             ok, _, cond = ski.factor()
             assert ok and ski.factor_mode == (3 if tag == 'hi' else 2), (ski.factor_mode, ski.factor_reason)
+            out['forms'] = [int(f) for f in K.device_operator().grid.top_forms()[0]] if hasattr(K.device_operator(), 'grid') else None
             M = K.preconditioner
             assert M is not None and not M.exact
             Kd = _dense_spd(op, p.n)

@@ -197,6 +197,11 @@ def test_precond_hi():
     ps.check_precond_hi()
 
 
+def test_precond_hi_mixed_rows():
+    out = ps.check_precond_hi(kern='mix', Q=3)
+    assert out['forms'] == [1, 1, 2] or sorted(set(out['forms'])) == [1, 2], out
+
+
 def test_direct_golden():
     print(ps.check_direct_golden())
 
