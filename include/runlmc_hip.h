@@ -277,7 +277,13 @@ int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond);
  * by the reference's rule ||b - K~ x||_2 < tol (the recurrence's residual norm every iteration,
  * the explicit residual before a system is let go), at most maxiter iterations (<= 0: n).
  * BASELINE's 'mix' family (four smooth rows and a Matern row) ends in 4-5 iterations where
- * MINRES runs 590 without meeting the rule; Matern rows alone take ~100.  Also valid with
+ * MINRES runs 590 without meeting the rule; Matern rows alone take ~100.
+ * *available = 3: the same on a LARGER basis of the handle's own -- operators of >= 10^5 rows
+ * not entirely in the polynomial form: up to 192 polynomials per output (as many blocks of 48
+ * as D * R <= 2048, m >= 8 R and n >= 10^5 (D R / 960)^3 allow; 96 of them when some rows are
+ * in the form), table, Gram matrices once per handle, the map per parameter update
+ * (csrc/rl_solve.hip hz_*).  C5 (n = 10^6): Matern rows 38 iterations (48 functions: 1358),
+ * the mix family 11 (59).  Callers treat 2 and 3 alike.  Also valid with
  * *available = 1 (then M is K~^-1 and one iteration suffices: rl_solve_direct is the shorter way).
  *   iters_out / resid_out / istop_out as rl_solve_direct (istop 6: maxiter reached).       */
 int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,

@@ -214,52 +214,74 @@ k_pcg_update(double* __restrict__ x, double* __restrict__ r, const double* __res
 }
 
 // ---------------------------------------------------------------------------
-// k_dz_mix_blocks: the dense map of a factorisation whose basis is NB blocks of RL_HZ_BLK functions
-// (the high-rank preconditioner of operators without a polynomial row, rl_solve.hip: hz_*): the
-// projection ran block by block (k_rp_project<48> on 48 columns of F at a time), so
-//   S[v][(b, 48 k + j)] = sum_{runs c of output b} part[k][c][v][j]
-//   zhat[k][v][a][i]    = sum_f Zt[f][(a, 48 k + i)] S[v][f]        (each block's coefficients a
-//                         standalone [nvec][D][48] array for its expansion)
-//   grid (ceil(nvec / RL_DZ_VB), RL_HZ_SPLIT)   block 256   LDS: S [RL_DZ_VB][D NB 48]
+// The dense map of a factorisation whose basis is NB blocks of RL_HZ_BLK functions (the larger
+// preconditioner, rl_solve.hip: hz_*): the projection ran block by block (k_rp_project<48> on 48
+// columns of F at a time), the map is up to 2048 x 2048 -- one workgroup per four vectors walking all
+// of it (k_dz_mix's scheme: 0.94 ms at C5's 129 x 1920, a quarter of the chip busy) became three
+// launches, ~10x less:
+//   k_hz_sums:    S[v][(b, 48 k + j)] = sum_{runs c of output b} part[k][c][v][j]
+//   k_hz_map:     P[s][v][e] = sum_{f in slice s} Zt[f][e] S[v][f]       (RL_HZ_FS slices of f)
+//   k_hz_collect: zhat[k][v][a][i] = sum_s P[s][v][(a, 48 k + i)]        (fixed order: no atomics)
+// each block's coefficients a standalone [nvec][D][48] array for its expansion.
 // ---------------------------------------------------------------------------
 #define RL_HZ_BLK 48
-#define RL_HZ_SPLIT 4          // workgroups per group of vectors: each a quarter of the output coefficients
+#define RL_HZ_VB 8             // vectors per k_hz_map workgroup
+#define RL_HZ_FS 4             // slices of the contraction index
+#define RL_HZ_FMAX 512         // longest slice (2048 / RL_HZ_FS): S rows in LDS, [f][RL_HZ_VB]
+//   grid (ceil(D R / 256), nvec)   block 256
 static __global__ void __launch_bounds__(256)
-k_dz_mix_blocks(const double* __restrict__ part, const int* __restrict__ run_ptr, int nruns, int nvec,
-                int D, int NB, const double* __restrict__ Zt, double* __restrict__ zhat) {
+k_hz_sums(const double* __restrict__ part, const int* __restrict__ run_ptr, int nruns, int nvec,
+          int D, int NB, double* __restrict__ S) {
+    const int R = NB * RL_HZ_BLK, Dr = D * R;
+    const int e = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (e >= Dr) return;
+    const int b = e / R, jg = e - b * R, k = jg / RL_HZ_BLK, j = jg - k * RL_HZ_BLK;
+    const double* src = part + ((size_t)k * nruns * nvec + v) * RL_HZ_BLK + j;
+    double s = 0.0;
+    for (int c = run_ptr[b]; c < run_ptr[b + 1]; ++c) s += src[(size_t)c * nvec * RL_HZ_BLK];
+    S[(size_t)v * Dr + e] = s;
+}
+//   grid (ceil(D R / 256), ceil(nvec / RL_HZ_VB), RL_HZ_FS)   block 256
+//   LDS: [slice length][RL_HZ_VB] doubles.  A thread owns one output coefficient e of RL_HZ_VB
+//   vectors; Zt rows are read along e (the map is symmetric: Zt = Z).
+static __global__ void __launch_bounds__(256)
+k_hz_map(const double* __restrict__ S, const double* __restrict__ Zt, int nvec, int Dr,
+         double* __restrict__ P) {
     RL_SMEM(smem);
-    double* S = reinterpret_cast<double*>(smem);          // [RL_DZ_VB][Dr]
-    const int tid = threadIdx.x, R = NB * RL_HZ_BLK, Dr = D * R;
-    const int v0 = blockIdx.x * RL_DZ_VB;
-    for (int e = tid; e < Dr; e += 256) {
-        const int b = e / R, jg = e - b * R, k = jg / RL_HZ_BLK, j = jg - k * RL_HZ_BLK;
-        const int c0 = run_ptr[b], c1 = run_ptr[b + 1];
-        const double* pk = part + (size_t)k * nruns * nvec * RL_HZ_BLK;
-#pragma unroll
-        for (int q = 0; q < RL_DZ_VB; ++q) {
-            const int v = v0 + q < nvec ? v0 + q : nvec - 1;
-            const double* src = pk + (size_t)v * RL_HZ_BLK + j;
-            double s = 0.0;
-            for (int c = c0; c < c1; ++c) s += src[(size_t)c * nvec * RL_HZ_BLK];
-            S[q * Dr + e] = s;
-        }
+    double* Sl = reinterpret_cast<double*>(smem);         // [flen][RL_HZ_VB]
+    const int tid = threadIdx.x, e = blockIdx.x * 256 + tid, v0 = blockIdx.y * RL_HZ_VB;
+    const int per = (Dr + gridDim.z - 1) / gridDim.z;
+    const int f0 = blockIdx.z * per, f1 = f0 + per < Dr ? f0 + per : Dr, flen = f1 > f0 ? f1 - f0 : 0;
+    for (int t = tid; t < flen * RL_HZ_VB; t += 256) {
+        const int q = t / flen, f = t - q * flen;             // (consecutive threads: consecutive f)
+        const int v = v0 + q < nvec ? v0 + q : nvec - 1;
+        Sl[f * RL_HZ_VB + q] = S[(size_t)v * Dr + f0 + f];
     }
     __syncthreads();
-    const int per = (Dr + gridDim.y - 1) / gridDim.y;
-    const int e_lo = blockIdx.y * per, e_hi = e_lo + per < Dr ? e_lo + per : Dr;
-    for (int e = e_lo + tid; e < e_hi; e += 256) {
-        double acc[RL_DZ_VB];
+    if (e >= Dr) return;
+    double acc[RL_HZ_VB];
 #pragma unroll
-        for (int q = 0; q < RL_DZ_VB; ++q) acc[q] = 0.0;
-        for (int f = 0; f < Dr; ++f) {
-            const double z = Zt[(size_t)f * Dr + e];
+    for (int q = 0; q < RL_HZ_VB; ++q) acc[q] = 0.0;
+    const double* z = Zt + (size_t)f0 * Dr + e;
+#pragma unroll 4
+    for (int f = 0; f < flen; ++f) {
+        const double zf = z[(size_t)f * Dr];
 #pragma unroll
-            for (int q = 0; q < RL_DZ_VB; ++q) acc[q] = fma(z, S[q * Dr + f], acc[q]);
-        }
-        const int a = e / R, ig = e - a * R, k = ig / RL_HZ_BLK, i = ig - k * RL_HZ_BLK;
-#pragma unroll
-        for (int q = 0; q < RL_DZ_VB; ++q)
-            if (v0 + q < nvec)
-                zhat[(((size_t)k * nvec + v0 + q) * D + a) * RL_HZ_BLK + i] = acc[q];
+        for (int q = 0; q < RL_HZ_VB; ++q) acc[q] = fma(zf, Sl[f * RL_HZ_VB + q], acc[q]);
     }
+#pragma unroll
+    for (int q = 0; q < RL_HZ_VB; ++q)
+        if (v0 + q < nvec) P[((size_t)blockIdx.z * nvec + v0 + q) * Dr + e] = acc[q];
+}
+//   grid (ceil(D R / 256), nvec)   block 256
+static __global__ void __launch_bounds__(256)
+k_hz_collect(const double* __restrict__ P, int nvec, int D, int NB, int slices,
+             double* __restrict__ zhat) {
+    const int R = NB * RL_HZ_BLK, Dr = D * R;
+    const int e = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (e >= Dr) return;
+    double s = 0.0;
+    for (int t = 0; t < slices; ++t) s += P[((size_t)t * nvec + v) * Dr + e];
+    const int a = e / R, ig = e - a * R, k = ig / RL_HZ_BLK, i = ig - k * RL_HZ_BLK;
+    zhat[(((size_t)k * nvec + v) * D + a) * RL_HZ_BLK + i] = s;
 }

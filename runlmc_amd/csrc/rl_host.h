@@ -431,6 +431,8 @@ struct rl_ski {
     double* hz_part = nullptr;          // dev [2][runs][cap][48]
     double* hz_zhat = nullptr;          // dev [2][cap][D][48]
     double* hz_tmp = nullptr;           // dev [cap][n]: the first half's expansion
+    double* hz_S = nullptr;             // dev [cap][D R]: projections summed over the runs
+    double* hz_P = nullptr;             // dev [RL_HZ_FS][cap][D R]: the map's partial products
     size_t hz_vec_cap = 0;
     double dz_logdet = 0.0;             // log det K~ of that factorisation
     double dz_cond = 0.0;               // ratio of the largest to the smallest pivot of chol(S), squared

@@ -1049,7 +1049,8 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
 //   * per parameter update C_q = Phi^T T_q Phi from ONE product of the row with the functions
 //     (rl_gridop_mvm_top) and an R x R block of dot products, then dz_host_map at size D * R;
 //   * per application the 48-function kernels on one block of 48 columns of the table at a time
-//     (rp_project_plain<48> / rp_expand_plain<48> with a table argument) around k_dz_mix_blocks.
+//     (rp_project_plain<48> / rp_expand_plain<48> with a table argument) around the dense map
+//     (k_hz_sums -> k_hz_map -> k_hz_collect, rl_direct.h).
 // The factorisation is a PRECONDITIONER (rl_solve_pcg): nothing here is exact, and nothing else in
 // the library reads this basis.  ("96" in names and comments below: the smallest such basis.)
 // An operator with SOME rows in the polynomial form (C5 'mix') takes the first 96 of them: hz_try.
@@ -1057,7 +1058,7 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
 static_assert(RL_HZ_BLK == RL_RP_RMAX, "the blocks run the rank-48 kernels");
 // basis size of this handle: the largest number of whole blocks of 48, at most RUNLMC_PRECOND_HI_RANK
 // (default RL_HZ_RDEF) and at least two, that
-//   * k_dz_mix_blocks' coefficient rows leave room for in 64 KB of LDS (D * R <= 2048),
+//   * k_hz_map's slices of the coefficient rows are sized for (D * R <= 2048),
 //   * the grid carries (the recurrence keeps its functions orthonormal well past m = 8 R; hz_basis
 //     checks), and
 //   * pays: the host's part of a parameter update grows as (D R)^3 -- measured on the MI355X box's
@@ -1068,7 +1069,7 @@ static_assert(RL_HZ_BLK == RL_RP_RMAX, "the blocks run the rank-48 kernels");
 #define RL_HZ_RDEF 192
 static int hz_rank(const rl_ski* s) {
     const int D = s->g->D;
-    const int lim = (int)(65536 / sizeof(double) / RL_DZ_VB / D) / RL_HZ_BLK * RL_HZ_BLK;
+    const int lim = RL_HZ_FS * RL_HZ_FMAX / D / RL_HZ_BLK * RL_HZ_BLK;
     for (int R = std::min(s->kn.precond_hi_rank / RL_HZ_BLK * RL_HZ_BLK, lim); R >= 2 * RL_HZ_BLK; R -= RL_HZ_BLK) {
         const double f = (double)D * R / 960.0;
         if (s->g->m >= 8 * R && (double)s->n >= 1e5 * f * f * f) return R;
@@ -1092,6 +1093,8 @@ static int hz_reserve(rl_ski* s, int nvec) {
     RL_TRY(hz_grow(&s->hz_part, nb * s->rp_nruns * cap * RL_HZ_BLK));
     RL_TRY(hz_grow(&s->hz_zhat, nb * cap * s->g->D * RL_HZ_BLK));
     RL_TRY(hz_grow(&s->hz_tmp, cap * s->n));
+    RL_TRY(hz_grow(&s->hz_S, cap * s->g->D * s->hz_R));
+    RL_TRY(hz_grow(&s->hz_P, (size_t)RL_HZ_FS * cap * s->g->D * s->hz_R));
     s->hz_vec_cap = cap;
     return RL_OK;
 }
@@ -1263,9 +1266,14 @@ static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStrea
     for (int k = 0; k < NB; ++k)
         rp_project_plain<RL_HZ_BLK>(s, in, nvec, st, s->hz_F + (size_t)k * RL_HZ_BLK * n,
                                     s->hz_part + (size_t)k * s->rp_nruns * nvec * RL_HZ_BLK);
-    RL_LAUNCH(k_dz_mix_blocks, dim3((nvec + RL_DZ_VB - 1) / RL_DZ_VB, RL_HZ_SPLIT), dim3(256),
-              (size_t)RL_DZ_VB * Dr * sizeof(double), st, (const double*)s->hz_part,
-              (const int*)s->rp_run_ptr, s->rp_nruns, nvec, D, NB, (const double*)s->dz_Zt, s->hz_zhat);
+    const dim3 egrid((Dr + 255) / 256, nvec);
+    RL_LAUNCH(k_hz_sums, egrid, dim3(256), 0, st, (const double*)s->hz_part, (const int*)s->rp_run_ptr,
+              s->rp_nruns, nvec, D, NB, s->hz_S);
+    const int per = (Dr + RL_HZ_FS - 1) / RL_HZ_FS;
+    RL_LAUNCH(k_hz_map, dim3((Dr + 255) / 256, (nvec + RL_HZ_VB - 1) / RL_HZ_VB, RL_HZ_FS), dim3(256),
+              (size_t)per * RL_HZ_VB * sizeof(double), st, (const double*)s->hz_S, (const double*)s->dz_Zt,
+              nvec, Dr, s->hz_P);
+    RL_LAUNCH(k_hz_collect, egrid, dim3(256), 0, st, (const double*)s->hz_P, nvec, D, NB, RL_HZ_FS, s->hz_zhat);
     // (a pass over the rows per block, each adding to the one before through the noise term's
     // operand with a diagonal of ones: not in place -- the kernel's pointers are declared not
     // to alias -- but alternating between `out` and one more buffer so that the last lands in out)

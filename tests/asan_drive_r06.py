@@ -5,7 +5,8 @@ over what round 6 added (emulator build): k_dz_mix / k_dz_resid / k_dz_norms / k
 host factorisation (rl_ski_factor, rl_solve_direct, rl_ski_project), k_lr_small_project / k_lr_small_expand on odd
 and even grids and D above / below the segment count, k_lr_coeffs (rl_gridop_project), the preconditioned CG
 (k_pcg_head / k_pcg_p / k_pcg_update, lr_all_coeffs on filter rows), the transposed weight table of k_sf_carries2,
-the host helpers rl_probes_to_int8 (strided rows, several threads) and rl_slq_log_quadrature."""
+the host helpers rl_probes_to_int8 (strided rows, several threads) and rl_slq_log_quadrature; the larger
+preconditioner basis (hz_*, k_hz_*)."""
 import ctypes, os, sys
 os.environ['RUNLMC_DEBUG'] = '1'
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
@@ -48,6 +49,22 @@ print('factor (matern)', sm.factor(), sm.factor_mode, gm.top_forms())
 Bm = torch.from_numpy(np.vstack([pm.y] + [rng.randint(0, 2, pm.n) * 2.0 - 1 for _ in range(4)]))
 Xm, itm, rsm, stm = solve_pcg(sm, Bm, tol=1e-8)
 print('pcg', itm, rsm, stm)
+# 3b. the larger preconditioner basis (96 functions here: m >= 768; hz_* in rl_solve.hip, k_hz_sums / k_hz_map /
+#     k_hz_collect, the table arguments of k_rp_project<48> / k_rp_expand<48>): Matern rows alone, then mixed rows
+os.environ['RUNLMC_PRECOND_HI_MIN'] = '0'
+for kern, Qh in (('matern', 2), ('mix', 3)):
+    ph = synth.make_problem(3, Qh, 1, 811, kern=kern)
+    gh = GridOp(ph.D, ph.m, ph.Q); gh.set_lmc(synth.tops(ph), list(ph.coreg_vecs), list(ph.coreg_diags))
+    sh = SkiOp(gh, ph.W, ph.WT); sh.set_noise(ph.noise, ph.lens)
+    print('factor (%s, larger basis)' % kern, sh.factor(), sh.factor_mode, gh.top_forms())
+    for nb in (2, 19):
+        Bh = torch.from_numpy(np.vstack([ph.y] + [rng.randint(0, 2, ph.n) * 2.0 - 1 for _ in range(nb - 1)]))
+        Xh, ith, rsh, sth = solve_pcg(sh, Bh, tol=1e-8)
+        print('pcg', nb, ith.max(), rsh.max(), sorted(set(int(v) for v in sth)))
+    gh.set_lmc(synth.tops(ph), [1.3 * a for a in ph.coreg_vecs], list(ph.coreg_diags))
+    print('after an update', sh.factor(), sh.factor_mode)
+    del sh, gh
+os.environ.pop('RUNLMC_PRECOND_HI_MIN')
 gm.set_form_gate(0)
 Xg = rng.randn(4, pm.D * pm.m)
 print('filter product (gate 0)', np.abs(gm.matmat_host(Xg)).max())

@@ -11,7 +11,7 @@ echo "== $tag: $*"
 tail -n 3 $O/run_$tag.log | grep -v "rocprofv3\]" | cut -c1-400
 if [ -n "$f" ] && [ -f "$f" ]; then
   cp "$f" $O/kernel_stats_$tag.csv
-  python3 - "$f" <<'PY' < /dev/null
+  python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:14]:
