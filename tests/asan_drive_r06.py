@@ -53,7 +53,7 @@ print('pcg', itm, rsm, stm)
 #     k_hz_collect, the table arguments of k_rp_project<48> / k_rp_expand<48>): Matern rows alone, then mixed rows
 os.environ['RUNLMC_PRECOND_HI_MIN'] = '0'
 for kern, Qh in (('matern', 2), ('mix', 3)):
-    ph = synth.make_problem(3, Qh, 1, 811, kern=kern)
+    ph = synth.make_problem(3, Qh, 1, 1001, kern=kern)
     gh = GridOp(ph.D, ph.m, ph.Q); gh.set_lmc(synth.tops(ph), list(ph.coreg_vecs), list(ph.coreg_diags))
     sh = SkiOp(gh, ph.W, ph.WT); sh.set_noise(ph.noise, ph.lens)
     print('factor (%s, larger basis)' % kern, sh.factor(), sh.factor_mode, gh.top_forms())
