@@ -157,6 +157,81 @@ def test_two_rank_direct_path():
     assert abs(got[0][4] - ll_ref) <= 1e-12 * abs(ll_ref)
 
 
+def _grads_matern(world_group=None):
+    """A step on a synthetic problem whose rows are all Matern (filter form): the solves run
+    conjugate gradients preconditioned on the larger basis (RUNLMC_PRECOND_HI_MIN lowered)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ['RUNLMC_DEBUG'] = '1'
+    os.environ['RUNLMC_PRECOND_HI_MIN'] = '0'
+    from runlmc_amd.util import synth
+    from runlmc_amd.lmc.grid_kernel import gen_grid_kernel
+    from runlmc_amd.lmc.likelihood import ApproxLMCLikelihood
+    from runlmc_amd.lmc.stochastic_deriv import StochasticDerivService
+    p = synth.make_problem(2, 2, 1, 1000, kern='matern')
+    fk = synth.functional_kernel(p)
+    ad = (0,)
+    K, _ = gen_grid_kernel(fk, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.lens)
+    assert K.device_operator().factor()[0] and K.device_operator().factor_mode == 3
+    rs = np.random.RandomState(5).randint(0, 2, (6, p.n)) * 2 - 1
+    svc = StochasticDerivService(None, None, len(rs), 1e-9, group=world_group)
+    lik = ApproxLMCLikelihood(fk, K, {ad: p.grid_dists}, {ad: (p.W, p.WT)}, p.Ys, svc, probes=rs)
+    assert lik.deriv.lanczos is None and lik.deriv.logdet_exact is None   # the preconditioned path answered
+    flat = np.concatenate([np.ravel(g) for g in lik.coreg_vec_gradients()] +
+                          [np.ravel(g) for g in lik.coreg_diags_gradients()] +
+                          [np.ravel(g) for g in lik.kernel_gradients()] +
+                          [lik.noise_gradient()])
+    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy()
+
+
+def _worker_matern(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.EMU_LIB)
+    flat, nloc, alpha = _grads_matern()
+    q.put((rank, flat, nloc, alpha))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_preconditioned_path():
+    """Probe sharding when the solves are conjugate gradients preconditioned by the factorisation on
+    the larger basis (Matern rows; csrc/rl_solve.hip hz_*): every rank builds its replica's basis,
+    table and map, solves alpha and its share of the probes; the same bits on both ranks, the
+    one-rank step's gradient to 1e-7 of its largest entry (solves to 1e-9 -- a system's
+    iterates do not depend on which systems share its batch, its exit does not either)."""
+    from runlmc_amd import _lib, build
+    _lib.use_library(build.build_emu())
+    saved = {k: os.environ.get(k) for k in ('RUNLMC_DEBUG', 'RUNLMC_PRECOND_HI_MIN')}
+    try:
+        ref, nall, alpha_ref = _grads_matern()
+    finally:
+        _lib.use_library(None)
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_matern, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert got[0][2] + got[1][2] == nall
+    assert np.array_equal(got[0][3], got[1][3])            # alpha: rank 0's, broadcast
+    assert np.array_equal(got[0][1], got[1][1])            # the assembled gradient
+    assert np.abs(got[0][1] - ref).max() < 1e-7 * np.abs(ref).max()
+    assert np.abs(got[0][3] - alpha_ref).max() < 1e-8 * np.abs(alpha_ref).max()
+
+
 def _grads_n(n_probes):
     """The step on `lmc_small` with a seeded matrix of n_probes probes (every rank draws the
     same matrix and keeps its own rows: rank, rank + world, ...)."""
