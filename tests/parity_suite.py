@@ -2276,6 +2276,33 @@ def check_precond_hi(m_data=1000, kern='matern', Q=2):
                 _close(x, la.solve(_dense_spd(op2, p.n), p.y, assume_a='pos'), rel=1e-8)
                 out['hi', 'updated'] = int(it2)
     assert out['hi', 3] < out['lo', 3] and out['hi', 20] < out['lo', 20], out
+    if kern == 'matern':
+        # the caller's rows in any order (one noise level): the handle sorts them, the table and the
+        # solves live in its own order, the answers come back in the caller's
+        from runlmc_amd._native import GridOp, SkiOp
+        from runlmc_amd.util import synth
+        with _env_set(RUNLMC_PRECOND_HI_MIN=0):
+            tops = synth.tops(p)
+            perm = rng.permutation(p.n)
+            W = p.W.tocsr()[perm]
+            WT = W.transpose().tocsr()
+            WT.sort_indices()
+            g = GridOp(p.D, p.m, p.Q)
+            g.set_lmc(tops, list(p.coreg_vecs), list(p.coreg_diags))
+            s = SkiOp(g, W, WT)
+        s.set_noise(np.full(p.D, 0.07), p.lens)
+        ok, _, _ = s.factor()
+        assert ok and s.factor_mode == 3, (s.factor_mode, s.factor_reason)
+        Bs = ops.coreg_mats(list(p.coreg_vecs), list(p.coreg_diags))
+        toeps = [ops.BTTBOracle(t) for t in tops]
+        B = rng.randn(3, p.n)
+        X, it, rs, st = solve_pcg(s, torch.from_numpy(B).to(s.device), tol=1e-8)
+        assert np.all(st == 10)
+        X = X.cpu().numpy()
+        for i in range(3):
+            r = B[i] - (W @ ops.grid_sum_matvec(Bs, toeps, WT @ X[i]) + 0.07 * X[i])
+            assert np.linalg.norm(r) < 2e-8, np.linalg.norm(r)
+        out['permuted'] = int(np.max(it))
     return out
 
 
