@@ -280,8 +280,9 @@ int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond);
  * MINRES runs 590 without meeting the rule; Matern rows alone take ~100.
  * *available = 3: the same on a LARGER basis of the handle's own -- operators of >= 10^5 rows
  * not entirely in the polynomial form: up to 192 polynomials per output (as many blocks of 48
- * as D * R <= 2048, m >= 8 R and n >= 10^5 (D R / 960)^3 allow; 96 of them when some rows are
- * in the form), table, Gram matrices once per handle, the map per parameter update
+ * as D * R <= 2048, m >= 8 R and n >= 10^5 (D R / 960)^3 allow; a factorisation uses the
+ * first blocks that hold all but 1e-5 of every row's trace), table, Gram matrices once per
+ * handle, the map per parameter update
  * (csrc/rl_solve.hip hz_*).  C5 (n = 10^6): Matern rows 38 iterations (48 functions: 1358),
  * the mix family 11 (59).  Callers treat 2 and 3 alike.  Also valid with
  * *available = 1 (then M is K~^-1 and one iteration suffices: rl_solve_direct is the shorter way).

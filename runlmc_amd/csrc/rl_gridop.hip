@@ -103,6 +103,7 @@ RlKnobs read_knobs() {
     k.no_precond_hi_mixed = flag("RUNLMC_NO_PRECOND_HI_MIXED");
     k.precond_hi_min = num("RUNLMC_PRECOND_HI_MIN", 100000);
     k.precond_hi_rank = (int)num("RUNLMC_PRECOND_HI_RANK", 192);
+    k.precond_hi_use = (int)num("RUNLMC_PRECOND_HI_USE", 0);
     k.rp_fly = (int)num("RUNLMC_RP_FLY", 1);
     k.no_rp_small = flag("RUNLMC_NO_RP_SMALL");
     k.no_rp_fuse = flag("RUNLMC_NO_RP_FUSE");

@@ -94,6 +94,7 @@ struct RlKnobs {
     bool no_precond_approx = false;   // RUNLMC_NO_PRECOND_APPROX: no preconditioner for operators outside the polynomial form
     long long precond_hi_min = 100000;   // RUNLMC_PRECOND_HI_MIN: rows from which an operator without a polynomial row
                                       // gets the 96-function preconditioner
+    int precond_hi_use = 0;           // RUNLMC_PRECOND_HI_USE: functions of it a factorisation uses (0: the library's rule)
     int precond_hi_rank = 192;         // RUNLMC_PRECOND_HI_RANK: its basis size (whole blocks of 48)
     bool no_precond_hi_mixed = false; // RUNLMC_NO_PRECOND_HI_MIXED: ... but not operators with SOME rows in the polynomial form
     bool no_precond_hi = false;       // RUNLMC_NO_PRECOND_HI: operators without a polynomial row keep the 48-function
@@ -417,6 +418,7 @@ struct rl_ski {
     // the 96-function preconditioner of an operator without a polynomial row (rl_solve.hip: hz_*)
     bool dz_hz = false;                 // the valid factorisation is THAT one (dz_Zt: [D 96][D 96])
     int hz_R = 0;                       // its basis size (blocks of 48; "96" below stands for it)
+    bool hz_traced = false;
     int hz_Ruse = 0;                    // ... of which the current factorisation uses the first hz_Ruse
     bool hz_basis_tried = false;        // basis generated (or found unusable) once per handle
     const char* hz_why = nullptr;       // why the handle has none (decided once)

@@ -1053,7 +1053,7 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
 //     (k_hz_sums -> k_hz_map -> k_hz_collect, rl_direct.h).
 // The factorisation is a PRECONDITIONER (rl_solve_pcg): nothing here is exact, and nothing else in
 // the library reads this basis.  ("96" in names and comments below: the smallest such basis.)
-// An operator with SOME rows in the polynomial form (C5 'mix') takes the first 96 of them: hz_try.
+// A factorisation uses the first blocks of the table that hold all but 1e-5 of every row: hz_try.
 // ---------------------------------------------------------------------------
 static_assert(RL_HZ_BLK == RL_RP_RMAX, "the blocks run the rank-48 kernels");
 // basis size of this handle: the largest number of whole blocks of 48, at most RUNLMC_PRECOND_HI_RANK
@@ -1197,37 +1197,63 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
     *ok = false;
     RL_TRY(hz_basis(s));
     if (s->hz_why != nullptr) { *why = s->hz_why; return RL_OK; }
-    // (an operator with SOME rows in the polynomial form is close to its projection already --
-    // C5 'mix': 59 iterations with the operator's own 36 functions, 11 with 96, 4 with 192, and
-    // the update's host time decides: 0.13 s a step with 96 against 0.16 with 192 -- so it uses
-    // the table's first two blocks; the others all of it)
     const int D = g->D, m = g->m, Q = g->Q, RT = s->hz_R;
-    const int R = g->lr_np > 0 ? std::min(RT, 2 * RL_HZ_BLK) : RT;
-    const int nv = (R + D - 1) / D;
+    int R = RT;
+    const int nv = (RT + D - 1) / D;
     hipStream_t st = nullptr;
-    std::vector<double> hC((size_t)Q * R * R), one((size_t)R * R);
-    const unsigned nb = ((R + RL_XD_A - 1) / RL_XD_A) * ((R + RL_XD_B - 1) / RL_XD_B);
+    std::vector<double> hCT((size_t)Q * RT * RT), one((size_t)RT * RT);
+    std::vector<double> capb((size_t)Q * (RT / RL_HZ_BLK), 0.0);      // captured by the first 48 (k + 1) functions
+    const unsigned nb = ((RT + RL_XD_A - 1) / RL_XD_A) * ((RT + RL_XD_B - 1) / RL_XD_B);
     for (int q = 0; q < Q; ++q) {
         RL_TRY(rl_gridop_mvm_top(g, q, s->hz_phi, s->hz_tphi, nv, st));
         RL_LAUNCH(k_cross_dots_tiled, dim3(nb, 1), dim3(RL_SOLVER_THREADS), RL_SOLVER_THREADS * sizeof(double),
-                  st, (const double*)s->hz_phi, (const double*)s->hz_tphi, R, m, s->hz_C);
+                  st, (const double*)s->hz_phi, (const double*)s->hz_tphi, RT, m, s->hz_C);
         RL_HIP(hipGetLastError());
         RL_HIP(hipMemcpy(one.data(), s->hz_C, one.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double t0 = g->h_tops.size() > (size_t)q * m ? g->h_tops[(size_t)q * m] : 0.0;
         double tr = 0.0;
-        double* dst = hC.data() + (size_t)q * R * R;
-        for (int i = 0; i < R; ++i) {
-            tr += one[(size_t)i * R + i];
-            for (int j = 0; j < R; ++j) {
-                dst[(size_t)i * R + j] = 0.5 * (one[(size_t)i * R + j] + one[(size_t)j * R + i]);
-                if (!std::isfinite(dst[(size_t)i * R + j])) { *why = "a top row's projection is not finite"; return RL_OK; }
+        double* dst = hCT.data() + (size_t)q * RT * RT;
+        for (int i = 0; i < RT; ++i) {
+            tr += one[(size_t)i * RT + i];
+            if ((i + 1) % RL_HZ_BLK == 0) capb[(size_t)q * (RT / RL_HZ_BLK) + i / RL_HZ_BLK] = t0 > 0.0 ? tr / (t0 * m) : 0.0;
+            for (int j = 0; j < RT; ++j) {
+                dst[(size_t)i * RT + j] = 0.5 * (one[(size_t)i * RT + j] + one[(size_t)j * RT + i]);
+                if (!std::isfinite(dst[(size_t)i * RT + j])) { *why = "a top row's projection is not finite"; return RL_OK; }
             }
         }
-        const double t0 = g->h_tops.size() > (size_t)q * m ? g->h_tops[(size_t)q * m] : 0.0;
         if (!(t0 > 0.0 && tr / (t0 * m) >= 0.8)) {
             *why = "the larger subspace holds less than 0.8 of a row's spectrum either";
             return RL_OK;
         }
     }
+    if (getenv("RUNLMC_TRACE") != nullptr && !s->hz_traced) {
+        s->hz_traced = true;
+        for (int q = 0; q < Q; ++q) {
+            fprintf(stderr, "[runlmc] larger basis: row %d (form %d) holds", q, (int)g->top_form.size() > q ? g->top_form[q] : -1);
+            for (int k = 0; k < RT / RL_HZ_BLK; ++k) fprintf(stderr, " %.6f", capb[(size_t)q * (RT / RL_HZ_BLK) + k]);
+            fprintf(stderr, " of its trace in the first 48, 96 ... functions\n");
+        }
+    }
+    // How many of the functions this factorisation uses.  Iterations fall with the basis, the
+    // host's part of the update grows as (D R)^3: where that part is small (D R <= 960: under
+    // 50 ms) all of them; else the fewest blocks that leave at most 1e-5 of every row's trace
+    // outside (the tail is what conjugate gradients have to resolve), else all.  Measured --
+    // C5 'mix' (Matern gamma = 1 next to four smooth rows: < 5e-7 outside 96 functions): 11
+    // iterations / 0.13 s a step with 96, 6 / 0.13 with 144, 4 / 0.16 with 192 (59 with the
+    // operator's own 36); C5 matern (gamma up to 10: 1.8e-4 outside 96, 2.3e-5 outside 192): 220 /
+    // 77 / 38 iterations, 1.6 / 0.76 / 0.50 s; a D = 3 fit with a gamma = 20 row (1.4e-3 outside 96):
+    // 98 / 50 / 23 iterations, 73 / 58 / 50 ms a step.
+    if ((double)D * RT > 960.0)
+        for (int k = 2; k < RT / RL_HZ_BLK; ++k) {
+            double worst = 1.0;
+            for (int q = 0; q < Q; ++q) worst = std::min(worst, capb[(size_t)q * (RT / RL_HZ_BLK) + k - 1]);
+            if (worst >= 1.0 - 1e-5) { R = k * RL_HZ_BLK; break; }
+        }
+    if (s->kn.precond_hi_use > 0) R = std::max(2 * RL_HZ_BLK, std::min(RT, s->kn.precond_hi_use / RL_HZ_BLK * RL_HZ_BLK));
+    std::vector<double> hC((size_t)Q * R * R);
+    for (int q = 0; q < Q; ++q)
+        for (int i = 0; i < R; ++i)
+            std::memcpy(hC.data() + ((size_t)q * R + i) * R, hCT.data() + ((size_t)q * RT + i) * RT, (size_t)R * sizeof(double));
     std::vector<double> Zs;
     double logdet = 0.0, pmin = 1.0, pmax = 1.0;
     std::vector<double> Usub;
