@@ -495,13 +495,19 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
                                 ('SciPy 1.15 exits' if scipy_exits else 'reference residual rule only')),
                         nll=float(-ll), logdet=float(logdet),
                         logdet_kind=('exact: determinant lemma on the factorisation' if direct else
-                                     'none on this path (see nll_grad_krylov)' if pcg else
+                                     ('log det P exactly (determinant lemma on the preconditioner) + preconditioned '
+                                      'stochastic Lanczos quadrature of tr log(P^-1/2 K~ P^-1/2): %d extra conjugate-gradient '
+                                      'solves of +-1 rows mapped to covariance P (rl_ski_precond_sample, '
+                                      'rl_solve_pcg_lanczos)' % K.preconditioner.LOGDET_PROBES) if pcg else
                                      'stochastic Lanczos quadrature from the probe solves'),
                         grad_norm=float(np.linalg.norm(flat_gradient(g))),
                         # a few entries, so that runs can be compared with each other
                         grad_sample=[float(v) for v in np.concatenate(
                             [np.ravel(g[3]), np.ravel(g[1][0]), np.ravel(g[0][0])])[:12]])
             info['seconds_loglik'] = el - (t1 - t0)
+            if pcg and lik.deriv.logdet_precond is not None:
+                info['logdet_sem'] = float(lik.deriv.logdet_precond[1])
+                info['logdet_solves_iterations_max'] = int(np.max(lik.deriv.logdet_precond[2]))
             if not direct and not pcg:
                 est = lik.deriv.logdet_probe_estimates()
                 if len(est) > 1:
@@ -817,7 +823,8 @@ def bench_config(name, args, rank, world, dev, steps, warmup, headline):
                 kry['speedup_vs_one_rank'] = one_s / kry['seconds']
             kry.update(n_probes_global=n_probes, eps=eps,
                        gradient_rel_distance_to_default_step=rel_dist(grad_kry, grad_default),
-                       logdet_exact=info['logdet'],
+                       logdet_exact=info['logdet'],            # (exact, or the preconditioned quadrature's)
+                       logdet_default_step_kind=info.get('logdet_kind'),
                        logdet_slq_minus_exact=(kry['logdet'] - info['logdet']
                                                if kry['logdet'] is not None and info['logdet'] is not None
                                                else None))

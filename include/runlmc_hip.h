@@ -289,6 +289,27 @@ int rl_ski_factor(rl_ski* s, int* available, double* logdet, double* cond);
  *   iters_out / resid_out / istop_out as rl_solve_direct (istop 6: maxiter reached).       */
 int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
                  int* iters_out, double* resid_out, int* istop_out, void* stream);
+/* log det K~ on that path (the reference's log_det_K, models/interpolated_llgp.py:262-276, is a dense
+ * Cholesky; rounds 1-5 answered with Lanczos quadrature of the UNpreconditioned solves, which these
+ * operators' solves no longer run):  log det K~ = log det P + tr log(P^-1/2 K~ P^-1/2),  P the
+ * factorised matrix (its log det exact, determinant lemma), the trace by Hutchinson + Gauss
+ * quadrature on the Lanczos matrices conjugate gradients build anyway -- unbiased when the right-hand
+ * sides have covariance P.  The preconditioned operator is close to I, so the estimator's variance
+ * is orders of magnitude below the plain quadrature's: a dozen probes do.
+ * rl_ski_precond_sample: Rout[v] = P^1/2 Win[v]  (P = E^1/2 B B^T E^1/2, B = I + Q (C - I) Q^T from
+ *   the factorisation's own Cholesky factors: one projection, one dense map, one expansion; Win, Rout
+ *   dev [nvec][n], caller's row order; Win rows of identity covariance, e.g. the reference's +-1
+ *   probes), *logdet_p = log det P.  The first call makes the handle keep that map with every later
+ *   factorisation.
+ * rl_solve_pcg_lanczos: rl_solve_pcg that also leaves each system's Lanczos matrix of P^-1/2 K~ P^-1/2
+ *   (lanczos_out host [nrhs][cap][2]: diagonal, off-diagonal; as rl_solve_batch_lanczos) and
+ *   sqnorms_out[v] = r0^T P^-1 r0 -- what rl_slq_log_quadrature takes; at most cap iterations, no
+ *   restarts from explicit residuals.                                                       */
+int rl_ski_precond_sample(rl_ski* s, const double* Win, double* Rout, int nvec, double* logdet_p,
+                          void* stream);
+int rl_solve_pcg_lanczos(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
+                         int* iters_out, double* resid_out, int* istop_out, double* lanczos_out,
+                         int cap, double* sqnorms_out, void* stream);
 /* The pieces of that form, for callers that work in its coefficient space (the gradient's
  * Gram terms: with T = Phi C Phi^T,  u~_a . T v~_b = c_u[a]^T C c_v[b],  c_u = Phi^T W^T u
  * -- runlmc_amd/lmc/likelihood.py; reference loops: lmc/likelihood.py:48-96):

@@ -62,6 +62,8 @@ _SIGNATURES = {
     'rl_gridop_set_rank_hint': [_vp, _i],
     'rl_solve_direct': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp],
     'rl_solve_pcg': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp],
+    'rl_solve_pcg_lanczos': [_vp, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    'rl_ski_precond_sample': [_vp, _vp, _vp, _i, _c_dbl_p, _vp],
     'rl_cross_dots': [_vp, _vp, _i, _i, _i, _vp, _vp],
     'rl_segment_dots': [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 }

@@ -292,6 +292,16 @@ class SkiOp:
                       ctypes.byref(r), self.lib.stream_ptr(self.device))
         return flat[:k * self.grid.D * r.value].reshape(k, self.grid.D, r.value)
 
+    def precond_sample(self, W):
+        """(P^1/2 W rows, log det P): rows of identity covariance (+-1 probes) become rows with the
+        covariance P of the operator's current factorisation (rl_ski_precond_sample)."""
+        W = W.contiguous()
+        out = torch.empty_like(W)
+        ld = ctypes.c_double()
+        self.lib.call('rl_ski_precond_sample', self._h, dev_ptr(W), dev_ptr(out), W.shape[0],
+                      ctypes.byref(ld), self.lib.stream_ptr(self.device))
+        return out, float(ld.value)
+
     def mvm(self, X, out=None):
         if out is None:
             out = torch.empty_like(X)
@@ -382,6 +392,25 @@ def solve_pcg(ski, B, tol=1e-4, maxiter=0):
     ski.lib.call('rl_solve_pcg', ski.handle, dev_ptr(B), dev_ptr(X), k, float(tol), int(maxiter),
                  host_ptr(iters), host_ptr(resid), host_ptr(istop), ski.lib.stream_ptr(ski.device))
     return X, iters, resid, istop
+
+
+def solve_pcg_lanczos(ski, B, tol=1e-4, maxiter=0, cap=1024):
+    """solve_pcg that also returns each system's Lanczos matrix of the PRECONDITIONED operator
+    (host (k, cap, 2): diagonal, off-diagonal) and r0^T P^-1 r0 (rl_solve_pcg_lanczos): what
+    slq_quadratic_forms takes.  Returns (X, iterations, residuals, istop, lanczos, sqnorms)."""
+    k = B.shape[0]
+    X = torch.empty_like(B)
+    iters = np.zeros(k, dtype=np.int32)
+    istop = np.zeros(k, dtype=np.int32)
+    resid = np.zeros(k, dtype=np.float64)
+    lanczos = np.zeros((k, int(cap), 2), dtype=np.float64)
+    sq = np.zeros(k, dtype=np.float64)
+    if k == 0:
+        return X, iters, resid, istop, lanczos, sq
+    ski.lib.call('rl_solve_pcg_lanczos', ski.handle, dev_ptr(B), dev_ptr(X), k, float(tol), int(maxiter),
+                 host_ptr(iters), host_ptr(resid), host_ptr(istop), host_ptr(lanczos), int(cap),
+                 host_ptr(sq), ski.lib.stream_ptr(ski.device))
+    return X, iters, resid, istop, lanczos, sq
 
 
 def slq_quadratic_forms(lanczos, iters, sqnorms, lib=None):

@@ -130,6 +130,19 @@ k_dz_axpy(double* __restrict__ X, const double* __restrict__ T, int n,
 }
 
 // ---------------------------------------------------------------------------
+// k_dz_scale: Y[v][i] = d[i] X[v][i]   (rows scaled by a per-row vector: the 1 / sqrt(eps) in front
+// of the preconditioner's square-root factor, rl_ski_precond_sample).   grid (nblk, nvec)   block 256
+// ---------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256)
+k_dz_scale(const double* __restrict__ X, const double* __restrict__ d, int n, double* __restrict__ Y) {
+    const int v = blockIdx.y;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    const size_t off = (size_t)v * n;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) Y[off + i] = d[i] * X[off + i];
+}
+
+// ---------------------------------------------------------------------------
 // k_dz_coeffs: out[v][b][j] = nu_j sum_{runs c of output b} part[c][v][j] -- the coefficients
 // Phi^T W^T x of a batch on the NORMALISED basis from k_rp_project's partial sums (ascending run
 // order).   grid (nvec)   block 256
@@ -186,7 +199,7 @@ static __global__ void __launch_bounds__(256)
 k_pcg_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
              const double* __restrict__ q, int n, const double* __restrict__ scal,
              const double* __restrict__ partPQ, double* __restrict__ partRR,
-             const int* __restrict__ go) {
+             const int* __restrict__ go, double* __restrict__ rec = nullptr) {
     RL_SMEM(smem);
     double* red = reinterpret_cast<double*>(smem);
     const int rhs = blockIdx.y, nblk = gridDim.x;
@@ -194,6 +207,12 @@ k_pcg_update(double* __restrict__ x, double* __restrict__ r, const double* __res
     double pq = 0.0;
     for (int c = 0; c < nblk; ++c) pq += partPQ[(size_t)rhs * nblk + c];
     const double alpha = scal[2 * rhs] / pq;
+    // (rec: this iteration's row of the recurrence's scalars, [nrhs][2] = (rho, p.q) -- the
+    // Lanczos matrix of the preconditioned operator is made of them, rl_solve_pcg_lanczos)
+    if (rec != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        rec[2 * rhs] = scal[2 * rhs];
+        rec[2 * rhs + 1] = pq;
+    }
     const int per = (n + nblk - 1) / nblk;
     const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     const size_t off = (size_t)rhs * n;

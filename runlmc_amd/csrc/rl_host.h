@@ -416,6 +416,16 @@ struct rl_ski {
     unsigned long long dz_param_ver = 0, dz_noise_ver = 0;
     int dz_R = 0;
     // the 96-function preconditioner of an operator without a polynomial row (rl_solve.hip: hz_*)
+    bool dz_want_sample = false;        // rl_ski_precond_sample was called: factorisations keep the square-root map
+    double* dz_Zh = nullptr;            // dev [D r][D r]: that map, transposed (rl_solve.hip dz_host_map)
+    size_t dz_Zh_cap = 0;
+    bool dz_Zh_valid = false;
+    double* dz_isq = nullptr;           // dev [n]: 1 / sqrt(eps) per row
+    unsigned long long dz_isq_ver = ~0ull;
+    double* dz_smp = nullptr;           // dev [cap][n]: scaled probes
+    size_t dz_smp_cap = 0;
+    double* dz_rec = nullptr;           // dev [cap][nrhs][2]: conjugate gradients' scalars of a recorded run
+    size_t dz_rec_cap = 0;
     bool dz_hz = false;                 // the valid factorisation is THAT one (dz_Zt: [D 96][D 96])
     int hz_R = 0;                       // its basis size (blocks of 48; "96" below stands for it)
     bool hz_traced = false;

@@ -249,7 +249,7 @@ extern "C" int rl_ski_destroy(rl_ski* s) {
                     s->poly_part, s->rp_F, s->rp_Fc, s->rp_runs, s->rp_run_ptr, s->rp_out_end, s->rp_part, s->rp_nrm, s->rp_pp,
                     s->rp_base_c, s->rp_w4_c, s->dz_Zt, s->dz_inv, s->dz_res, s->dz_cor, s->dz_part,
                     s->dz_go, s->dz_p, s->dz_q, s->dz_scal, s->hz_beta, s->hz_phi, s->hz_tphi, s->hz_C,
-                    s->hz_F, s->hz_ones, s->hz_part, s->hz_zhat, s->hz_tmp, s->hz_S, s->hz_P};
+                    s->hz_F, s->hz_ones, s->hz_part, s->hz_zhat, s->hz_tmp, s->hz_S, s->hz_P, s->dz_Zh, s->dz_isq, s->dz_smp, s->dz_rec};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete s;

@@ -896,7 +896,7 @@ static void rp_expand_plain(rl_ski* s, const double* zhat, double* Yp, int nvec,
 static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, const std::vector<double>& eps,
                         const std::vector<int>& rows, const double* hB, const double* hC,
                         std::vector<double>& Zs, double* logdet_out, double* pmin_out, double* pmax_out,
-                        const char** why) {
+                        const char** why, std::vector<double>* Zh_t = nullptr) {
     const int Dr = D * R;
     // G_d = nu nu^T (.) U_d / eps_d = L_d L_d^T; Li_d = L_d^-1
     std::vector<std::vector<double>> L(D), Li(D);
@@ -1031,6 +1031,45 @@ static bool dz_host_map(int D, int R, int Q, const double* U, const double* nu, 
                 }
       }
     });
+    // The square-root factor's map (rl_ski_precond_sample), on request: with Q = E^-1/2 F L^-T
+    // (orthonormal columns) the factorised matrix is E^1/2 (I + Q (S - I) Q^T) E^1/2 and, S = C C^T,
+    //     I + Q (S - I) Q^T = B B^T,   B = I + Q (C - I) Q^T
+    // so  E^1/2 B w = sqrt(eps) w + F_q [Zh F_q^T (w / sqrt(eps))],  Zh = nu L^-T (C - I) L^-1 nu
+    // (block lower triangular, NOT symmetric: stored transposed, the layout the map kernels read).
+    if (Zh_t != nullptr) {
+        Zh_t->assign((size_t)Dr * Dr, 0.0);
+        dz_parallel((int)blocks.size(), 1, [&](int first, int step) {
+          std::vector<double> T1((size_t)R * R), A((size_t)R * R);
+          for (size_t pb = first; pb < blocks.size(); pb += step) {
+                const int a = blocks[pb].first, b = blocks[pb].second;       // a >= b
+                // T1 = (C - I)_ab Li_b   (the diagonal block of C is lower triangular: S's strict
+                // upper part still holds the symmetric matrix's entries -- masked here)
+                std::fill(T1.begin(), T1.end(), 0.0);
+                for (int i = 0; i < R; ++i) {
+                    double* t = T1.data() + (size_t)i * R;
+                    const double* c = S.data() + ((size_t)a * R + i) * Dr + (size_t)b * R;
+                    const int kmax = a == b ? i : R - 1;
+                    for (int k = 0; k <= kmax; ++k) {
+                        const double ck = c[k] - (a == b && k == i ? 1.0 : 0.0);
+                        const double* l = Li[b].data() + (size_t)k * R;
+                        for (int j = 0; j <= k; ++j) t[j] += ck * l[j];
+                    }
+                }
+                std::fill(A.begin(), A.end(), 0.0);
+                for (int k = 0; k < R; ++k) {
+                    const double* t = T1.data() + (size_t)k * R;
+                    for (int i = 0; i <= k; ++i) {
+                        const double lk = Li[a][(size_t)k * R + i];
+                        double* o = A.data() + (size_t)i * R;
+                        for (int j = 0; j < R; ++j) o[j] += lk * t[j];
+                    }
+                }
+                for (int i = 0; i < R; ++i)
+                    for (int j = 0; j < R; ++j)
+                        (*Zh_t)[((size_t)b * R + j) * Dr + (size_t)a * R + i] = nu[i] * A[(size_t)i * R + j] * nu[j];
+          }
+        });
+    }
     *logdet_out = logdet;
     *pmin_out = pmin;
     *pmax_out = pmax;
@@ -1081,6 +1120,20 @@ static int hz_grow(T** p, size_t count) {
     if (*p) RL_HIP(hipFree(*p));
     *p = nullptr;
     RL_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return RL_OK;
+}
+
+// the square-root factor's map of the current factorisation on the device (empty: not asked for)
+static int dz_upload_sample_map(rl_ski* s, const std::vector<double>& Zh) {
+    s->dz_Zh_valid = false;
+    if (Zh.empty()) return RL_OK;
+    if (s->dz_Zh_cap < Zh.size()) {
+        s->dz_Zh_cap = 0;
+        RL_TRY(hz_grow(&s->dz_Zh, Zh.size()));
+        s->dz_Zh_cap = Zh.size();
+    }
+    RL_HIP(hipMemcpy(s->dz_Zh, Zh.data(), Zh.size() * sizeof(double), hipMemcpyHostToDevice));
+    s->dz_Zh_valid = true;
     return RL_OK;
 }
 
@@ -1266,9 +1319,11 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
                             (size_t)R * sizeof(double));
         U = Usub.data();
     }
+    std::vector<double> Zh;
     if (!dz_host_map(D, R, Q, U, s->hz_hnu.data(), eps, rows, g->lr_hB.data(), hC.data(), Zs,
-                     &logdet, &pmin, &pmax, why))
+                     &logdet, &pmin, &pmax, why, s->dz_want_sample ? &Zh : nullptr))
         return RL_OK;
+    RL_TRY(dz_upload_sample_map(s, Zh));
     for (double v : Zs)
         if (!std::isfinite(v)) { *why = "the solve map is not finite"; return RL_OK; }
     if (s->dz_Zt_cap < Zs.size()) {
@@ -1285,7 +1340,11 @@ static int hz_try(rl_ski* s, const std::vector<double>& eps, const std::vector<i
 }
 
 // out = P^-1 in through the 96-function factorisation (dz_apply's other branch)
-static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st) {
+// (map / diag: another dense map and another diagonal than the solve's -- the square-root factor)
+static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st,
+                    const double* map = nullptr, const double* diag = nullptr) {
+    if (map == nullptr) map = s->dz_Zt;
+    if (diag == nullptr) diag = s->dz_inv;
     rl_gridop* g = s->g;
     const int D = g->D, n = s->n, Dr = D * s->hz_Ruse, NB = s->hz_Ruse / RL_HZ_BLK;
     RL_TRY(hz_reserve(s, nvec));
@@ -1297,7 +1356,7 @@ static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStrea
               s->rp_nruns, nvec, D, NB, s->hz_S);
     const int per = (Dr + RL_HZ_FS - 1) / RL_HZ_FS;
     RL_LAUNCH(k_hz_map, dim3((Dr + 255) / 256, (nvec + RL_HZ_VB - 1) / RL_HZ_VB, RL_HZ_FS), dim3(256),
-              (size_t)per * RL_HZ_VB * sizeof(double), st, (const double*)s->hz_S, (const double*)s->dz_Zt,
+              (size_t)per * RL_HZ_VB * sizeof(double), st, (const double*)s->hz_S, map,
               nvec, Dr, s->hz_P);
     RL_LAUNCH(k_hz_collect, egrid, dim3(256), 0, st, (const double*)s->hz_P, nvec, D, NB, RL_HZ_FS, s->hz_zhat);
     // (a pass over the rows per block, each adding to the one before through the noise term's
@@ -1307,7 +1366,7 @@ static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStrea
     for (int k = 0; k < NB; ++k) {
         double* dst = (NB - 1 - k) % 2 == 0 ? out : s->hz_tmp;
         rp_expand_plain<RL_HZ_BLK>(s, s->hz_zhat + (size_t)k * nvec * D * RL_HZ_BLK, dst, nvec,
-                                   k == 0 ? s->dz_inv : s->hz_ones, src, st, s->hz_F + (size_t)k * RL_HZ_BLK * n);
+                                   k == 0 ? diag : (const double*)s->hz_ones, src, st, s->hz_F + (size_t)k * RL_HZ_BLK * n);
         src = dst;
     }
     RL_HIP(hipGetLastError());
@@ -1493,9 +1552,11 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
     if ((int)g->lr_hnu.size() < R) { *why = "no host copy of the basis normalisation"; return RL_OK; }
     std::vector<double> Zs;
     double logdet = 0.0, pmin = 1.0, pmax = 1.0;
+    std::vector<double> Zh;
     if (!dz_host_map(D, R, Q, s->dz_U.data(), g->lr_hnu.data(), eps, rows, g->lr_hB.data(), hC, Zs, &logdet,
-                     &pmin, &pmax, why))
+                     &pmin, &pmax, why, s->dz_want_sample ? &Zh : nullptr))
         return RL_OK;
+    RL_TRY(dz_upload_sample_map(s, Zh));
     for (double v : Zs)
         if (!std::isfinite(v)) { *why = "the solve map is not finite"; return RL_OK; }
     if (s->dz_Zt_cap < Zs.size()) {
@@ -1518,17 +1579,20 @@ static int dz_ensure(rl_ski* s, bool* ok, const char** why) {
 }
 
 // out = K~^-1 in (to roundoff), both in internal row order; in and out may not alias
-static int dz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st) {
+static int dz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStream_t st,
+                    const double* map = nullptr, const double* diag = nullptr) {
     rl_gridop* g = s->g;
-    if (s->dz_hz) return hz_apply(s, in, out, nvec, st);
+    if (s->dz_hz) return hz_apply(s, in, out, nvec, st, map, diag);
+    if (map == nullptr) map = s->dz_Zt;
+    if (diag == nullptr) diag = s->dz_inv;
     const int R = g->lr_r, D = g->D;
 #define RL_DZ_PROJ(R_) rp_project_plain<R_>(s, in, nvec, st)
     RL_DZ_RANKS(RL_DZ_PROJ);
 #undef RL_DZ_PROJ
     RL_LAUNCH(k_dz_mix, dim3((nvec + RL_DZ_VB - 1) / RL_DZ_VB), dim3(256),
               (size_t)RL_DZ_VB * D * R * sizeof(double), st, (const double*)s->rp_part,
-              (const int*)s->rp_run_ptr, nvec, D, R, (const double*)s->dz_Zt, g->lr_zhat);
-#define RL_DZ_EXP(R_) rp_expand_plain<R_>(s, g->lr_zhat, out, nvec, s->dz_inv, in, st)
+              (const int*)s->rp_run_ptr, nvec, D, R, map, g->lr_zhat);
+#define RL_DZ_EXP(R_) rp_expand_plain<R_>(s, g->lr_zhat, out, nvec, diag, in, st)
     RL_DZ_RANKS(RL_DZ_EXP);
 #undef RL_DZ_EXP
     RL_HIP(hipGetLastError());
@@ -1739,13 +1803,16 @@ static bool slq_ql_first_row(std::vector<double>& d, std::vector<double>& e, std
     return true;
 }
 
-extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
-                            int* iters_out, double* resid_out, int* istop_out, void* stream) {
-    if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_pcg: NULL argument");
-    if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_pcg: nrhs < 0");
-    if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_pcg: tol must be > 0");
-    if (nrhs == 0) return RL_OK;
+// The loop of rl_solve_pcg.  lanczos / sqnorms (host [nrhs][cap][2], [nrhs]; both or neither): the run
+// also RECORDS the recurrence's scalars and leaves the Lanczos matrix of the preconditioned operator
+// P^-1/2 K~ P^-1/2 per system -- diagonal and off-diagonal pairs as rl_solve_batch_lanczos leaves
+// MINRES's -- with r0^T P^-1 r0; such a run does not restart from explicit residuals (a restart
+// starts another Krylov space) and ends at cap iterations at the latest.
+static int pcg_core(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
+                    int* iters_out, double* resid_out, int* istop_out, void* stream,
+                    double* lanczos, int cap, double* sqnorms) {
     rl_gridop* g = s->g;
+    const bool record = lanczos != nullptr;
     RL_HIP(hipSetDevice(g->device));
     hipStream_t st = (hipStream_t)stream;
     bool ok = false;
@@ -1754,6 +1821,15 @@ extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, dou
     if (!ok) return fail(RL_ELIMIT, std::string("rl_solve_pcg: no preconditioner for this operator: ") + why);
     const int n = s->n, R = g->lr_r;
     if (maxiter <= 0) maxiter = n;
+    if (record) {
+        maxiter = std::min(maxiter, cap);
+        const size_t need = (size_t)cap * nrhs * 2;
+        if (s->dz_rec_cap < need) {
+            s->dz_rec_cap = 0;
+            RL_TRY(hz_grow(&s->dz_rec, need));
+            s->dz_rec_cap = need;
+        }
+    }
     RL_TRY(rp_prepare(s, std::max(nrhs, R)));
     RL_TRY(ski_reserve(s, nrhs));
     RL_TRY(gridop_prepare(g, nrhs));
@@ -1835,7 +1911,8 @@ extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, dou
         RL_TRY(ski_mvm_int(s, p, q, nrhs, st));                            // q = K~ p
         RL_LAUNCH(k_dot_partial, vgrid, vblk, red, st, (const double*)p, (const double*)q, n, s->dz_part);
         RL_LAUNCH(k_pcg_update, vgrid, vblk, red, st, Xi, r, (const double*)p, (const double*)q, n,
-                  (const double*)s->dz_scal, (const double*)s->dz_part, part2, (const int*)s->dz_go);
+                  (const double*)s->dz_scal, (const double*)s->dz_part, part2, (const int*)s->dz_go,
+                  record ? s->dz_rec + (size_t)k * nrhs * 2 : (double*)nullptr);
         RL_LAUNCH(k_dz_norms, hgrid, hblk, 0, st, (const double*)part2, nblk, nrhs, norms);
         RL_HIP(hipGetLastError());
         RL_HIP(hipMemcpyAsync(res.data(), norms, (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1849,7 +1926,7 @@ extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, dou
             else if (its[v] >= maxiter) { go[v] = 0; stop[v] = 6; }
             else ++active;
         }
-        if (active == 0 && restarts < 3) {
+        if (active == 0 && restarts < 3 && !record) {
             // the recurrence's residuals met the rule: the EXPLICIT residuals decide (the
             // reference's own final check, iterative.py:54); a system whose explicit residual is
             // still above the tolerance goes on from it
@@ -1886,8 +1963,109 @@ extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, dou
         if (resid_out) resid_out[v] = res[v];
         if (istop_out) istop_out[v] = stop[v];
     }
+    if (record) {
+        // conjugate gradients' scalars -> the Lanczos matrix (Saad, Iterative Methods, 6.7.3):
+        //   alpha_j = rho_j / (p_j . q_j),  beta_j = rho_j / rho_{j-1};
+        //   T[j][j] = 1 / alpha_j + beta_j / alpha_{j-1},  T[j][j+1] = sqrt(beta_{j+1}) / alpha_j
+        int kmax = 0;
+        for (int v = 0; v < nrhs; ++v) kmax = std::max(kmax, its[v]);
+        std::vector<double> rec((size_t)std::max(kmax, 1) * nrhs * 2, 0.0);
+        if (kmax > 0)
+            RL_HIP(hipMemcpy(rec.data(), s->dz_rec, (size_t)kmax * nrhs * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int v = 0; v < nrhs; ++v) {
+            double* lz = lanczos + (size_t)v * cap * 2;
+            std::fill(lz, lz + (size_t)cap * 2, 0.0);
+            sqnorms[v] = its[v] > 0 ? rec[2 * (size_t)v] : 0.0;
+            double alpha_prev = 0.0, rho_prev = 0.0;
+            for (int j = 0; j < its[v]; ++j) {
+                const double rho = rec[((size_t)j * nrhs + v) * 2], pq = rec[((size_t)j * nrhs + v) * 2 + 1];
+                const double alpha = rho / pq;
+                const double beta = j > 0 ? rho / rho_prev : 0.0;
+                lz[2 * j] = 1.0 / alpha + (j > 0 ? beta / alpha_prev : 0.0);
+                if (j > 0) lz[2 * (j - 1) + 1] = std::sqrt(beta) / alpha_prev;
+                alpha_prev = alpha;
+                rho_prev = rho;
+            }
+        }
+    }
     return RL_OK;
 }
+
+extern "C" int rl_solve_pcg(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
+                            int* iters_out, double* resid_out, int* istop_out, void* stream) {
+    if (!s || !B || !X) return fail(RL_EINVAL, "rl_solve_pcg: NULL argument");
+    if (nrhs < 0) return fail(RL_EINVAL, "rl_solve_pcg: nrhs < 0");
+    if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_pcg: tol must be > 0");
+    if (nrhs == 0) return RL_OK;
+    return pcg_core(s, B, X, nrhs, tol, maxiter, iters_out, resid_out, istop_out, stream, nullptr, 0, nullptr);
+}
+
+extern "C" int rl_solve_pcg_lanczos(rl_ski* s, const double* B, double* X, int nrhs, double tol, int maxiter,
+                                    int* iters_out, double* resid_out, int* istop_out, double* lanczos_out,
+                                    int cap, double* sqnorms_out, void* stream) {
+    if (!s || !B || !X || !lanczos_out || !sqnorms_out) return fail(RL_EINVAL, "rl_solve_pcg_lanczos: NULL argument");
+    if (nrhs < 0 || cap < 1) return fail(RL_EINVAL, "rl_solve_pcg_lanczos: bad sizes");
+    if (!(tol > 0.0)) return fail(RL_EINVAL, "rl_solve_pcg_lanczos: tol must be > 0");
+    if (nrhs == 0) return RL_OK;
+    return pcg_core(s, B, X, nrhs, tol, maxiter, iters_out, resid_out, istop_out, stream, lanczos_out, cap,
+                    sqnorms_out);
+}
+
+// Rout[v] = E^1/2 B Win[v]: rows of Win with identity covariance (the reference's +-1 probes) become
+// rows with the covariance P of the current (inexact) factorisation -- the right-hand sides whose
+// preconditioned Lanczos quadrature estimates log det (P^-1 K~) without bias.  *logdet_p = log det P.
+extern "C" int rl_ski_precond_sample(rl_ski* s, const double* Win, double* Rout, int nvec, double* logdet_p,
+                                     void* stream) {
+    if (!s || !Win || !Rout) return fail(RL_EINVAL, "rl_ski_precond_sample: NULL argument");
+    if (nvec < 0) return fail(RL_EINVAL, "rl_ski_precond_sample: nvec < 0");
+    rl_gridop* g = s->g;
+    RL_HIP(hipSetDevice(g->device));
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+    const char* why = "";
+    if (!s->dz_want_sample) {
+        s->dz_want_sample = true;          // (from now on every factorisation of this handle keeps the map)
+        s->dz_valid = false;
+    }
+    RL_TRY(dz_ensure(s, &ok, &why));
+    if (!ok) return fail(RL_ELIMIT, std::string("rl_ski_precond_sample: no factorisation for this operator: ") + why);
+    if (!s->dz_Zh_valid) return fail(RL_ELIMIT, "rl_ski_precond_sample: no square-root map");
+    if (logdet_p) *logdet_p = s->dz_logdet;
+    if (nvec == 0) return RL_OK;
+    const int n = s->n;
+    if (s->dz_isq_ver != s->noise_ver || s->dz_isq == nullptr) {
+        std::vector<double> isq((size_t)n);
+        for (int i = 0; i < n; ++i) isq[i] = 1.0 / std::sqrt(s->h_noise[i]);
+        if (!s->dz_isq) RL_HIP(hipMalloc((void**)&s->dz_isq, (size_t)n * sizeof(double)));
+        RL_HIP(hipMemcpy(s->dz_isq, isq.data(), isq.size() * sizeof(double), hipMemcpyHostToDevice));
+        s->dz_isq_ver = s->noise_ver;
+    }
+    RL_TRY(rp_prepare(s, std::max(nvec, g->lr_r)));
+    RL_TRY(ski_reserve_perm(s, nvec));
+    if (s->dz_hz) RL_TRY(hz_reserve(s, nvec));
+    RL_TRY(lr_reserve(g, nvec));
+    const double* Wi = Win;
+    double* Ri = Rout;
+    if (s->permuted) {
+        permute_rows(s, Win, s->P1, nvec, 0, st);
+        Wi = s->P1;
+        Ri = s->P2;
+    }
+    // in = w / sqrt(eps), in a buffer of its own (the apply functions do not alias in and out)
+    const size_t ve = (size_t)nvec * n;
+    if (s->dz_smp_cap < ve) {
+        s->dz_smp_cap = 0;
+        RL_TRY(hz_grow(&s->dz_smp, ve));
+        s->dz_smp_cap = ve;
+    }
+    const int nblk = std::max(1, std::min(RL_DZ_NBLK, (n + 1023) / 1024));
+    RL_LAUNCH(k_dz_scale, dim3(nblk, nvec), dim3(256), 0, st, Wi, (const double*)s->dz_isq, n, s->dz_smp);
+    RL_TRY(dz_apply(s, s->dz_smp, Ri, nvec, st, (const double*)s->dz_Zh, (const double*)s->noise_diag));
+    if (s->permuted) permute_rows(s, Ri, Rout, nvec, 1, st);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 
 // ---------------------------------------------------------------------------
 // Host helper: +-1 probes drawn as the reference draws them (int64) -> one byte per entry

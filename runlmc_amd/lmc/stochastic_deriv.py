@@ -156,12 +156,17 @@ class StochasticDerivService:
         # (no Lanczos coefficients when the operator's preconditioner answered -- its
         # factorisation holds log det K~ exactly instead)
         logdet_exact = None
+        logdet_fn = None
         if lanczos is None:
             M = K.preconditioner
             if M is not None and M.exact:
                 logdet_exact = M.logdet()
-            # (preconditioned CG through an INEXACT factorisation: no Lanczos recurrence of K~ ran
-            # and the factorisation's log det is not the operator's -- logdet_K() says so)
+            elif M is not None:
+                # (preconditioned CG through an INEXACT factorisation: no Lanczos recurrence of K~
+                # ran and the factorisation's log det is not the operator's -- asked for, the log
+                # det comes from a few extra preconditioned solves, FactoredInverse.logdet_estimate)
+                tol = self._tol
+                logdet_fn = lambda: M.logdet_estimate(tol=tol)    # noqa: E731
         else:
             lanczos = lanczos[order]
         if self.metrics is not None:
@@ -176,7 +181,7 @@ class StochasticDerivService:
         broadcast_(alpha, src=0, group=self._group)        # (no-op in a world of one)
         return StochasticDeriv(alpha, B[1:], X[1:], self._n_it, group=self._group,
                                iterations=iters, residuals=resid, istop=istop,
-                               lanczos=lanczos, logdet_exact=logdet_exact)
+                               lanczos=lanczos, logdet_exact=logdet_exact, logdet_fn=logdet_fn)
 
     def _concurrent_solve(self, ls):
         """Reference entry point (stochastic_deriv.py:51-52): a list of
@@ -197,7 +202,7 @@ class StochasticDeriv(Derivative):
     ``n_it`` is the GLOBAL probe count (the 1/N of the estimator)."""
 
     def __init__(self, alpha, rs, inv_rs, n_it, group=None, iterations=None,
-                 residuals=None, istop=None, lanczos=None, logdet_exact=None):
+                 residuals=None, istop=None, lanczos=None, logdet_exact=None, logdet_fn=None):
         to_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(a, dtype=np.float64))
         self.alpha_dev = to_t(alpha)
@@ -208,6 +213,8 @@ class StochasticDeriv(Derivative):
         self.iterations, self.residuals, self.istop = iterations, residuals, istop
         self.lanczos = lanczos
         self.logdet_exact = logdet_exact
+        self._logdet_fn = logdet_fn          # () -> (estimate, sem, iterations), run on first use
+        self.logdet_precond = None           # its result, once asked for
         self._alpha_host = None
 
     @property
@@ -239,10 +246,16 @@ class StochasticDeriv(Derivative):
 
     def logdet_K(self):
         """log det K: exact (determinant lemma, rl_ski_factor) when the solves went
-        through the operator's factorisation, else the Hutchinson + Lanczos-quadrature
-        estimate (mean over all ranks' probes)."""
+        through the operator's factorisation; when that factorisation was a preconditioner, its
+        exact log det plus the preconditioned Lanczos-quadrature estimate of the rest (a few extra
+        solves, run on first use); else the Hutchinson + Lanczos-quadrature estimate from the
+        probe solves (mean over all ranks' probes)."""
         if self.logdet_exact is not None:
             return self.logdet_exact
+        if self.lanczos is None and self._logdet_fn is not None:
+            if self.logdet_precond is None:
+                self.logdet_precond = self._logdet_fn()
+            return self.logdet_precond[0]
         local = self.logdet_probe_estimates()
         tot = torch.tensor([float(local.sum())], dtype=torch.float64)
         all_reduce_sum_(tot, self._group)

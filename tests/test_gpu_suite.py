@@ -197,6 +197,10 @@ def test_precond_hi():
     ps.check_precond_hi()
 
 
+def test_logdet_preconditioned():
+    ps.check_logdet_preconditioned()
+
+
 def test_precond_hi_mixed_rows():
     out = ps.check_precond_hi(kern='mix', Q=3)
     assert out['forms'] == [1, 1, 2] or sorted(set(out['forms'])) == [1, 2], out
