@@ -6,7 +6,7 @@ host factorisation (rl_ski_factor, rl_solve_direct, rl_ski_project), k_lr_small_
 and even grids and D above / below the segment count, k_lr_coeffs (rl_gridop_project), the preconditioned CG
 (k_pcg_head / k_pcg_p / k_pcg_update, lr_all_coeffs on filter rows), the transposed weight table of k_sf_carries2,
 the host helpers rl_probes_to_int8 (strided rows, several threads) and rl_slq_log_quadrature; the larger
-preconditioner basis (hz_*, k_hz_*)."""
+preconditioner basis (hz_*, k_hz_*), the preconditioned log det's sampling and recorded conjugate gradients."""
 import ctypes, os, sys
 os.environ['RUNLMC_DEBUG'] = '1'
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
@@ -61,8 +61,14 @@ for kern, Qh in (('matern', 2), ('mix', 3)):
         Bh = torch.from_numpy(np.vstack([ph.y] + [rng.randint(0, 2, ph.n) * 2.0 - 1 for _ in range(nb - 1)]))
         Xh, ith, rsh, sth = solve_pcg(sh, Bh, tol=1e-8)
         print('pcg', nb, ith.max(), rsh.max(), sorted(set(int(v) for v in sth)))
+    # the preconditioned log det: square-root sampling (k_dz_scale, the second dense map), recorded CG
+    from runlmc_amd._native import solve_pcg_lanczos
+    Wh = torch.from_numpy(rng.randint(0, 2, (5, ph.n)) * 2.0 - 1)
+    Rh, ldp = sh.precond_sample(Wh)
+    Xl, itl, rsl, stl, lzl, sql = solve_pcg_lanczos(sh, Rh, tol=1e-8, cap=64)
+    print('sample + recorded cg', ldp, itl.max(), rsl.max(), slq_quadratic_forms(lzl, itl, sql)[:2])
     gh.set_lmc(synth.tops(ph), [1.3 * a for a in ph.coreg_vecs], list(ph.coreg_diags))
-    print('after an update', sh.factor(), sh.factor_mode)
+    print('after an update', sh.factor(), sh.factor_mode, sh.precond_sample(Wh[:2])[1])
     del sh, gh
 os.environ.pop('RUNLMC_PRECOND_HI_MIN')
 gm.set_form_gate(0)

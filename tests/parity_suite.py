@@ -2672,6 +2672,35 @@ def check_round6_abi_errors():
             raise AssertionError('accepted a bad argument')
         except ValueError:
             pass
+    # rl_ski_precond_sample / rl_solve_pcg_lanczos: argument errors; on an EXACT factorisation the
+    # sampled rows have covariance K~ itself, conjugate gradients end in one iteration and the
+    # quadrature adds nothing to the exact log det
+    from runlmc_amd._native import solve_pcg_lanczos, slq_quadratic_forms
+    W = (torch.randint(0, 2, (3, p.n), dtype=torch.int8) * 2 - 1).to(torch.float64).to(s.device)
+    ldp = ctypes.c_double()
+    Xo = torch.empty_like(W)
+    it3, st3, rs3 = (np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32), np.zeros(3))
+    lz, sq = np.zeros((3, 8, 2)), np.zeros(3)
+    for call in (lambda: lib.call('rl_ski_precond_sample', s.handle, None, dev_ptr(Xo), 3, ctypes.byref(ldp), None),
+                 lambda: lib.call('rl_ski_precond_sample', s.handle, dev_ptr(W), dev_ptr(Xo), -1, ctypes.byref(ldp), None),
+                 lambda: lib.call('rl_solve_pcg_lanczos', s.handle, dev_ptr(W), dev_ptr(Xo), 3, 1e-4, 0, host_ptr(it3),
+                                  host_ptr(rs3), host_ptr(st3), None, 8, host_ptr(sq), None),
+                 lambda: lib.call('rl_solve_pcg_lanczos', s.handle, dev_ptr(W), dev_ptr(Xo), 3, 1e-4, 0, host_ptr(it3),
+                                  host_ptr(rs3), host_ptr(st3), host_ptr(lz), 0, host_ptr(sq), None),
+                 lambda: lib.call('rl_solve_pcg_lanczos', s.handle, dev_ptr(W), dev_ptr(Xo), 3, 0.0, 0, host_ptr(it3),
+                                  host_ptr(rs3), host_ptr(st3), host_ptr(lz), 8, host_ptr(sq), None)):
+        try:
+            call()
+            raise AssertionError('accepted a bad argument')
+        except ValueError:
+            pass
+    Rs, ldP = s.precond_sample(W)
+    assert abs(ldP - ld) <= 1e-12 * abs(ld)
+    Xs, its, rss, sts, lzs, sqs = solve_pcg_lanczos(s, Rs, tol=1e-6, cap=8)
+    assert np.all(its <= 2) and np.all(sts == 10), (its, sts)
+    q = slq_quadratic_forms(lzs, its, sqs, lib=lib)
+    assert np.abs(q).max() <= 1e-6 * p.n, q                 # log(1) per unit of r0^T P^-1 r0 = n
+    _close(sqs, np.full(3, float(p.n)), rel=1e-9)           # r0^T P^-1 r0 = w^T w
     # C_q really is Phi^T T Phi: the form's product of a vector in the subspace
     x = torch.randn(3, p.n, dtype=torch.float64).to(s.device)
     cx = s.project(x)                                   # (3, D, r)
