@@ -1197,6 +1197,14 @@ static int hz_basis(rl_ski* s) {
         for (int j : probe) worst = std::max(worst, std::fabs(dz_dot(last, phi.data() + (size_t)j * m, m)));
         if (!(worst < 1e-9)) { s->hz_why = "the larger basis is not orthonormal on this grid (too few points)"; return RL_OK; }
     }
+    // (the table is R n doubles -- 1.5 GB at C5, 15 GB at n = 10^7: a handle that cannot spare
+    // twice that keeps the 48 functions instead of failing its solves on an allocation)
+    {
+        size_t free_b = 0, total_b = 0;
+        RL_HIP(hipMemGetInfo(&free_b, &total_b));
+        const double need = 2.0 * (double)R * n * sizeof(double) + 2.0 * (double)rows * m * sizeof(double) + 1e9;
+        if ((double)free_b < need) { s->hz_why = "not enough free device memory for the larger basis' table"; return RL_OK; }
+    }
     RL_TRY(upload(&s->hz_phi, phi));
     RL_TRY(upload(&s->hz_beta, beta));
     s->hz_hnu = nu;

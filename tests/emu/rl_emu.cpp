@@ -230,6 +230,12 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+// (host memory stands in for the device's: a fixed, generous answer)
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes) {
+    if (free_bytes) *free_bytes = (size_t)16 << 30;
+    if (total_bytes) *total_bytes = (size_t)32 << 30;
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {

@@ -52,6 +52,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
 
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
 enum { hipHostMallocDefault = 0 };
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void* p);
