@@ -134,16 +134,36 @@ class StochasticDerivService:
                     if dev.type == 'cuda':
                         stage = stage.pin_memory()
                     self._stage = stage
-                ok = ctypes.c_int()
                 lib = _lib.get_library()
+                # The pass over the probes is host work only (ctypes drops the GIL around it) and the
+                # bytes cross the bus on a stream of their own, a few rows' worth at a time: while
+                # both run, this thread has the operator's forms verified and its factorisation
+                # built -- what the solve below would otherwise start with (C5: ~5 ms of a 30 ms step).
+                on_gpu = dev.type == 'cuda'
+                side = torch.cuda.Stream(device=dev) if on_gpu else None
+                dev8 = torch.empty((nm, n), dtype=torch.int8, device=dev)
+                pieces = [(a, min(nm, a + max(1, (nm + 3) // 4))) for a in range(0, nm, max(1, (nm + 3) // 4))]
+                state = {'ok': True, 'error': None}
 
                 def narrow_on_host():
-                    lib.call('rl_probes_to_int8', ctypes.c_void_p(mine_rows.ctypes.data), nm,
-                             mine_rows.strides[0] // 8, n, ctypes.c_void_p(stage.data_ptr()),
-                             max(1, min(_host_cores(), 32)), ctypes.byref(ok))
-                # The pass over the probes is host work only (ctypes drops the GIL around it): while
-                # it runs, this thread has the operator's forms verified and its factorisation built
-                # -- what the solve below would otherwise start with (C5: ~5 ms of a 30 ms step).
+                    try:
+                        for a, b in pieces:
+                            ok = ctypes.c_int()
+                            lib.call('rl_probes_to_int8',
+                                     ctypes.c_void_p(mine_rows.ctypes.data + a * mine_rows.strides[0]), b - a,
+                                     mine_rows.strides[0] // 8, n, ctypes.c_void_p(stage.data_ptr() + a * n),
+                                     max(1, min(_host_cores(), 32)), ctypes.byref(ok))
+                            if not ok.value:
+                                state['ok'] = False
+                                return
+                            src = stage[a * n:b * n].view(b - a, n)
+                            if on_gpu:
+                                with torch.cuda.stream(side):
+                                    dev8[a:b].copy_(src, non_blocking=True)
+                            else:
+                                dev8[a:b].copy_(src)
+                    except Exception as e:              # (re-raised on the caller's thread)
+                        state['error'] = e
                 worker = threading.Thread(target=narrow_on_host)
                 worker.start()
                 try:
@@ -151,8 +171,13 @@ class StochasticDerivService:
                         getattr(K, 'preconditioner', None)
                 finally:
                     worker.join()
-                if ok.value:
-                    narrow = stage[:nm * n].view(nm, n).to(dev, non_blocking=True)
+                if state['error'] is not None:
+                    raise state['error']
+                if on_gpu:
+                    dev8.record_stream(side)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                if state['ok']:
+                    narrow = dev8
             if narrow is not None:
                 Bfull[first:first + nm] = narrow
             else:
