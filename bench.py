@@ -448,7 +448,14 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
                                  scipy_exits=bool(scipy_exits), maxiter=maxiter,
                                  precondition=precondition)
     best, info = None, None
-    for _ in range(repeats + 1):          # first pass warms workspaces and graphs
+    # The first pass warms workspaces and graphs.  A FAST step (through the factorisation: tens of
+    # milliseconds) gets a second untimed pass and at least three timed ones: the likelihood object
+    # of pass k is alive while pass k + 1 allocates its gigabyte of right-hand sides and solutions,
+    # so torch's allocator grows for two passes (hipMalloc: +20-30 ms each) before blocks are
+    # reused -- a fit sees that once, the steady step is what the line reports
+    # (tools/r06_step_times.py: 55, 60, then 28 +- 1 ms over thirty passes; profiles/r06/step_times.txt).
+    warm_left, timed, all_s = 1, 0, []
+    while True:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         gks[ad].update(fk, p.grid_dists)
@@ -468,9 +475,17 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
             logdet = ll = float('nan')
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if info is None:
+        if warm_left > 0:
+            warm_left -= 1
+            # (decided from the solver that answered, not from the clock: every rank must run the
+            # same number of passes -- they hold collectives)
+            if info is None and lik.deriv.lanczos is None:
+                warm_left += 1
+                repeats = max(repeats, 3)
             info = {}
             continue
+        timed += 1
+        all_s.append(el)
         if best is None or el < best:
             best = el
             direct = lik.deriv.logdet_exact is not None
@@ -513,6 +528,10 @@ def gpu_nll_grad(p, probes_local, n_probes_global, group=None, repeats=2, scipy_
                 if len(est) > 1:
                     info['logdet_sem'] = float(est.std(ddof=1) / np.sqrt(len(est)))
                 info['lanczos_steps_kept'] = int(lik.deriv.lanczos.shape[1])
+        if timed >= repeats:
+            break
+    info['seconds_all_timed_passes'] = [float(v) for v in all_s]
+    info['seconds_median'] = float(np.median(all_s))
     if group is not None:
         # the same BITS on every rank?  (64-bit checksums of alpha and of the gradient,
         # max and min over the ranks)

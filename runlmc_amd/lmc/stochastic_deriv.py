@@ -47,6 +47,8 @@ class StochasticDerivService:
         self._scipy_exits = scipy_exits
         self._maxiter = int(maxiter)
         self._precondition = precondition
+        self._side = None          # copy stream and device-side byte buffer of the probe hand-over
+        self._dev8 = None
         # device_probes: None -- probes come from NumPy's global legacy RNG exactly as the
         # reference draws them (stochastic_deriv.py:35; 0.6 s of host time for C5's 128 x 10^6
         # int64 matrix, twenty times the step that uses them); an int -- a seed: every call of
@@ -140,8 +142,18 @@ class StochasticDerivService:
                 # both run, this thread has the operator's forms verified and its factorisation
                 # built -- what the solve below would otherwise start with (C5: ~5 ms of a 30 ms step).
                 on_gpu = dev.type == 'cuda'
-                side = torch.cuda.Stream(device=dev) if on_gpu else None
-                dev8 = torch.empty((nm, n), dtype=torch.int8, device=dev)
+                # (stream and device-side byte buffer are the service's, like the pinned one: a
+                # fresh 128 MB block and a fresh stream per step cost the first steps of a fit
+                # 20 ms each until the allocator's pool had grown)
+                side = None
+                if on_gpu:
+                    if self._side is None or self._side.device != dev:
+                        self._side = torch.cuda.Stream(device=dev)
+                    side = self._side
+                    side.wait_stream(torch.cuda.current_stream(dev))   # (the last step's widening read it)
+                if self._dev8 is None or self._dev8.device != dev or self._dev8.numel() < nm * n:
+                    self._dev8 = torch.empty(nm * n, dtype=torch.int8, device=dev)
+                dev8 = self._dev8[:nm * n].view(nm, n)
                 pieces = [(a, min(nm, a + max(1, (nm + 3) // 4))) for a in range(0, nm, max(1, (nm + 3) // 4))]
                 state = {'ok': True, 'error': None}
 
@@ -174,7 +186,6 @@ class StochasticDerivService:
                 if state['error'] is not None:
                     raise state['error']
                 if on_gpu:
-                    dev8.record_stream(side)
                     torch.cuda.current_stream(dev).wait_stream(side)
                 if state['ok']:
                     narrow = dev8
