@@ -293,14 +293,140 @@ k_hz_map(const double* __restrict__ S, const double* __restrict__ Zt, int nvec, 
         if (v0 + q < nvec) P[((size_t)blockIdx.z * nvec + v0 + q) * Dr + e] = acc[q];
 }
 //   grid (ceil(D R / 256), nvec)   block 256
+// (nvp > 0: the layout of k_hz_expand_mm at the end of this file instead, zT[a][48 k + i][v] with rows
+// of nvp vectors, entries of vectors nvec .. nvp - 1 zero)
 static __global__ void __launch_bounds__(256)
 k_hz_collect(const double* __restrict__ P, int nvec, int D, int NB, int slices,
-             double* __restrict__ zhat) {
+             double* __restrict__ zhat, int nvp = 0) {
     const int R = NB * RL_HZ_BLK, Dr = D * R;
     const int e = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
     if (e >= Dr) return;
+    if (nvp > 0) {
+        double s = 0.0;
+        if (v < nvec)
+            for (int t = 0; t < slices; ++t) s += P[((size_t)t * nvec + v) * Dr + e];
+        zhat[(size_t)e * nvp + v] = s;            // (e = a R + degree)
+        return;
+    }
     double s = 0.0;
     for (int t = 0; t < slices; ++t) s += P[((size_t)t * nvec + v) * Dr + e];
     const int a = e / R, ig = e - a * R, k = ig / RL_HZ_BLK, i = ig - k * RL_HZ_BLK;
     zhat[(((size_t)k * nvec + v) * D + a) * RL_HZ_BLK + i] = s;
+}
+
+// ---------------------------------------------------------------------------
+// k_hz_expand_mm<NVT>: out[v][i] = diag[i] X2[v][i] + sum_{j < R} F[j][i] zT[d(i)][j][v] for ALL
+// R = 48 NB functions of the larger basis in one pass over the rows, on the fp64 matrix cores.
+// The rank-48 expansion keeps 48 values of F per row in registers and streams the vectors, so R
+// functions took R / 48 passes, each reading the previous one's output and writing its own (four
+// passes at C5: 2.55 ms an application, 9.8 GB).  As a product  D(vectors x rows) += A(vectors x
+// degrees) B(degrees x rows)  the accumulators of 16 vectors x 16 rows are four registers a lane,
+// so a wave holds ALL the batch's vectors for 32 rows and walks the degrees once:
+//   A[v][k] = zT[d][j0 + k][v0 + v]   (lane v + 16 k; the coefficients transposed, [D][R][nvp],
+//             nvp = nvec rounded up to 16: 221 KB per output at C5 -- L2)
+//   B[k][i] = F[j0 + k][i0 + i]       (lane i + 16 k: 16 consecutive rows of the degree-major table)
+//   D: register r of lane l = vector (l >> 4) + 4 r, row l & 15 -- loads of X2 and stores of out are
+//      16 consecutive rows of one vector per quarter wave.
+// (Operand layouts: rl_rowpoly.h.)  A 16-row tile that straddles outputs runs the degrees once per
+// output with the other outputs' rows of B zeroed.  Vector tiles beyond nvp / 16 are skipped.
+//   grid (ceil(n / 128), ceil(nvp / (16 NVT)))   block 256: wave w owns rows 32 w .. 32 w + 31
+// (emulator: a thread owns a row and sums the degrees itself)
+// ---------------------------------------------------------------------------
+template <int NVT>
+__global__ void __launch_bounds__(256)
+k_hz_expand_mm(const double* __restrict__ zT, const double* __restrict__ F, int n, int nvec, int nvp,
+               int D, int R, const int* __restrict__ out_end, double* __restrict__ out,
+               const double* __restrict__ diag, const double* __restrict__ X2) {
+    const int tid = threadIdx.x;
+    const int vt0 = blockIdx.y * NVT, nvt = nvp / 16 - vt0 < NVT ? nvp / 16 - vt0 : NVT;
+#if !defined(RL_EMU)
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int r0 = blockIdx.x * 128 + wave * 32;
+    if (r0 >= n) return;
+    rp_double4 C[2][NVT];
+    // C = diag (.) X2
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int i = r0 + 16 * rt + li;
+        const double dg = i < n ? diag[i] : 0.0;
+#pragma unroll
+        for (int t = 0; t < NVT; ++t) {
+            rp_double4 c = rp_double4{0.0, 0.0, 0.0, 0.0};
+            if (t < nvt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v = (vt0 + t) * 16 + lk + 4 * r;
+                    c[r] = i < n && v < nvec ? dg * X2[(size_t)v * n + i] : 0.0;
+                }
+            }
+            C[rt][t] = c;
+        }
+    }
+    const int rlast = r0 + 31 < n ? r0 + 31 : n - 1;
+    const int dlo = RL_LR_UNIFORM(rp_output_of(out_end, D, r0));
+    const int dhi = RL_LR_UNIFORM(rp_output_of(out_end, D, rlast));
+    const int ia = r0 + li, ib = r0 + 16 + li;
+    const int da = dlo == dhi ? dlo : rp_output_of(out_end, D, ia < n ? ia : n - 1);
+    const int db = dlo == dhi ? dlo : rp_output_of(out_end, D, ib < n ? ib : n - 1);
+    for (int d = dlo; d <= dhi; ++d) {
+        const bool ona = ia < n && da == d, onb = ib < n && db == d;
+        const double* fa = F + (size_t)lk * n + (ia < n ? ia : n - 1);
+        const double* fb = F + (size_t)lk * n + (ib < n ? ib : n - 1);
+        const double* za = zT + ((size_t)d * R + lk) * nvp + (size_t)vt0 * 16 + li;
+        // (operands of the NEXT four degrees are requested before this step's 2 NVT matrix
+        // instructions are issued: without that every step waited for its own loads -- 3.05 ms an
+        // application against the four passes' 2.55)
+        double a[NVT], b0 = ona ? fa[0] : 0.0, b1 = onb ? fb[0] : 0.0;
+#pragma unroll
+        for (int t = 0; t < NVT; ++t) a[t] = t < nvt ? za[16 * t] : 0.0;
+#pragma unroll 2
+        for (int j0 = 0; j0 < R; j0 += 4) {
+            const int jn = j0 + 4 < R ? j0 + 4 : j0;
+            double an[NVT];
+            const double* zj = za + (size_t)jn * nvp;
+#pragma unroll
+            for (int t = 0; t < NVT; ++t) an[t] = t < nvt ? zj[16 * t] : 0.0;
+            const double b0n = ona ? fa[(size_t)jn * n] : 0.0;
+            const double b1n = onb ? fb[(size_t)jn * n] : 0.0;
+#pragma unroll
+            for (int t = 0; t < NVT; ++t) {
+                if (t < nvt) {
+                    C[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b0, C[0][t], 0, 0, 0);
+                    C[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b1, C[1][t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NVT; ++t) a[t] = an[t];
+            b0 = b0n;
+            b1 = b1n;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int i = r0 + 16 * rt + li;
+#pragma unroll
+        for (int t = 0; t < NVT; ++t) {
+            if (t < nvt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v = (vt0 + t) * 16 + lk + 4 * r;
+                    if (i < n && v < nvec) out[(size_t)v * n + i] = C[rt][t][r];
+                }
+            }
+        }
+    }
+#else
+    if (tid >= 128) return;
+    const int i = blockIdx.x * 128 + tid;
+    if (i >= n) return;
+    const int d = rp_output_of(out_end, D, i);
+    for (int t = 0; t < nvt; ++t)
+        for (int q = 0; q < 16; ++q) {
+            const int v = (vt0 + t) * 16 + q;
+            if (v >= nvec) continue;
+            double acc = diag[i] * X2[(size_t)v * n + i];
+            for (int j = 0; j < R; ++j) acc = fma(F[(size_t)j * n + i], zT[((size_t)d * R + j) * nvp + v], acc);
+            out[(size_t)v * n + i] = acc;
+        }
+#endif
 }

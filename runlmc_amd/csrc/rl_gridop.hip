@@ -100,6 +100,7 @@ RlKnobs read_knobs() {
     k.no_lr_small = flag("RUNLMC_NO_LR_SMALL");
     k.no_precond_approx = flag("RUNLMC_NO_PRECOND_APPROX");
     k.no_precond_hi = flag("RUNLMC_NO_PRECOND_HI");
+    k.precond_hi_passes = flag("RUNLMC_PRECOND_HI_PASSES");
     k.no_precond_hi_mixed = flag("RUNLMC_NO_PRECOND_HI_MIXED");
     k.precond_hi_min = num("RUNLMC_PRECOND_HI_MIN", 100000);
     k.precond_hi_rank = (int)num("RUNLMC_PRECOND_HI_RANK", 192);

@@ -97,6 +97,8 @@ struct RlKnobs {
     int precond_hi_use = 0;           // RUNLMC_PRECOND_HI_USE: functions of it a factorisation uses (0: the library's rule)
     int precond_hi_rank = 192;         // RUNLMC_PRECOND_HI_RANK: its basis size (whole blocks of 48)
     bool no_precond_hi_mixed = false; // RUNLMC_NO_PRECOND_HI_MIXED: ... but not operators with SOME rows in the polynomial form
+    bool precond_hi_passes = false;   // RUNLMC_PRECOND_HI_PASSES: its expansion block by block through the rank-48
+                                      // kernel (as first built) instead of k_hz_expand_mm's one pass (A/B)
     bool no_precond_hi = false;       // RUNLMC_NO_PRECOND_HI: operators without a polynomial row keep the 48-function
                                       // preconditioner (not the 96-function one of rl_solve.hip: hz_*)
     int rp_fly = 1;              // RUNLMC_RP_FLY: bit 0: k_rp_expand computes F from the interpolation entries,

@@ -1144,8 +1144,8 @@ static int hz_reserve(rl_ski* s, int nvec) {
     s->hz_vec_cap = 0;
     const size_t nb = (size_t)s->hz_R / RL_HZ_BLK;
     RL_TRY(hz_grow(&s->hz_part, nb * s->rp_nruns * cap * RL_HZ_BLK));
-    RL_TRY(hz_grow(&s->hz_zhat, nb * cap * s->g->D * RL_HZ_BLK));
-    RL_TRY(hz_grow(&s->hz_tmp, cap * s->n));
+    RL_TRY(hz_grow(&s->hz_zhat, nb * (cap + 16) * s->g->D * RL_HZ_BLK));
+    RL_TRY(hz_grow(&s->hz_tmp, cap * s->n));      // (the block-by-block expansion's)
     RL_TRY(hz_grow(&s->hz_S, cap * s->g->D * s->hz_R));
     RL_TRY(hz_grow(&s->hz_P, (size_t)RL_HZ_FS * cap * s->g->D * s->hz_R));
     s->hz_vec_cap = cap;
@@ -1366,7 +1366,25 @@ static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStrea
     RL_LAUNCH(k_hz_map, dim3((Dr + 255) / 256, (nvec + RL_HZ_VB - 1) / RL_HZ_VB, RL_HZ_FS), dim3(256),
               (size_t)per * RL_HZ_VB * sizeof(double), st, (const double*)s->hz_S, map,
               nvec, Dr, s->hz_P);
-    RL_LAUNCH(k_hz_collect, egrid, dim3(256), 0, st, (const double*)s->hz_P, nvec, D, NB, RL_HZ_FS, s->hz_zhat);
+    if (!s->kn.precond_hi_passes && NB >= 3) {
+        // ONE pass over the rows for all blocks, on the matrix cores (k_hz_expand_mm): the vectors
+        // cross the fabric once -- in, out -- and the table once.  C5, 129 vectors: 2.05 ms for four
+        // blocks against 4 x 0.64 ms block by block (solve 0.337 against 0.355 s); for TWO blocks
+        // 1.45 against 2 x 0.63 ms -- those stay on the rank-48 kernel below.
+        const int nvp = (nvec + 15) / 16 * 16, nvt = nvp / 16;
+        RL_LAUNCH(k_hz_collect, dim3((Dr + 255) / 256, nvp), dim3(256), 0, st, (const double*)s->hz_P, nvec, D, NB,
+                  RL_HZ_FS, s->hz_zhat, nvp);
+        const dim3 xgrid((n + 127) / 128, (nvt + 8) / 9), xgrid2((n + 127) / 128, (nvt + 1) / 2);
+        if (nvt <= 2)
+            RL_LAUNCH((k_hz_expand_mm<2>), xgrid2, dim3(256), 0, st, (const double*)s->hz_zhat, (const double*)s->hz_F,
+                      n, nvec, nvp, D, s->hz_Ruse, (const int*)s->rp_out_end, out, diag, in);
+        else
+            RL_LAUNCH((k_hz_expand_mm<9>), xgrid, dim3(256), 0, st, (const double*)s->hz_zhat, (const double*)s->hz_F,
+                      n, nvec, nvp, D, s->hz_Ruse, (const int*)s->rp_out_end, out, diag, in);
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
+    RL_LAUNCH(k_hz_collect, egrid, dim3(256), 0, st, (const double*)s->hz_P, nvec, D, NB, RL_HZ_FS, s->hz_zhat, 0);
     // (a pass over the rows per block, each adding to the one before through the noise term's
     // operand with a diagonal of ones: not in place -- the kernel's pointers are declared not
     // to alias -- but alternating between `out` and one more buffer so that the last lands in out)

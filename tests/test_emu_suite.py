@@ -219,6 +219,13 @@ def test_precond_hi():
     ps.check_precond_hi()
 
 
+def test_precond_hi_three_blocks(monkeypatch):
+    """144 functions: the one-pass matrix-core expansion (k_hz_expand_mm, from three blocks on)."""
+    monkeypatch.setenv('RUNLMC_PRECOND_HI_RANK', '144')
+    out = ps.check_precond_hi(m_data=1400)
+    assert out['hi', 3] <= 8, out
+
+
 def test_logdet_preconditioned():
     ps.check_logdet_preconditioned()
 
