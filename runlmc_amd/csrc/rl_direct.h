@@ -321,7 +321,7 @@ k_hz_collect(const double* __restrict__ P, int nvec, int D, int NB, int slices,
 // functions took R / 48 passes, each reading the previous one's output and writing its own (four
 // passes at C5: 2.55 ms an application, 9.8 GB).  As a product  D(vectors x rows) += A(vectors x
 // degrees) B(degrees x rows)  the accumulators of 16 vectors x 16 rows are four registers a lane,
-// so a wave holds ALL the batch's vectors for 32 rows and walks the degrees once:
+// so a wave holds ALL the batch's vectors for 16 RT rows and walks the degrees once:
 //   A[v][k] = zT[d][j0 + k][v0 + v]   (lane v + 16 k; the coefficients transposed, [D][R][nvp],
 //             nvp = nvec rounded up to 16: 221 KB per output at C5 -- L2)
 //   B[k][i] = F[j0 + k][i0 + i]       (lane i + 16 k: 16 consecutive rows of the degree-major table)
@@ -329,24 +329,26 @@ k_hz_collect(const double* __restrict__ P, int nvec, int D, int NB, int slices,
 //      16 consecutive rows of one vector per quarter wave.
 // (Operand layouts: rl_rowpoly.h.)  A 16-row tile that straddles outputs runs the degrees once per
 // output with the other outputs' rows of B zeroed.  Vector tiles beyond nvp / 16 are skipped.
-//   grid (ceil(n / 128), ceil(nvp / (16 NVT)))   block 256: wave w owns rows 32 w .. 32 w + 31
+//   grid (ceil(n / (64 RT)), ceil(nvp / (16 NVT)))   block 256: wave w owns 16 RT rows (RT = 2: 144
+//   accumulation registers, two waves a SIMD, 2.05 ms at C5; RT = 3: 216, one wave, 2.73 ms)
 // (emulator: a thread owns a row and sums the degrees itself)
 // ---------------------------------------------------------------------------
-template <int NVT>
+template <int NVT, int RT = 2>
 __global__ void __launch_bounds__(256)
 k_hz_expand_mm(const double* __restrict__ zT, const double* __restrict__ F, int n, int nvec, int nvp,
                int D, int R, const int* __restrict__ out_end, double* __restrict__ out,
                const double* __restrict__ diag, const double* __restrict__ X2) {
     const int tid = threadIdx.x;
     const int vt0 = blockIdx.y * NVT, nvt = nvp / 16 - vt0 < NVT ? nvp / 16 - vt0 : NVT;
+    constexpr int WR = 16 * RT;                     // rows of a wave
 #if !defined(RL_EMU)
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const int r0 = blockIdx.x * 128 + wave * 32;
+    const int r0 = blockIdx.x * (4 * WR) + wave * WR;
     if (r0 >= n) return;
-    rp_double4 C[2][NVT];
+    rp_double4 C[RT][NVT];
     // C = diag (.) X2
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const int i = r0 + 16 * rt + li;
         const double dg = i < n ? diag[i] : 0.0;
 #pragma unroll
@@ -362,47 +364,56 @@ k_hz_expand_mm(const double* __restrict__ zT, const double* __restrict__ F, int 
             C[rt][t] = c;
         }
     }
-    const int rlast = r0 + 31 < n ? r0 + 31 : n - 1;
+    const int rlast = r0 + WR - 1 < n ? r0 + WR - 1 : n - 1;
     const int dlo = RL_LR_UNIFORM(rp_output_of(out_end, D, r0));
     const int dhi = RL_LR_UNIFORM(rp_output_of(out_end, D, rlast));
-    const int ia = r0 + li, ib = r0 + 16 + li;
-    const int da = dlo == dhi ? dlo : rp_output_of(out_end, D, ia < n ? ia : n - 1);
-    const int db = dlo == dhi ? dlo : rp_output_of(out_end, D, ib < n ? ib : n - 1);
+    int irow[RT], drow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        irow[rt] = r0 + 16 * rt + li;
+        drow[rt] = dlo == dhi ? dlo : rp_output_of(out_end, D, irow[rt] < n ? irow[rt] : n - 1);
+    }
     for (int d = dlo; d <= dhi; ++d) {
-        const bool ona = ia < n && da == d, onb = ib < n && db == d;
-        const double* fa = F + (size_t)lk * n + (ia < n ? ia : n - 1);
-        const double* fb = F + (size_t)lk * n + (ib < n ? ib : n - 1);
+        bool on[RT];
+        const double* fr[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            on[rt] = irow[rt] < n && drow[rt] == d;
+            fr[rt] = F + (size_t)lk * n + (irow[rt] < n ? irow[rt] : n - 1);
+        }
         const double* za = zT + ((size_t)d * R + lk) * nvp + (size_t)vt0 * 16 + li;
-        // (operands of the NEXT four degrees are requested before this step's 2 NVT matrix
+        // (operands of the NEXT four degrees are requested before this step's RT NVT matrix
         // instructions are issued: without that every step waited for its own loads -- 3.05 ms an
         // application against the four passes' 2.55)
-        double a[NVT], b0 = ona ? fa[0] : 0.0, b1 = onb ? fb[0] : 0.0;
+        double a[NVT], b[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) b[rt] = on[rt] ? fr[rt][0] : 0.0;
 #pragma unroll
         for (int t = 0; t < NVT; ++t) a[t] = t < nvt ? za[16 * t] : 0.0;
-#pragma unroll 2
         for (int j0 = 0; j0 < R; j0 += 4) {
             const int jn = j0 + 4 < R ? j0 + 4 : j0;
-            double an[NVT];
+            double an[NVT], bn[RT];
             const double* zj = za + (size_t)jn * nvp;
 #pragma unroll
             for (int t = 0; t < NVT; ++t) an[t] = t < nvt ? zj[16 * t] : 0.0;
-            const double b0n = ona ? fa[(size_t)jn * n] : 0.0;
-            const double b1n = onb ? fb[(size_t)jn * n] : 0.0;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) bn[rt] = on[rt] ? fr[rt][(size_t)jn * n] : 0.0;
 #pragma unroll
             for (int t = 0; t < NVT; ++t) {
                 if (t < nvt) {
-                    C[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b0, C[0][t], 0, 0, 0);
-                    C[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b1, C[1][t], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        C[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[rt], C[rt][t], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int t = 0; t < NVT; ++t) a[t] = an[t];
-            b0 = b0n;
-            b1 = b1n;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) b[rt] = bn[rt];
         }
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const int i = r0 + 16 * rt + li;
 #pragma unroll
         for (int t = 0; t < NVT; ++t) {
@@ -416,8 +427,8 @@ k_hz_expand_mm(const double* __restrict__ zT, const double* __restrict__ F, int 
         }
     }
 #else
-    if (tid >= 128) return;
-    const int i = blockIdx.x * 128 + tid;
+    if (tid >= 4 * WR) return;
+    const int i = blockIdx.x * (4 * WR) + tid;
     if (i >= n) return;
     const int d = rp_output_of(out_end, D, i);
     for (int t = 0; t < nvt; ++t)
