@@ -52,11 +52,13 @@ print('pcg', itm, rsm, stm)
 # 3b. the larger preconditioner basis (96 functions here: m >= 768; hz_* in rl_solve.hip, k_hz_sums / k_hz_map /
 #     k_hz_collect, the table arguments of k_rp_project<48> / k_rp_expand<48>): Matern rows alone, then mixed rows
 os.environ['RUNLMC_PRECOND_HI_MIN'] = '0'
-for kern, Qh in (('matern', 2), ('mix', 3)):
-    ph = synth.make_problem(3, Qh, 1, 1001, kern=kern)
+for kern, Qh, mh, rank, Dh in (('matern', 2, 1001, 96, 3), ('mix', 3, 1001, 96, 3), ('matern', 2, 1501, 144, 2)):
+    # (144 functions = three blocks: the one-pass expansion k_hz_expand_mm and k_hz_collect's transposed layout)
+    os.environ['RUNLMC_PRECOND_HI_RANK'] = str(rank)
+    ph = synth.make_problem(Dh, Qh, 1, mh, kern=kern)
     gh = GridOp(ph.D, ph.m, ph.Q); gh.set_lmc(synth.tops(ph), list(ph.coreg_vecs), list(ph.coreg_diags))
     sh = SkiOp(gh, ph.W, ph.WT); sh.set_noise(ph.noise, ph.lens)
-    print('factor (%s, larger basis)' % kern, sh.factor(), sh.factor_mode, gh.top_forms())
+    print('factor (%s, larger basis, up to %d functions)' % (kern, rank), sh.factor(), sh.factor_mode, gh.top_forms())
     for nb in (2, 19):
         Bh = torch.from_numpy(np.vstack([ph.y] + [rng.randint(0, 2, ph.n) * 2.0 - 1 for _ in range(nb - 1)]))
         Xh, ith, rsh, sth = solve_pcg(sh, Bh, tol=1e-8)
@@ -71,6 +73,7 @@ for kern, Qh in (('matern', 2), ('mix', 3)):
     print('after an update', sh.factor(), sh.factor_mode, sh.precond_sample(Wh[:2])[1])
     del sh, gh
 os.environ.pop('RUNLMC_PRECOND_HI_MIN')
+os.environ.pop('RUNLMC_PRECOND_HI_RANK')
 gm.set_form_gate(0)
 Xg = rng.randn(4, pm.D * pm.m)
 print('filter product (gate 0)', np.abs(gm.matmat_host(Xg)).max())
