@@ -330,7 +330,8 @@ k_hz_collect(const double* __restrict__ P, int nvec, int D, int NB, int slices,
 // (Operand layouts: rl_rowpoly.h.)  A 16-row tile that straddles outputs runs the degrees once per
 // output with the other outputs' rows of B zeroed.  Vector tiles beyond nvp / 16 are skipped.
 //   grid (ceil(n / (64 RT)), ceil(nvp / (16 NVT)))   block 256: wave w owns 16 RT rows (RT = 2: 144
-//   accumulation registers, two waves a SIMD, 2.05 ms at C5; RT = 3: 216, one wave, 2.73 ms)
+//   accumulation registers, two waves a SIMD, 1.83 ms at C5; RT = 3: 216, one wave, 2.73 ms with one
+//   step of request-ahead where RT = 2 took 2.05)
 // (emulator: a thread owns a row and sums the degrees itself)
 // ---------------------------------------------------------------------------
 template <int NVT, int RT = 2>
@@ -385,31 +386,32 @@ k_hz_expand_mm(const double* __restrict__ zT, const double* __restrict__ F, int 
         // (operands of the NEXT four degrees are requested before this step's RT NVT matrix
         // instructions are issued: without that every step waited for its own loads -- 3.05 ms an
         // application against the four passes' 2.55)
-        double a[NVT], b[RT];
+        // a ring of three operand sets: step s computes on set s % 3 while the loads of steps s + 1
+        // and s + 2 are in flight (R / 4 is a multiple of 3 for every basis size: 24, 36, 48 steps)
+        double a[3][NVT], b[3][RT];
+        auto request = [&](int slot, int j) {
+            const int jc = j < R ? j : R - 4;
+            const double* zj = za + (size_t)jc * nvp;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) b[rt] = on[rt] ? fr[rt][0] : 0.0;
+            for (int t = 0; t < NVT; ++t) a[slot][t] = t < nvt ? zj[16 * t] : 0.0;
 #pragma unroll
-        for (int t = 0; t < NVT; ++t) a[t] = t < nvt ? za[16 * t] : 0.0;
-        for (int j0 = 0; j0 < R; j0 += 4) {
-            const int jn = j0 + 4 < R ? j0 + 4 : j0;
-            double an[NVT], bn[RT];
-            const double* zj = za + (size_t)jn * nvp;
+            for (int rt = 0; rt < RT; ++rt) b[slot][rt] = on[rt] ? fr[rt][(size_t)jc * n] : 0.0;
+        };
+        request(0, 0);
+        request(1, 4);
+        for (int j0 = 0; j0 < R; j0 += 12) {
 #pragma unroll
-            for (int t = 0; t < NVT; ++t) an[t] = t < nvt ? zj[16 * t] : 0.0;
+            for (int u = 0; u < 3; ++u) {
+                request((u + 2) % 3, j0 + 4 * u + 8);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) bn[rt] = on[rt] ? fr[rt][(size_t)jn * n] : 0.0;
+                for (int t = 0; t < NVT; ++t) {
+                    if (t < nvt) {
 #pragma unroll
-            for (int t = 0; t < NVT; ++t) {
-                if (t < nvt) {
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        C[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[rt], C[rt][t], 0, 0, 0);
+                        for (int rt = 0; rt < RT; ++rt)
+                            C[rt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], b[u][rt], C[rt][t], 0, 0, 0);
+                    }
                 }
             }
-#pragma unroll
-            for (int t = 0; t < NVT; ++t) a[t] = an[t];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) b[rt] = bn[rt];
         }
     }
 #pragma unroll

@@ -1368,8 +1368,8 @@ static int hz_apply(rl_ski* s, const double* in, double* out, int nvec, hipStrea
               nvec, Dr, s->hz_P);
     if (!s->kn.precond_hi_passes && NB >= 3) {
         // ONE pass over the rows for all blocks, on the matrix cores (k_hz_expand_mm): the vectors
-        // cross the fabric once -- in, out -- and the table once.  C5, 129 vectors: 2.05 ms for four
-        // blocks against 4 x 0.64 ms block by block (solve 0.337 against 0.355 s); for TWO blocks
+        // cross the fabric once -- in, out -- and the table once.  C5, 129 vectors: 1.83 ms for four
+        // blocks against 4 x 0.64 ms block by block (solve 0.336 against 0.355 s); for TWO blocks
         // 1.45 against 2 x 0.63 ms -- those stay on the rank-48 kernel below.
         const int nvp = (nvec + 15) / 16 * 16, nvt = nvp / 16;
         RL_LAUNCH(k_hz_collect, dim3((Dr + 255) / 256, nvp), dim3(256), 0, st, (const double*)s->hz_P, nvec, D, NB,
