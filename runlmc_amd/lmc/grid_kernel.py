@@ -205,26 +205,33 @@ class FactoredInverse(Matrix):
     LOGDET_PROBES = 16
     LOGDET_SEED = 20240607
 
-    def logdet_estimate(self, n_probes=None, tol=1e-4, maxiter=0, seed=None):
+    def logdet_estimate(self, n_probes=None, tol=1e-4, maxiter=0, seed=None, group=None):
         """log det K~ when the factorisation is a PRECONDITIONER (include/runlmc_hip.h,
         rl_ski_precond_sample):  log det P  exactly  +  Hutchinson / Lanczos-quadrature estimate of
         tr log(P^-1/2 K~ P^-1/2)  from a few extra conjugate-gradient solves whose right-hand sides
         are +-1 rows mapped to covariance P.  Returns (estimate, standard error of the mean,
-        iterations of those solves).  Every rank draws the same rows (fixed seed): the same value
-        everywhere, no collective."""
+        iterations of this rank's solves).  Every rank draws the same rows (fixed seed); with a
+        process group each solves rows rank, rank + world, ... and ONE all-reduce of (sum, sum of
+        squares) gives every rank the same estimate."""
         from .._native import solve_pcg_lanczos, slq_quadratic_forms
         if self.exact:
             return self.logdet(), 0.0, np.zeros(0, dtype=np.int32)
         N = int(n_probes or self.LOGDET_PROBES)
         gen = torch.Generator().manual_seed(self.LOGDET_SEED if seed is None else int(seed))
         W = (torch.randint(0, 2, (N, self._skiop.n), generator=gen, dtype=torch.int8) * 2 - 1)
-        W = W.to(self._skiop.device).to(torch.float64)
+        from ..util.dist import rank_world, all_reduce_sum_
+        rank, world = rank_world(group)
+        W = W[rank::world].contiguous().to(self._skiop.device).to(torch.float64)
         R, ld_p = self._skiop.precond_sample(W)
         cap = int(min(max(maxiter or 1024, 1), 4096))
         X, it, res, st, lz, sq = solve_pcg_lanczos(self._skiop, R, tol=tol, maxiter=maxiter, cap=cap)
         quad = slq_quadratic_forms(lz, it, sq, lib=self._skiop.lib)
-        sem = float(np.std(quad, ddof=1) / np.sqrt(N)) if N > 1 else float('nan')
-        return ld_p + float(np.mean(quad)), sem, it
+        sums = torch.tensor([float(np.sum(quad)), float(np.sum(quad * quad))], dtype=torch.float64)
+        all_reduce_sum_(sums, group)                      # (no-op in a world of one)
+        mean = float(sums[0]) / N
+        var = max(float(sums[1]) / N - mean * mean, 0.0) * N / (N - 1) if N > 1 else float('nan')
+        sem = float(np.sqrt(var / N)) if N > 1 else float('nan')
+        return ld_p + mean, sem, it
 
     def matmat_device(self, X):
         if not self.exact:

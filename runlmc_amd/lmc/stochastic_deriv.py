@@ -214,8 +214,8 @@ class StochasticDerivService:
                 # (preconditioned CG through an INEXACT factorisation: no Lanczos recurrence of K~
                 # ran and the factorisation's log det is not the operator's -- asked for, the log
                 # det comes from a few extra preconditioned solves, FactoredInverse.logdet_estimate)
-                tol = self._tol
-                logdet_fn = lambda: M.logdet_estimate(tol=tol)    # noqa: E731
+                tol, grp = self._tol, self._group
+                logdet_fn = lambda: M.logdet_estimate(tol=tol, group=grp)    # noqa: E731
         else:
             lanczos = lanczos[order]
         if self.metrics is not None:

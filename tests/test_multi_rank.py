@@ -181,7 +181,7 @@ def _grads_matern(world_group=None):
                           [np.ravel(g) for g in lik.coreg_diags_gradients()] +
                           [np.ravel(g) for g in lik.kernel_gradients()] +
                           [lik.noise_gradient()])
-    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy()
+    return flat, lik.deriv.rs_dev.shape[0], lik.deriv.alpha.copy(), lik.log_det_K(), lik.deriv.logdet_precond[1]
 
 
 def _worker_matern(rank, world, port, q):
@@ -191,8 +191,8 @@ def _worker_matern(rank, world, port, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from runlmc_amd import _lib, build
     _lib.use_library(build.EMU_LIB)
-    flat, nloc, alpha = _grads_matern()
-    q.put((rank, flat, nloc, alpha))
+    flat, nloc, alpha, ld, sem = _grads_matern(dist.group.WORLD)
+    q.put((rank, flat, nloc, alpha, ld, sem))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -207,7 +207,7 @@ def test_two_rank_preconditioned_path():
     _lib.use_library(build.build_emu())
     saved = {k: os.environ.get(k) for k in ('RUNLMC_DEBUG', 'RUNLMC_PRECOND_HI_MIN')}
     try:
-        ref, nall, alpha_ref = _grads_matern()
+        ref, nall, alpha_ref, ld_ref, sem_ref = _grads_matern()
     finally:
         _lib.use_library(None)
         for k, v in saved.items():
@@ -230,6 +230,10 @@ def test_two_rank_preconditioned_path():
     assert np.array_equal(got[0][1], got[1][1])            # the assembled gradient
     assert np.abs(got[0][1] - ref).max() < 1e-7 * np.abs(ref).max()
     assert np.abs(got[0][3] - alpha_ref).max() < 1e-8 * np.abs(alpha_ref).max()
+    # the preconditioned log det: its 16 probes dealt to the ranks, one all-reduce of (sum, sum of
+    # squares) -- the same value on both ranks, the one-rank value to roundoff
+    assert got[0][4] == got[1][4] and got[0][5] == got[1][5]
+    assert abs(got[0][4] - ld_ref) <= 1e-9 * abs(ld_ref) and abs(got[0][5] - sem_ref) <= 1e-6 * sem_ref
 
 
 def _grads_n(n_probes):
